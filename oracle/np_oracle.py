@@ -1,0 +1,242 @@
+"""NumPy restatement of the reference hot path (oracle; test infrastructure only).
+
+Every function cites the reference lines it restates (paths relative to the
+upstream tree mounted read-only at /root/reference in the build container).
+
+Pinning status
+--------------
+* Network rows (A4-A10: LSTM stack, BatchNorm, Linear heads, normalise,
+  sigmoid): PINNED.  ``tools/gen_golden.py`` imports the reference's own
+  ``onssen.nn`` modules on torch-CPU in the build container, loads this
+  repo's deterministic weights into them and commits inputs + outputs under
+  ``tests/golden/``; ``tests/test_oracle.py`` checks this file against them.
+* Front/back end (A1-A3, A11: STFT / log-magnitude / phase / mask + iSTFT):
+  **parity unpinned** by the reference.  The arithmetic lives in the
+  third-party package ``librosa`` (un-vendored, version un-pinned; the call
+  signatures used at onssen/data/feature_utils.py:19,39-44 imply < 0.10) and
+  the reference holds no test or golden vector for it.  The restatement
+  below follows librosa 0.7/0.8 ``core.stft`` / ``core.istft`` semantics and
+  is cross-checked against ``torch.stft`` / ``torch.istft`` (an independent
+  implementation) in ``tests/test_oracle.py``.
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------
+# Front end  (onssen/data/feature_utils.py)
+# --------------------------------------------------------------------------
+
+def hann_periodic(n):
+    """scipy.signal.get_window('hann', n, fftbins=True) (what librosa's
+    default window='hann' resolves to), float64."""
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+
+
+def stft(sig, n_fft, hop):
+    """onssen/data/feature_utils.py:20  ``np.transpose(librosa.core.stft(sig,
+    n_fft=window_size, hop_length=hop_size))``.
+
+    librosa<0.10 defaults: win_length=n_fft, window='hann' (periodic),
+    center=True, pad_mode='reflect'; frames = 1 + len(sig)//hop; the windowed
+    frames are float64 (float32 signal x float64 window), rfft in float64,
+    result stored as complex64.  Returns (T, F) complex64.
+    """
+    sig = np.asarray(sig, dtype=np.float32)
+    pad = n_fft // 2
+    y = np.pad(sig, pad, mode="reflect")
+    n_frames = 1 + (len(y) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = y[idx].astype(np.float64) * hann_periodic(n_fft)[None, :]
+    return np.fft.rfft(frames, axis=1).astype(np.complex64)
+
+
+def log_magnitude(spec, epsilon=1e-7):
+    """onssen/data/feature_utils.py:49-51  ``np.log10(np.abs(stft)+epsilon)``
+    -> float32 for a complex64 input."""
+    return np.log10(np.abs(spec) + np.float32(epsilon)).astype(np.float32)
+
+
+def phase_re_im(spec):
+    """onssen/data/feature_utils.py:54-64 get_phase: stack (Re, Im) on a new
+    last axis -> (T, F, 2) float32.  (Raw parts, not a unit phasor.)"""
+    return np.stack([np.real(spec), np.imag(spec)], axis=-1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# Back end  (egs/wsj0-2mix/*/evaluate.py + librosa.core.istft)
+# --------------------------------------------------------------------------
+
+def istft(spec_tf, hop, length):
+    """``librosa.core.istft(stft_est[i].T, hop_length=hop, length=nsample)``
+    (egs/wsj0-2mix/deep_clustering/evaluate.py:45,
+    egs/wsj0-2mix/chimera/evaluate.py:43).
+
+    spec_tf: (T, F) complex.  n_fft = 2(F-1); periodic-Hann synthesis window;
+    overlap-add; divide by the window sum-of-squares where it exceeds
+    ``tiny``; drop the first n_fft//2 samples; fix length.  float64 result.
+    """
+    spec_tf = np.asarray(spec_tf)
+    T, F = spec_tf.shape
+    n_fft = 2 * (F - 1)
+    w = hann_periodic(n_fft)
+    exp_len = n_fft + hop * (T - 1)
+    y = np.zeros(exp_len, dtype=np.float64)
+    wss = np.zeros(exp_len, dtype=np.float64)
+    frames = np.fft.irfft(spec_tf.astype(np.complex128), n=n_fft, axis=1)
+    for t in range(T):
+        y[t * hop:t * hop + n_fft] += w * frames[t]
+        wss[t * hop:t * hop + n_fft] += w * w
+    nz = wss > np.finfo(np.float64).tiny
+    y[nz] /= wss[nz]
+    y = y[n_fft // 2:]
+    if len(y) >= length:
+        return y[:length]
+    return np.pad(y, (0, length - len(y)))
+
+
+def mask_istft(stft_mix, masks, hop, length):
+    """egs/wsj0-2mix/chimera/evaluate.py:34-43 (and deep_clustering/
+    evaluate.py:31-45 after the masks are built): ``stft_est = stft_mix *
+    mask``; one istft per speaker.  stft_mix (T,F) complex64, masks (C,T,F)
+    real.  Returns (C, length) float64."""
+    stft_mix = np.asarray(stft_mix)
+    masks = np.asarray(masks, dtype=np.float64)
+    return np.stack([istft(stft_mix * masks[c], hop, length)
+                     for c in range(masks.shape[0])])
+
+
+def dc_active_bins(feature_mix, db=40.0):
+    """egs/wsj0-2mix/deep_clustering/evaluate.py:36-37: bins with
+    ``feature >= max(feature) - 40/20`` take part in the clustering."""
+    return feature_mix >= (np.max(feature_mix) - db / 20.0)
+
+
+def dc_binary_masks(feature_mix, labels_active):
+    """egs/wsj0-2mix/deep_clustering/evaluate.py:36-41: mask[0]=label,
+    mask[1]=1-label on active bins, 0 on silent bins in both masks."""
+    act = dc_active_bins(feature_mix)
+    mask = np.zeros((2,) + feature_mix.shape, dtype=np.float64)
+    mask[0, act] = labels_active
+    mask[1, act] = 1 - labels_active
+    return mask
+
+
+# --------------------------------------------------------------------------
+# Network  (onssen/nn/*.py; PyTorch nn.LSTM / BatchNorm1d / Linear semantics)
+# --------------------------------------------------------------------------
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of one nn.LSTM layer (batch_first, zero initial state).
+    Gate row order in the 4H axis is i, f, g, o; the two bias vectors add.
+    x: (B, T, In) -> (B, T, H).  (onssen/nn/deep_clustering.py:15-22,35.)"""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    dt = x.dtype
+    gx = x @ w_ih.T + (b_ih + b_hh)
+    h = np.zeros((B, H), dtype=dt)
+    c = np.zeros((B, H), dtype=dt)
+    out = np.empty((B, T, H), dtype=dt)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        g = gx[:, t] + h @ w_hh.T
+        i = _sigmoid(g[:, 0:H])
+        f = _sigmoid(g[:, H:2 * H])
+        gg = np.tanh(g[:, 2 * H:3 * H])
+        o = _sigmoid(g[:, 3 * H:4 * H])
+        c = f * c + i * gg
+        h = o * np.tanh(c)
+        out[:, t] = h
+    return out
+
+
+def blstm_stack(x, sd, prefix, num_layers, collect=None):
+    """nn.LSTM(bidirectional=True, batch_first=True) in eval mode (inter-layer
+    dropout inactive): layer output = [forward | reverse] on the last axis,
+    which feeds the next layer.  ``sd`` is a reference-layout state_dict of
+    numpy arrays: {prefix}weight_ih_l{k}[_reverse] ..."""
+    for k in range(num_layers):
+        outs = []
+        for sfx, rev in (("", False), ("_reverse", True)):
+            outs.append(lstm_direction(
+                x,
+                sd[f"{prefix}weight_ih_l{k}{sfx}"], sd[f"{prefix}weight_hh_l{k}{sfx}"],
+                sd[f"{prefix}bias_ih_l{k}{sfx}"], sd[f"{prefix}bias_hh_l{k}{sfx}"], rev))
+        x = np.concatenate(outs, axis=-1)
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+def batchnorm_eval(x, sd, prefix, eps=1e-5):
+    """nn.BatchNorm1d(2H) in eval mode applied on the channel (last) axis of
+    (B,T,2H) (the reference permutes to (B,2H,T) and back,
+    onssen/nn/deep_clustering.py:36-38)."""
+    inv = 1.0 / np.sqrt(sd[prefix + "running_var"] + x.dtype.type(eps))
+    return (x - sd[prefix + "running_mean"]) * inv * sd[prefix + "weight"] + sd[prefix + "bias"]
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(p=2, dim=-1): x / max(||x||_2, eps)
+    (onssen/nn/deep_clustering.py:41)."""
+    n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True))
+    return x / np.maximum(n, x.dtype.type(eps))
+
+
+def num_layers_of(sd, prefix="rnn."):
+    k = 0
+    while f"{prefix}weight_ih_l{k}" in sd:
+        k += 1
+    return k
+
+
+def deep_clustering_forward(sd, x, dtype=np.float32, collect=None):
+    """onssen/nn/deep_clustering.py:29-43 (eval mode).  x (B,T,F) ->
+    embedding (B,T,F,D)."""
+    sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    x = np.asarray(x, dtype=dtype)
+    B, T, F = x.shape
+    r = blstm_stack(x, sd, "rnn.", num_layers_of(sd), collect)
+    r = batchnorm_eval(r, sd, "bn.")
+    if collect is not None:
+        collect.append(r)
+    e = r @ sd["fc_dc.weight"].T + sd["fc_dc.bias"]
+    e = l2_normalize(e.reshape(B, T * F, -1))
+    return e.reshape(B, T, F, -1)
+
+
+def chimera_forward(sd, x, dtype=np.float32, prefix=""):
+    """onssen/nn/chimera.py:30-46.  -> [embedding (B,T,F,D), mask_A, mask_B
+    (B,T,F)]; the fc_mi output index is f*C + c."""
+    sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    x = np.asarray(x, dtype=dtype)
+    B, T, F = x.shape
+    r = blstm_stack(x, sd, prefix + "rnn.", num_layers_of(sd, prefix + "rnn."))
+    e = r @ sd[prefix + "fc_dc.weight"].T + sd[prefix + "fc_dc.bias"]
+    e = l2_normalize(e.reshape(B, T * F, -1)).reshape(B, T, F, -1)
+    m = _sigmoid(r @ sd[prefix + "fc_mi.weight"].T + sd[prefix + "fc_mi.bias"])
+    m = m.reshape(B, T, F, -1)
+    return [e, m[..., 0], m[..., 1]]
+
+
+def phase_net_forward(sd, x_mag, x_phase, dtype=np.float32):
+    """onssen/nn/phase_network.py:34-67 with the only shape-consistent value
+    of its undefined free variable (output_dim = input_dim)."""
+    sdf = {k: np.asarray(v, dtype=dtype) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    x_mag = np.asarray(x_mag, dtype=dtype)
+    x_phase = np.asarray(x_phase, dtype=dtype)
+    B, T, F = x_mag.shape
+    e, mA, mB = chimera_forward(sdf, x_mag, dtype, prefix="chimera.")
+    outs = []
+    L = num_layers_of(sdf, "rnn.")
+    for m in (mA, mB):
+        inp = np.concatenate([x_mag * m, x_phase.reshape(B, T, -1)], axis=2)
+        r = blstm_stack(inp, sdf, "rnn.", L)
+        r = batchnorm_eval(r, sdf, "bn.")
+        p = r @ sdf["fc_phase.weight"].T + sdf["fc_phase.bias"]
+        p = p.reshape(B, T, F, -1) + x_phase
+        outs.append(l2_normalize(p))
+    return [e, mA, mB, outs[0], outs[1]]

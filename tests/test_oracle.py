@@ -1,0 +1,106 @@
+"""The CPU oracle (oracle/np_oracle.py) against the committed golden vectors
+(outputs of the reference's own onssen.nn modules, tools/gen_golden.py) and
+against torch.stft/istft for the librosa-backed front/back end."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from onssen_amd.synthetic import make_state_dict, synth_mixture
+from oracle import np_oracle as O
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-30)
+
+
+def load_case(fn):
+    z = np.load(fn)
+    sd = make_state_dict(str(z["kind"]), int(z["F"]), int(z["H"]), int(z["L"]), int(z["D"]),
+                         int(z["C"]), seed=int(z["seed"]), gain=float(z["gain"]))
+    return z, sd
+
+
+@pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
+def test_dc_tiny_matches_reference(golden_dir, name):
+    z, sd = load_case(f"{golden_dir}/{name}.npz")
+    emb = O.deep_clustering_forward(sd, z["x"])
+    assert emb.shape == z["out_embedding"].shape
+    np.testing.assert_allclose(emb, z["out_embedding"], atol=2e-6, rtol=0)
+    assert rel_l2(emb, z["out_embedding"]).max() < 1e-5
+
+
+def test_chimera_tiny_matches_reference(golden_dir):
+    z, sd = load_case(f"{golden_dir}/g1_chimera_H32_L2.npz")
+    e, a, b = O.chimera_forward(sd, z["x"])
+    np.testing.assert_allclose(e, z["out_embedding"], atol=2e-6)
+    np.testing.assert_allclose(a, z["out_mask_A"], atol=2e-6)
+    np.testing.assert_allclose(b, z["out_mask_B"], atol=2e-6)
+
+
+def test_phase_net_tiny_matches_reference(golden_dir):
+    z, sd = load_case(f"{golden_dir}/g1_phase_net_H16_L2.npz")
+    outs = O.phase_net_forward(sd, z["x"], z["x_phase"])
+    for o, n in zip(outs, ["embedding", "mask_A", "mask_B", "phase_A", "phase_B"]):
+        # phase_* normalise a 2-vector that can be short: fp32 round-off is amplified there
+        np.testing.assert_allclose(o, z["out_" + n], atol=3e-5 if n.startswith("phase") else 3e-6, err_msg=n)
+
+
+def _logmag_input(seed, B, T):
+    return np.stack([O.log_magnitude(O.stft(synth_mixture(seed * 100 + b, (T - 1) * 64), 256, 64))
+                     for b in range(B)])
+
+
+def test_dc_full_size_matches_reference_subsample(golden_dir):
+    """cfg1 (DC 2xBLSTM-600) at full width: the oracle vs the reference's
+    strided output subsample and per-frame checksums."""
+    z, sd = load_case(f"{golden_dir}/g2_cfg1_dc_L2.npz")
+    x = _logmag_input(int(z["x_seed"]), int(z["B"]), int(z["T"]))
+    emb = O.deep_clustering_forward(sd, x)
+    np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5)
+    assert rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max() < 1e-4
+    np.testing.assert_allclose(emb.astype(np.float64).sum(axis=(2, 3)), z["emb_sum_per_frame"],
+                               atol=2e-3)
+
+
+def test_stft_against_torch():
+    sig = synth_mixture(3, 25536)
+    X = O.stft(sig, 256, 64)
+    assert X.shape == (400, 129) and X.dtype == np.complex64
+    Xt = torch.stft(torch.from_numpy(sig).double(), 256, 64, window=torch.hann_window(256, periodic=True).double(),
+                    center=True, pad_mode="reflect", return_complex=True).numpy().T
+    assert np.abs(X - Xt).max() < 1e-5 * np.abs(Xt).max()
+    lm = O.log_magnitude(X)
+    assert lm.dtype == np.float32
+    # log10 amplifies the complex64 rounding of near-zero bins: compare where |X| is not tiny
+    big = np.abs(Xt) > 1e-3
+    np.testing.assert_allclose(lm[big], np.log10(np.abs(Xt) + 1e-7)[big], atol=1e-4)
+    np.testing.assert_allclose(10.0 ** lm.astype(np.float64), np.abs(Xt) + 1e-7, atol=1e-5)
+    ph = O.phase_re_im(X)
+    assert ph.shape == (400, 129, 2) and np.array_equal(ph[..., 1], X.imag)
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 25536), (256, 64, 9000), (512, 128, 16000)])
+def test_istft_against_torch_and_roundtrip(n_fft, hop, n):
+    sig = synth_mixture(9, n)
+    X = O.stft(sig, n_fft, hop)
+    y = O.istft(X, hop, n)
+    yt = torch.istft(torch.from_numpy(X.T.astype(np.complex128)), n_fft, hop,
+                     window=torch.hann_window(n_fft, periodic=True).double(), center=True, length=n).numpy()
+    assert np.abs(y - yt).max() < 1e-6
+    assert np.abs(y - sig).max() < 1e-5       # COLA: stft -> istft reproduces the signal
+    # masks that sum to one split the signal additively
+    rng = np.random.default_rng(0)
+    m = rng.random(X.shape)
+    parts = O.mask_istft(X, np.stack([m, 1 - m]), hop, n)
+    assert np.abs(parts.sum(0) - y).max() < 1e-6
+
+
+def test_istft_longer_than_signal_pads_with_zeros():
+    X = O.stft(synth_mixture(1, 2000), 256, 64)
+    y = O.istft(X, 64, 2600)
+    assert y.shape == (2600,) and np.all(y[X.shape[0] * 64 + 128:] == 0)
