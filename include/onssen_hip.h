@@ -1,0 +1,132 @@
+/*
+ * onssen_hip.h -- C ABI of libonssen_hip.so, the MI355X (gfx950) implementation of
+ * onssen's STFT-domain separation forward pass.
+ *
+ * The upstream project is pure Python on PyTorch ATen ops; it has no FFI of its
+ * own ("C ABI ... new; nothing in the reference to mirror").
+ * Each entry point below therefore cites the reference *call site* it replaces
+ * (paths relative to the upstream tree).  The binding a maintainer adds on the
+ * reference side is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (HBM) unless the parameter name ends in
+ *    `_host`.  The caller owns every buffer including workspaces; the library
+ *    never allocates, frees or synchronises (safe under hipGraph capture).
+ *  - `stream` is a hipStream_t passed as void*; work is stream-ordered.
+ *  - Return value: 0 = ok; >0 = hipError_t of a failed launch; <0 = ONSSEN_E_*.
+ *    No exceptions cross the ABI.  Functions are re-entrant; one in-flight call
+ *    per workspace.
+ *  - dtype: fp32 storage and arithmetic (exact-fp32 MFMA v_mfma_f32_16x16x4_f32);
+ *    STFT / iSTFT butterflies run in fp64 like the reference's NumPy FFT.
+ */
+#ifndef ONSSEN_HIP_H
+#define ONSSEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONSSEN_ABI_VERSION 1
+
+#define ONSSEN_OK 0
+#define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
+#define ONSSEN_E_WORKSPACE (-2)   /* workspace too small */
+#define ONSSEN_E_ALIGN (-3)       /* pointer / stride alignment requirement violated */
+
+/* epilogue modes of onssen_linear_f32 */
+#define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
+#define ONSSEN_EPI_L2NORM 1   /* ... then x / max(||x||_2, eps) over `group` consecutive outputs        */
+#define ONSSEN_EPI_SIGMOID 2  /* ... then logistic                                                      */
+
+int onssen_abi_version(void);
+const char* onssen_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1+K2  framed STFT + log-magnitude.
+ * Replaces onssen/data/feature_utils.py:20 (librosa.core.stft(sig, n_fft, hop_length), transposed)
+ * fused with :49-51 get_log_magnitude and :54-64 get_phase.
+ *   wav      (B, n_samples) float32, row stride `wav_stride` elements
+ *   logmag   (B, T, F) float32 = log10(|X| + eps),  T = 1 + n_samples/hop, F = n_fft/2 + 1
+ *   stft_ri  (B, T, F, 2) float32 (Re, Im) of the complex64 STFT, or NULL
+ * n_fft in {256, 512, 1024}; reflect padding needs n_samples > n_fft/2.
+ */
+int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop,
+                           float eps, float* logmag, float* stft_ri, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Packed-weight geometry of one LSTM direction for unit-group size `ug` (a multiple of 4, <= 20).
+ *   Hp = H rounded up to ug; NP = 4*Hp packed gate columns; KQ = ceil(Hp/16) k-chunks;
+ *   whh_elems = floats of the MFMA-fragment-ordered recurrent weight image.
+ */
+int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_elems);
+
+/* Pack one (layer, direction) of nn.LSTM parameters (state_dict layout, gate rows i,f,g,o;
+ * onssen/nn/deep_clustering.py:15-22) into the images the kernels consume.
+ *   w_ih (4H, in_dim), w_hh (4H, H), b_ih, b_hh (4H)
+ *   bidir_in = 0: the layer input has in_dim plain columns; wih_p is [NP][Kp], Kp = in_dim rounded up to 4
+ *   bidir_in = 1: the layer input is the previous layer's [fwd(H) | rev(H)]; it is stored by this
+ *                 library as [fwd(Hp) | rev(Hp)], so wih_p is [NP][2*Hp] (in_dim must equal 2H)
+ *   whh_p   [NU][KQ][ug/4][64][4]   bias_p [NP] = b_ih + b_hh (gate-permuted)
+ */
+int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int in_dim,
+                         int bidir_in, int H, int ug, float* wih_p, float* whh_p, float* bias_p, void* stream);
+
+/* Pack a head nn.Linear(2H -> N) for the [fwd(Hp) | rev(Hp)] activation layout, optionally folding an
+ * eval-mode nn.BatchNorm1d(2H) that precedes it (onssen/nn/deep_clustering.py:36-39):
+ *   w_p[n][d*Hp+j] = w[n][d*H+j] * s[d*H+j],  b_p[n] = b[n] + sum_k w[n][k] * (beta[k] - mean[k]*s[k]),
+ *   s = gamma / sqrt(var + bn_eps).  Pass bn_gamma = NULL for no BatchNorm (chimera heads).
+ */
+int onssen_head_pack_f32(const float* w, const float* b, int N, int H, int Hp, const float* bn_gamma,
+                         const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps,
+                         float* w_p, float* b_p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3/K7/K8/K9  C = epilogue(A W^T + bias)   (exact-fp32 MFMA GEMM, fused epilogue).
+ * Replaces nn.Linear + F.normalize / torch.sigmoid at onssen/nn/deep_clustering.py:39-42,
+ * onssen/nn/chimera.py:37-42, onssen/nn/phase_network.py:53-66, and nn.LSTM's input projection.
+ *   logical row m in [0, M):  i0 = m / R, i1 = m % R
+ *     A row  at  A + i0*a_s0 + i1*a_s1  (K contiguous floats)
+ *     C row  at  C + i0*c_s0 + i1*c_s1  (N contiguous floats); `resid` (nullable) is laid out like C
+ *   W[n][k] row-major with leading dimension ldw (multiple of 4, zero-filled beyond K), bias[N]
+ *   mode L2NORM: `group` must divide 80 and N; the residual (phase head) is added before the norm.
+ */
+int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, int K, const float* W, int ldw,
+                      const float* bias, int N, int mode, int group, float eps, const float* resid, float* C,
+                      int64_t c_s0, int64_t c_s1, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3+K4  stacked bidirectional LSTM, eval semantics (zero initial state, no dropout).
+ * Replaces `rnn_output, hidden = self.rnn(x)` (onssen/nn/deep_clustering.py:35, chimera.py:35,
+ * phase_network.py:48,55).
+ *   x         element (b, t, k) at x + b*xs_b + t*xs_t + k, k < in_dim
+ *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of L device pointers; entry l holds both
+ *             directions back to back: wih [2*NP][Kp_l], whh [2][whh_elems], bias [2*NP]
+ *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0
+ *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned
+ * One input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph to
+ * amortise launch cost.
+ */
+size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug);
+int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
+                             int ug, const float* const* wih_p_host, const float* const* whh_p_host,
+                             const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K10  mask-apply + inverse STFT overlap-add.
+ * Replaces `stft_est = stft_mix * mask; librosa.core.istft(stft_est[i].T, hop_length, length)` at
+ * egs/wsj0-2mix/deep_clustering/evaluate.py:42-45 and egs/wsj0-2mix/chimera/evaluate.py:40-43.
+ *   stft_ri  (B, T, F, 2) float32;  mask element (b,c,t,f) at mask + b*m_sb + c*m_sc + t*m_st + f*m_sf
+ *            (mask = NULL means all-ones);  out (B, C, length) float32
+ * n_fft = 2(F-1) in {256, 512, 1024}; periodic Hann; divide by the window sum-of-squares where > tiny.
+ */
+int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                          int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONSSEN_HIP_H */

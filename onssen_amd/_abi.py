@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI declared in include/onssen_hip.h.
+
+Pointer arguments are plain integers (``tensor.data_ptr()``); nothing here
+imports torch, so the same binding drives the product library
+(libonssen_hip.so, device pointers) and the host-side kernel-test build
+(tests/emu, host pointers).
+"""
+import ctypes as C
+
+EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
+ABI_VERSION = 1
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/onssen_hip.h one to one
+SIGNATURES = {
+    "onssen_abi_version": (_i, []),
+    "onssen_error_string": (C.c_char_p, [_i]),
+    "onssen_stft_logmag_f32": (_i, [_vp, _i, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
+    "onssen_lstm_geometry": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
+    "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
+    "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
+    "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _vp]),
+    "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+
+class OnssenError(RuntimeError):
+    pass
+
+
+class Lib:
+    """Thin, checked wrapper around a loaded libonssen_*.so."""
+
+    def __init__(self, path):
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)   # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if self.dll.onssen_abi_version() != ABI_VERSION:
+            raise OnssenError(f"{path}: ABI version {self.dll.onssen_abi_version()} != {ABI_VERSION}")
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.dll.onssen_error_string(rc)
+            raise OnssenError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+    # ---- geometry -------------------------------------------------------
+    def lstm_geometry(self, H, ug):
+        hp, np_, kq, we = _i(), _i(), _i(), _i64()
+        self.check(self.dll.onssen_lstm_geometry(H, ug, hp, np_, kq, we), "onssen_lstm_geometry")
+        return hp.value, np_.value, kq.value, we.value
+
+    def blstm_workspace_bytes(self, B, T, H, L, ug):
+        return int(self.dll.onssen_blstm_workspace_bytes(B, T, H, L, ug))
+
+    # ---- kernels (pointers are ints) --------------------------------------
+    def stft_logmag(self, wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream):
+        self.check(self.dll.onssen_stft_logmag_f32(wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream),
+                   "onssen_stft_logmag_f32")
+
+    def lstm_pack(self, w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p, bias_p, stream):
+        self.check(self.dll.onssen_lstm_pack_f32(w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p,
+                                                 bias_p, stream), "onssen_lstm_pack_f32")
+
+    def head_pack(self, w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream):
+        self.check(self.dll.onssen_head_pack_f32(w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream),
+                   "onssen_head_pack_f32")
+
+    def linear(self, A, a_s0, a_s1, R, M, K, W, ldw, bias, N, mode, group, eps, resid, Cp, c_s0, c_s1, stream):
+        self.check(self.dll.onssen_linear_f32(A, a_s0, a_s1, R, M, K, W, ldw, bias, N, mode, group, eps, resid, Cp,
+                                              c_s0, c_s1, stream), "onssen_linear_f32")
+
+    def blstm_forward(self, x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_ptrs, whh_ptrs, bias_ptrs, y, ws, ws_bytes,
+                      stream):
+        arr = C.c_void_p * L
+        self.check(self.dll.onssen_blstm_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, L, ug, arr(*wih_ptrs),
+                                                     arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, stream),
+                   "onssen_blstm_forward_f32")
+
+    def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
+        self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,
+                                                  length, out, stream), "onssen_mask_istft_f32")

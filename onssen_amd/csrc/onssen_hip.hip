@@ -1,0 +1,799 @@
+// libonssen_hip.so -- hand-written HIP kernels for gfx950 (MI355X / CDNA4) behind the C ABI of
+// include/onssen_hip.h.  See DESIGN.md for the data layouts and the per-kernel rooflines.
+//
+// Kernel inventory:
+//   stft_logmag_kernel   K1+K2   fp64 radix-2 FFT in LDS, one wavefront per frame, fused log10(|X|+eps)
+//   linear_kernel        K3/K7/K8/K9  128x80x16 LDS-tiled GEMM on v_mfma_f32_16x16x4_f32 (exact fp32),
+//                        epilogues: bias | bias(+residual)+group L2-normalise (wave shuffles) | bias+sigmoid
+//   lstm_step_kernel     K4      one launch per time step, both directions; K split over the 4 waves of a
+//                        workgroup, LDS reduction, fused sigmoid/tanh cell update
+//   mask_istft_kernel    K10     mask-apply + fp64 inverse FFT + gather overlap-add (no atomics)
+//   pack_* kernels       one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold)
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/onssen_hip.h"
+
+typedef float f32x4 __attribute__((vector_size(16)));
+
+#define ONSSEN_LAUNCH_CHECK()                   \
+  do {                                          \
+    hipError_t e__ = hipGetLastError();         \
+    if (e__ != hipSuccess) return (int)e__;     \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// =================================================================================================
+// Weight packing
+// =================================================================================================
+
+// packed gate column p of a direction  <->  (unit-group, gate, unit-in-group)
+//   p = ugi*(4*UG) + gate*UG + ju ;  original nn.LSTM row = gate*H + ugi*UG + ju  (gate order i,f,g,o)
+__global__ void pack_wih_kernel(const float* __restrict__ w_ih, const float* __restrict__ b_ih,
+                                const float* __restrict__ b_hh, int in_dim, int bidir_in, int H, int Hp, int UG,
+                                int Kp, float* __restrict__ wih_p, float* __restrict__ bias_p) {
+  const int NP = 4 * Hp;
+  const long total = (long)NP * Kp;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(e / Kp), kk = (int)(e % Kp);
+    const int ugi = p / (4 * UG), rem = p % (4 * UG), gate = rem / UG, ju = rem % UG;
+    const int u = ugi * UG + ju;
+    int k;
+    bool ok = u < H;
+    if (bidir_in) {
+      const int d = kk / Hp, j = kk % Hp;
+      k = d * H + j;
+      ok = ok && (j < H);
+    } else {
+      k = kk;
+      ok = ok && (kk < in_dim);
+    }
+    const int n = gate * H + u;
+    wih_p[e] = ok ? w_ih[(long)n * in_dim + k] : 0.0f;
+    if (kk == 0) bias_p[p] = (u < H) ? (b_ih[n] + b_hh[n]) : 0.0f;
+  }
+}
+
+// MFMA B-fragment image of W_hh: [ugi][q][nt][lane][r] with
+//   column = nt*16 + (lane&15) (local packed column = gate*UG + ju),  k = 16q + 4(lane>>4) + r
+__global__ void pack_whh_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ,
+                                float* __restrict__ whh_p) {
+  const int NTl = UG / 4, NU = Hp / UG;
+  const long total = (long)NU * KQ * NTl * 256;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    long rest = e >> 8;
+    const int nt = (int)(rest % NTl);
+    rest /= NTl;
+    const int q = (int)(rest % KQ);
+    const int ugi = (int)(rest / KQ);
+    const int pl = nt * 16 + (lane & 15);
+    const int gate = pl / UG, ju = pl % UG;
+    const int u = ugi * UG + ju;
+    const int k = 16 * q + 4 * (lane >> 4) + r;
+    whh_p[e] = (u < H && k < H) ? w_hh[(long)(gate * H + u) * H + k] : 0.0f;
+  }
+}
+
+// one workgroup per output row n: scale the weight row by the BatchNorm factor, fold the shift into the bias
+__global__ void pack_head_kernel(const float* __restrict__ w, const float* __restrict__ b, int N, int H, int Hp,
+                                 const float* __restrict__ g, const float* __restrict__ beta,
+                                 const float* __restrict__ mean, const float* __restrict__ var, float bn_eps,
+                                 float* __restrict__ w_p, float* __restrict__ b_p) {
+  __shared__ float red[256];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float part = 0.0f;
+  for (int kk = tid; kk < 2 * Hp; kk += 256) {
+    const int d = kk / Hp, j = kk % Hp;
+    float v = 0.0f;
+    if (j < H) {
+      const int k = d * H + j;
+      const float wv = w[(long)n * 2 * H + k];
+      if (g) {
+        const float s = g[k] / sqrtf(var[k] + bn_eps);
+        v = wv * s;
+        part += wv * (beta[k] - mean[k] * s);
+      } else {
+        v = wv;
+      }
+    }
+    w_p[(long)n * 2 * Hp + kk] = v;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) b_p[n] = b[n] + red[0];
+}
+
+// =================================================================================================
+// K3/K7/K8/K9: exact-fp32 MFMA GEMM  C = epi(A W^T + bias)
+// =================================================================================================
+namespace lin {
+constexpr int BM = 128, BN = 80, BK = 16;
+constexpr int LD = 20;              // LDS row stride (floats) of the staged A / W tiles: 16 + 4 pad
+constexpr int CLD = 84;             // LDS row stride of the C tile in the epilogue
+constexpr int STAGE = 2 * (BM + BN) * LD;
+constexpr int SMEM = (BM * CLD > STAGE) ? BM * CLD : STAGE;
+}  // namespace lin
+
+struct LinearArgs {
+  const float* A;
+  long a_s0, a_s1;
+  const float* W;
+  const float* bias;
+  const float* resid;
+  float* C;
+  long c_s0, c_s1;
+  int R, M, N, K, ldw, group;
+  float eps;
+};
+
+__device__ __forceinline__ float f4c(const float4& v, int r) {
+  return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w));
+}
+
+template <bool A_VEC, int MODE>
+__global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
+  using namespace lin;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  __shared__ long c_rowoff[BM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  float* As = smem;
+  float* Bs = smem + 2 * BM * LD;
+
+  // ---- staging coordinates: thread -> (row, 4-wide k quad) of the A tile (2 rows) and W tile (<=2 rows)
+  const int kq = tid & 3;
+  long a_off[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int m = m0 + (tid >> 2) + 64 * it;
+    a_ok[it] = m < p.M;
+    a_off[it] = a_ok[it] ? (long)(m / p.R) * p.a_s0 + (long)(m % p.R) * p.a_s1 : 0;
+  }
+  long w_off[2];
+  bool w_ok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = (tid >> 2) + 64 * it;
+    w_ok[it] = (row < BN) && (n0 + row < p.N);
+    w_off[it] = w_ok[it] ? (long)(n0 + row) * p.ldw : 0;
+  }
+
+  float4 ra[2], rb[2];
+  auto g_load = [&](int k0) {
+    const int k = k0 + 4 * kq;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_ok[it]) {
+        const float* src = p.A + a_off[it] + k;
+        if (A_VEC) {
+          if (k < p.K) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k + 0 < p.K) v.x = src[0];
+          if (k + 1 < p.K) v.y = src[1];
+          if (k + 2 < p.K) v.z = src[2];
+          if (k + 3 < p.K) v.w = src[3];
+        }
+      }
+      ra[it] = v;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w_ok[it] && k < p.ldw) u = *reinterpret_cast<const float4*>(p.W + w_off[it] + k);
+      rb[it] = u;
+    }
+  };
+  auto s_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = (tid >> 2) + 64 * it;
+      *reinterpret_cast<float4*>(As + (buf * BM + row) * LD + 4 * kq) = ra[it];
+      if (row < BN) *reinterpret_cast<float4*>(Bs + (buf * BN + row) * LD + 4 * kq) = rb[it];
+    }
+  };
+
+  f32x4 acc[2][5];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (p.K + BK - 1) / BK;
+  g_load(0);
+  s_store(0);
+  __syncthreads();
+  const int fi = lane & 15, fg = lane >> 4;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nkb) g_load((kb + 1) * BK);
+    const float* Ab = As + (cur * BM + wave * 32 + fi) * LD + 4 * fg;
+    const float* Bb = Bs + (cur * BN + fi) * LD + 4 * fg;
+    float4 av[2], bv[5];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(Ab + mt * 16 * LD);
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Bb + nt * 16 * LD);
+    // the MFMA contracts over the 4 lane groups; with one float4 per lane, step r covers
+    // k = 4*group + r -- A and W use the same permutation, so the sum is the plain dot product
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[mt], r), f4c(bv[nt], r), acc[mt][nt], 0, 0, 0);
+    if (kb + 1 < nkb) s_store(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators (+bias) -> LDS C tile -> (residual) -> (group L2 norm) -> coalesced store
+  float* Cs = smem;
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    const int col = nt * 16 + fi;
+    const float bv1 = (n0 + col < p.N) ? p.bias[n0 + col] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(wave * 32 + mt * 16 + 4 * fg + r) * CLD + col] = acc[mt][nt][r] + bv1;
+  }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    c_rowoff[tid] = (m < p.M) ? (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1 : -1;
+  }
+  __syncthreads();
+  if (MODE == ONSSEN_EPI_L2NORM) {
+    if (p.resid) {
+      for (int e = tid; e < BM * BN; e += 256) {
+        const int row = e / BN, col = e % BN;
+        const long off = c_rowoff[row];
+        if (off >= 0 && n0 + col < p.N) Cs[row * CLD + col] += p.resid[off + n0 + col];
+      }
+      __syncthreads();
+    }
+    // 4 lanes per (row, group): strided partial sums, two xor-shuffles, in-place divide
+    const int ng = BN / p.group, items = BM * ng, sub = tid & 3;
+    for (int it = tid >> 2; it < items; it += 64) {
+      float* v = Cs + (it / ng) * CLD + (it % ng) * p.group;
+      float s = 0.0f;
+      for (int d = sub; d < p.group; d += 4) s += v[d] * v[d];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      const float den = fmaxf(sqrtf(s), p.eps);
+      for (int d = sub; d < p.group; d += 4) v[d] = v[d] / den;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < BM * BN; e += 256) {
+    const int row = e / BN, col = e % BN;
+    const long off = c_rowoff[row];
+    if (off >= 0 && n0 + col < p.N) {
+      float v = Cs[row * CLD + col];
+      if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+      p.C[off + n0 + col] = v;
+    }
+  }
+}
+
+// =================================================================================================
+// K4: one LSTM time step, both directions
+// =================================================================================================
+struct StepArgs {
+  const float* G;    // [T][B][2][NP]   input projection + biases, gate-permuted columns
+  const float* whh;  // [2][NU][KQ][NT][64][4]
+  float* y;          // [T][B][2][Hp]   layer output (h_t)
+  float* c;          // [2][B][Hp]      cell state
+  int B, T, Hp, NP, KQ, NU, step;
+};
+
+namespace rec {
+constexpr int RLD = 72;  // LDS row stride of the per-wave partial accumulators (64 lanes + pad)
+constexpr int QB = 10;   // k-chunks (16 k each) a wave keeps in flight: 4 waves x 10 x 16 = 640 >= H
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
+  using namespace rec;
+  constexpr int UG = 4 * NT;          // hidden units per workgroup
+  constexpr int NE = 16 * MT * UG;    // (batch row, unit) elements per workgroup
+  constexpr int EPT = (NE + 255) / 256;
+  __shared__ float red[4 * MT * NT * 4 * RLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ugi = blockIdx.x, dir = blockIdx.y, b0 = blockIdx.z * 16 * MT;
+  const int t = dir == 0 ? p.step : p.T - 1 - p.step;
+  const int tprev = dir == 0 ? t - 1 : t + 1;
+  const bool first = p.step == 0;
+
+  // ---- issue the epilogue's global reads first: they are independent of the recurrent product
+  float gpre[EPT][4], cold[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / UG, ju = e % UG, b = b0 + row;
+    const bool ok = (e < NE) && (b < p.B);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      gpre[i][g] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + g * UG + ju] : 0.0f;
+    cold[i] = (ok && !first) ? p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] : 0.0f;
+  }
+
+  if (!first) {
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fi = lane & 15, fg = lane >> 4;
+    const float* wbase = p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256 + lane * 4;
+    // wave w owns k-chunks q = w, w+4, w+8, ...
+    for (int qb = wave; qb < p.KQ; qb += 4 * QB) {
+      float4 a[QB][MT], w[QB][NT];
+#pragma unroll
+      for (int i = 0; i < QB; ++i) {
+        const int q = qb + 4 * i;
+        const bool qok = q < p.KQ;
+        const int k = 16 * q + 4 * fg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int b = b0 + mt * 16 + fi;
+          a[i][mt] = (qok && b < p.B && k < p.Hp)
+                         ? *reinterpret_cast<const float4*>(p.y + ((long)(tprev * p.B + b) * 2 + dir) * p.Hp + k)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          w[i][nt] = qok ? *reinterpret_cast<const float4*>(wbase + ((long)q * NT + nt) * 256)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < QB; ++i) {
+        if (qb + 4 * i < p.KQ) {  // wave-uniform: skip chunks past the end of K
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[i][mt], r), f4c(w[i][nt], r), acc[mt][nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * MT * NT + mt * NT + nt) * 4 + r) * RLD + lane] = acc[mt][nt][r];
+    __syncthreads();
+  }
+
+  // ---- fused cell update: one (batch row, hidden unit) per thread
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / UG, ju = e % UG, b = b0 + row;
+    if (e < NE && b < p.B) {
+      float pre[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float s = 0.0f;
+        if (!first) {
+          const int pl = g * UG + ju;
+          const int tile = (row >> 4) * NT + (pl >> 4);
+          const int src = (((row & 15) >> 2) << 4) + (pl & 15), r = row & 3;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) s += red[((w * MT * NT + tile) * 4 + r) * RLD + src];
+        }
+        pre[g] = s + gpre[i][g];
+      }
+      const float ig = 1.0f / (1.0f + expf(-pre[0]));
+      const float fg2 = 1.0f / (1.0f + expf(-pre[1]));
+      const float gg = tanhf(pre[2]);
+      const float og = 1.0f / (1.0f + expf(-pre[3]));
+      const float cn = fg2 * cold[i] + ig * gg;
+      const float h = og * tanhf(cn);
+      p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] = cn;
+      p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
+    }
+  }
+}
+
+// =================================================================================================
+// K1+K2 / K10: fp64 radix-2 FFT helpers (one wavefront per frame, data in LDS)
+// =================================================================================================
+template <int N>
+struct FftTables {
+  double tw_re[N / 2], tw_im[N / 2];  // exp(-2 pi i k / N)
+  double win[N];                       // periodic Hann
+};
+
+template <int N>
+__device__ __forceinline__ void fft_tables_init(FftTables<N>& tb, int tid, int nthreads) {
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = tid; k < N / 2; k += nthreads) {
+    double s, c;
+    sincos(-two_pi * (double)k / (double)N, &s, &c);
+    tb.tw_re[k] = c;
+    tb.tw_im[k] = s;
+  }
+  for (int i = tid; i < N; i += nthreads) tb.win[i] = 0.5 - 0.5 * cos(two_pi * (double)i / (double)N);
+}
+
+template <int LOGN>
+__device__ __forceinline__ int bitrev(int i) {
+  int r = 0;
+#pragma unroll
+  for (int b = 0; b < LOGN; ++b) r |= ((i >> b) & 1) << (LOGN - 1 - b);
+  return r;
+}
+
+// In-place decimation-in-time butterflies over bit-reversed input; every wave of the workgroup calls
+// this together (the stage barrier is workgroup-wide).  inverse = conjugated twiddles, unscaled.
+template <int N, int LOGN>
+__device__ __forceinline__ void fft_stages(double* re, double* im, const FftTables<N>& tb, int lane, bool inverse) {
+  for (int s = 0; s < LOGN; ++s) {
+    const int half = 1 << s;
+    __syncthreads();
+    for (int j = lane; j < N / 2; j += 64) {
+      const int pos = j & (half - 1);
+      const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
+      const int tk = pos << (LOGN - 1 - s);
+      const double wr = tb.tw_re[tk], wi = inverse ? -tb.tw_im[tk] : tb.tw_im[tk];
+      const double xr = re[i1], xi = im[i1];
+      const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+      const double ur = re[i0], ui = im[i0];
+      re[i0] = ur + tr;
+      im[i0] = ui + ti;
+      re[i1] = ur - tr;
+      im[i1] = ui - ti;
+    }
+  }
+  __syncthreads();
+}
+
+template <int N, int LOGN>
+__global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ wav, int B, int n_samples,
+                                                          long wav_stride, int hop, int T, float eps,
+                                                          float* __restrict__ logmag, float* __restrict__ stft_ri) {
+  __shared__ FftTables<N> tb;
+  __shared__ double buf_re[4][N], buf_im[4][N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int F = N / 2 + 1;
+  fft_tables_init<N>(tb, tid, 256);
+  __syncthreads();
+  const long total = (long)B * T;
+  const long frame = (long)blockIdx.x * 4 + wave;
+  const bool active = frame < total;
+  const int b = active ? (int)(frame / T) : 0, t = active ? (int)(frame % T) : 0;
+  double* re = buf_re[wave];
+  double* im = buf_im[wave];
+  const float* sig = wav + (long)b * wav_stride;
+  for (int i = lane; i < N; i += 64) {
+    int pidx = t * hop + i - N / 2;  // centred frame, reflect padding (edge sample not repeated)
+    if (pidx < 0) pidx = -pidx;
+    if (pidx >= n_samples) pidx = 2 * (n_samples - 1) - pidx;
+    const double v = active ? (double)sig[pidx] * tb.win[i] : 0.0;
+    const int j = bitrev<LOGN>(i);
+    re[j] = v;
+    im[j] = 0.0;
+  }
+  fft_stages<N, LOGN>(re, im, tb, lane, false);
+  if (active) {
+    for (int f = lane; f < F; f += 64) {
+      const float xr = (float)re[f], xi = (float)im[f];  // complex128 -> complex64 like the reference
+      const long o = (frame * F + f);
+      logmag[o] = log10f(hypotf(xr, xi) + eps);
+      if (stft_ri) {
+        stft_ri[2 * o] = xr;
+        stft_ri[2 * o + 1] = xi;
+      }
+    }
+  }
+}
+
+// FB = frames transformed per workgroup (FB/4 rounds of 4 waves); sized so that the LDS image
+// (tables + 4 FFT buffers + FB windowed frames, all fp64) stays under 160 KiB.
+template <int N, int LOGN, int FB>
+__global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ stft_ri,
+                                                         const float* __restrict__ mask, long m_sb, long m_sc,
+                                                         long m_st, long m_sf, int C, int T, int hop, int length,
+                                                         int FR, float* __restrict__ out) {
+  __shared__ FftTables<N> tb;
+  __shared__ double buf_re[4][N], buf_im[4][N];
+  __shared__ double fr[FB][N];  // windowed time-domain frames of this chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int F = N / 2 + 1;
+  const int chunk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  fft_tables_init<N>(tb, tid, 256);
+  // output samples n in [chunk*FR*hop, +FR*hop); padded position p = n + N/2 is covered by frames
+  // t with t*hop <= p < t*hop + N
+  const int p0 = chunk * FR * hop + N / 2;
+  int tfirst = (p0 - N + hop) / hop;  // ceil((p0 - N + 1) / hop) for p0 >= N/2 >= 1 ... clamp below
+  if (p0 - N + 1 <= 0) tfirst = 0;
+  const double inv_n = 1.0 / (double)N;
+  for (int round = 0; round < FB / 4; ++round) {
+    const int fidx = round * 4 + wave, t = tfirst + fidx;
+    const bool active = t < T;
+    double* re = buf_re[wave];
+    double* im = buf_im[wave];
+    __syncthreads();  // tables ready / previous round's buffers consumed
+    const float* xs = stft_ri + ((long)(b * T + (active ? t : 0)) * F) * 2;
+    const float* ms = mask ? mask + (long)b * m_sb + (long)c * m_sc + (long)(active ? t : 0) * m_st : nullptr;
+    for (int f = lane; f < F; f += 64) {
+      double xr = 0.0, xi = 0.0;
+      if (active) {
+        const float mv = ms ? ms[(long)f * m_sf] : 1.0f;
+        xr = (double)xs[2 * f] * (double)mv;
+        xi = (double)xs[2 * f + 1] * (double)mv;
+      }
+      if (f == 0 || f == N / 2) xi = 0.0;  // c2r transforms ignore the imaginary part of DC / Nyquist
+      const int j = bitrev<LOGN>(f);
+      re[j] = xr;
+      im[j] = xi;
+      if (f > 0 && f < N / 2) {  // Hermitian mirror
+        const int jm = bitrev<LOGN>(N - f);
+        re[jm] = xr;
+        im[jm] = -xi;
+      }
+    }
+    fft_stages<N, LOGN>(re, im, tb, lane, true);
+    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? tb.win[i] * (re[i] * inv_n) : 0.0;
+  }
+  __syncthreads();
+  const int exp_len = N + hop * (T - 1);
+  for (int idx = tid; idx < FR * hop; idx += 256) {
+    const int n = chunk * FR * hop + idx;
+    if (n >= length) continue;
+    const int pp = n + N / 2;
+    double y = 0.0;
+    if (pp < exp_len) {
+      int tlo = (pp - N + hop) / hop;
+      if (pp - N + 1 <= 0) tlo = 0;
+      int thi = pp / hop;
+      if (thi > T - 1) thi = T - 1;
+      double s = 0.0, wss = 0.0;
+      for (int t = tlo; t <= thi && t - tfirst < FB; ++t) {
+        const int i = pp - t * hop;
+        s += fr[t - tfirst][i];
+        wss += tb.win[i] * tb.win[i];
+      }
+      y = (wss > 2.2250738585072014e-308) ? s / wss : s;
+    }
+    out[((long)b * C + c) * length + n] = (float)y;
+  }
+}
+
+template <int MT, int NT>
+static int launch_steps(StepArgs sp, int T, hipStream_t st) {
+  const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
+  for (int s = 0; s < T; ++s) {
+    sp.step = s;
+    hipLaunchKernelGGL((lstm_step_kernel<MT, NT>), grid, block, 0, st, sp);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ONSSEN_OK : (int)e;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int onssen_abi_version(void) { return ONSSEN_ABI_VERSION; }
+
+const char* onssen_error_string(int code) {
+  switch (code) {
+    case ONSSEN_OK: return "ok";
+    case ONSSEN_E_ARG: return "onssen: invalid argument or unsupported shape";
+    case ONSSEN_E_WORKSPACE: return "onssen: workspace too small";
+    case ONSSEN_E_ALIGN: return "onssen: pointer or stride alignment requirement violated";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "onssen: unknown error";
+  }
+}
+
+int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop, float eps,
+                           float* logmag, float* stft_ri, void* stream) {
+  if (!wav || !logmag || B <= 0 || hop <= 0 || n_samples <= n_fft / 2) return ONSSEN_E_ARG;
+  const int T = 1 + n_samples / hop;
+  const long frames = (long)B * T;
+  const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_fft == 256)
+    hipLaunchKernelGGL((stft_logmag_kernel<256, 8>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
+                       eps, logmag, stft_ri);
+  else if (n_fft == 512)
+    hipLaunchKernelGGL((stft_logmag_kernel<512, 9>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
+                       eps, logmag, stft_ri);
+  else if (n_fft == 1024)
+    hipLaunchKernelGGL((stft_logmag_kernel<1024, 10>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop,
+                       T, eps, logmag, stft_ri);
+  else
+    return ONSSEN_E_ARG;
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_elems) {
+  if (H <= 0 || ug < 4 || ug > 20 || (ug % 4) != 0) return ONSSEN_E_ARG;
+  const int hp = ceil_div(H, ug) * ug, kq = ceil_div(hp, 16);
+  if (Hp) *Hp = hp;
+  if (NP) *NP = 4 * hp;
+  if (KQ) *KQ = kq;
+  if (whh_elems) *whh_elems = (int64_t)(hp / ug) * kq * (ug / 4) * 256;
+  return ONSSEN_OK;
+}
+
+int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int in_dim,
+                         int bidir_in, int H, int ug, float* wih_p, float* whh_p, float* bias_p, void* stream) {
+  int Hp, NP, KQ;
+  int64_t we;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
+  if (!w_ih || !w_hh || !b_ih || !b_hh || !wih_p || !whh_p || !bias_p || in_dim <= 0) return ONSSEN_E_ARG;
+  if (bidir_in && in_dim != 2 * H) return ONSSEN_E_ARG;
+  const int Kp = bidir_in ? 2 * Hp : ceil_div(in_dim, 4) * 4;
+  hipStream_t st = (hipStream_t)stream;
+  const long n1 = (long)NP * Kp;
+  hipLaunchKernelGGL(pack_wih_kernel, dim3((unsigned)((n1 + 255) / 256 > 4096 ? 4096 : (n1 + 255) / 256)), dim3(256),
+                     0, st, w_ih, b_ih, b_hh, in_dim, bidir_in, H, Hp, ug, Kp, wih_p, bias_p);
+  ONSSEN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_whh_kernel, dim3((unsigned)((we + 255) / 256 > 4096 ? 4096 : (we + 255) / 256)), dim3(256),
+                     0, st, w_hh, H, Hp, ug, KQ, whh_p);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_head_pack_f32(const float* w, const float* b, int N, int H, int Hp, const float* bn_gamma,
+                         const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, float* w_p,
+                         float* b_p, void* stream) {
+  if (!w || !b || !w_p || !b_p || N <= 0 || H <= 0 || Hp < H || (Hp % 4) != 0) return ONSSEN_E_ARG;
+  if (bn_gamma && (!bn_beta || !bn_mean || !bn_var)) return ONSSEN_E_ARG;
+  hipLaunchKernelGGL(pack_head_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, w, b, N, H, Hp,
+                     bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, w_p, b_p);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, int K, const float* W, int ldw,
+                      const float* bias, int N, int mode, int group, float eps, const float* resid, float* C,
+                      int64_t c_s0, int64_t c_s1, void* stream) {
+  if (!A || !W || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0 || ldw < K) return ONSSEN_E_ARG;
+  if ((ldw % 4) != 0 || !aligned16(W)) return ONSSEN_E_ALIGN;
+  if (mode == ONSSEN_EPI_L2NORM) {
+    if (group <= 0 || (lin::BN % group) != 0 || (N % group) != 0) return ONSSEN_E_ARG;
+  } else if (resid) {
+    return ONSSEN_E_ARG;
+  }
+  LinearArgs p;
+  p.A = A; p.a_s0 = (long)a_s0; p.a_s1 = (long)a_s1; p.W = W; p.bias = bias; p.resid = resid; p.C = C;
+  p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N; p.K = K; p.ldw = ldw; p.group = group;
+  p.eps = eps;
+  const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
+  const dim3 grid((unsigned)ceil_div(N, lin::BN), (unsigned)ceil_div(M, lin::BM)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define ONSSEN_LIN(VEC, MODE_) hipLaunchKernelGGL((linear_kernel<VEC, MODE_>), grid, block, 0, st, p)
+  if (mode == ONSSEN_EPI_BIAS) {
+    if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_BIAS); else ONSSEN_LIN(false, ONSSEN_EPI_BIAS);
+  } else if (mode == ONSSEN_EPI_L2NORM) {
+    if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_L2NORM); else ONSSEN_LIN(false, ONSSEN_EPI_L2NORM);
+  } else if (mode == ONSSEN_EPI_SIGMOID) {
+    if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_SIGMOID); else ONSSEN_LIN(false, ONSSEN_EPI_SIGMOID);
+  } else {
+    return ONSSEN_E_ARG;
+  }
+#undef ONSSEN_LIN
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
+  int Hp, NP, KQ;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, nullptr) != ONSSEN_OK || B <= 0 || T <= 0 || L <= 0) return 0;
+  const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
+  const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
+  const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
+  return g + (L > 1 ? y : 0) + c;
+}
+
+int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
+                             int ug, const float* const* wih_p_host, const float* const* whh_p_host,
+                             const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, void* stream) {
+  int Hp, NP, KQ;
+  int64_t we;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
+  if (!x || !y || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || T <= 0 || in_dim <= 0 || L <= 0)
+    return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_blstm_workspace_bytes(B, T, H, L, ug)) return ONSSEN_E_WORKSPACE;
+  if (!aligned16(ws) || !aligned16(y)) return ONSSEN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  char* wsp = (char*)ws;
+  float* G = (float*)wsp;
+  wsp += align256((size_t)T * B * 2 * NP * sizeof(float));
+  float* ybuf = nullptr;
+  if (L > 1) {
+    ybuf = (float*)wsp;
+    wsp += align256((size_t)T * B * 2 * Hp * sizeof(float));
+  }
+  float* cst = (float*)wsp;
+  const int mt = B > 16 ? 2 : 1;
+  for (int l = 0; l < L; ++l) {
+    // the last layer writes `y`; the layers before it alternate so that each reads what the previous wrote
+    float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;
+    const float* yin = ((L - 1 - l) % 2 == 0) ? ybuf : y;
+    int rc;
+    if (l == 0) {
+      const int Kp = ceil_div(in_dim, 4) * 4;
+      rc = onssen_linear_f32(x, xs_t, xs_b, B, T * B, in_dim, wih_p_host[0], Kp, bias_p_host[0], 2 * NP,
+                             ONSSEN_EPI_BIAS, 0, 0.f, nullptr, G, (int64_t)B * 2 * NP, 2 * NP, stream);
+    } else {
+      rc = onssen_linear_f32(yin, (int64_t)B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, wih_p_host[l], 2 * Hp,
+                             bias_p_host[l], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, nullptr, G, (int64_t)B * 2 * NP,
+                             2 * NP, stream);
+    }
+    if (rc != ONSSEN_OK) return rc;
+    StepArgs sp;
+    sp.G = G; sp.whh = whh_p_host[l]; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
+    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0;
+#define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, T, st)
+    if (mt == 1) {
+      switch (ug) {
+        case 4: ONSSEN_STEPS(1, 1); break;
+        case 8: ONSSEN_STEPS(1, 2); break;
+        case 12: ONSSEN_STEPS(1, 3); break;
+        case 16: ONSSEN_STEPS(1, 4); break;
+        default: ONSSEN_STEPS(1, 5); break;
+      }
+    } else {
+      switch (ug) {
+        case 4: ONSSEN_STEPS(2, 1); break;
+        case 8: ONSSEN_STEPS(2, 2); break;
+        case 12: ONSSEN_STEPS(2, 3); break;
+        case 16: ONSSEN_STEPS(2, 4); break;
+        default: ONSSEN_STEPS(2, 5); break;
+      }
+    }
+#undef ONSSEN_STEPS
+    if (rc != ONSSEN_OK) return rc;
+  }
+  return ONSSEN_OK;
+}
+
+int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                          int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
+                          void* stream) {
+  if (!stft_ri || !out || B <= 0 || C <= 0 || T <= 0 || hop <= 0 || length <= 0 || hop > n_fft) return ONSSEN_E_ARG;
+  // a chunk of FR hops of output needs FR + ceil(n_fft/hop) - 1 frames (one more when the chunk
+  // origin n_fft/2 is not hop-aligned); FB frames fit in LDS
+  const int FB = n_fft <= 512 ? 16 : 8;
+  const int halo = ceil_div(n_fft, hop) - 1;
+  const bool hop_aligned = (n_fft % hop) == 0 && ((n_fft / 2) % hop) == 0;
+  const int FR = FB - halo - (hop_aligned ? 0 : 1);
+  if (FR <= 0) return ONSSEN_E_ARG;
+  const dim3 grid((unsigned)ceil_div(length, FR * hop), (unsigned)C, (unsigned)B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_fft == 256)
+    hipLaunchKernelGGL((mask_istft_kernel<256, 8, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
+  else if (n_fft == 512)
+    hipLaunchKernelGGL((mask_istft_kernel<512, 9, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
+  else if (n_fft == 1024)
+    hipLaunchKernelGGL((mask_istft_kernel<1024, 10, 8>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
+  else
+    return ONSSEN_E_ARG;
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+}  // extern "C"

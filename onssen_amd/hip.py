@@ -1,0 +1,20 @@
+"""Loader of the product library libonssen_hip.so (built in-tree by
+``__graft_entry__.build()``).  There is no fallback: if the library is
+missing or does not export the full ABI, importing a kernel raises."""
+import os
+
+from ._abi import Lib, OnssenError
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libonssen_hip.so")
+
+
+def get_lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise OnssenError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+                "onssen_amd has no CPU or PyTorch-op fallback for its hot path.")
+        _LIB = Lib(LIB_PATH)
+    return _LIB

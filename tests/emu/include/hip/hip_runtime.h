@@ -1,0 +1,147 @@
+// Mock HIP runtime for HOST-SIDE KERNEL TESTS ONLY (tests/emu).
+//
+// The product (onssen_amd/csrc/onssen_hip.hip) is plain HIP for gfx950 and has
+// no conditional compilation.  To exercise its index arithmetic, MFMA
+// fragment bookkeeping and predication on a box without a GPU, the test
+// suite compiles that same source with g++ against THIS header instead of
+// ROCm's <hip/hip_runtime.h>.  Every workgroup runs as real OS threads
+// (one per work-item, workgroups one after another); __syncthreads() is a
+// pthread barrier, wave-level collectives (shuffles, the f32 MFMA) exchange
+// operands through a per-wave buffer following the gfx950 lane layouts
+// documented in cdna_hip_programming.md section 3.  Slow by design; sizes in
+// tests/test_emu_*.py are tiny.  Never shipped, never timed.
+#pragma once
+#include <pthread.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return {x, y}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace emu {
+struct WaveBuf { float a[64]; float b[64]; };
+struct BlockCtx {
+  pthread_barrier_t block_bar;
+  std::vector<pthread_barrier_t> wave_bar;
+  std::vector<WaveBuf> wbuf;
+  explicit BlockCtx(int nthr) : wave_bar((nthr + 63) / 64), wbuf((nthr + 63) / 64) {
+    pthread_barrier_init(&block_bar, nullptr, nthr);
+    for (size_t w = 0; w < wave_bar.size(); ++w) {
+      int n = nthr - int(w) * 64;
+      pthread_barrier_init(&wave_bar[w], nullptr, n > 64 ? 64 : n);
+    }
+  }
+  ~BlockCtx() {
+    pthread_barrier_destroy(&block_bar);
+    for (auto& b : wave_bar) pthread_barrier_destroy(&b);
+  }
+};
+inline thread_local BlockCtx* ctx = nullptr;
+inline thread_local int lane = 0, wave = 0;
+inline void wave_sync() { pthread_barrier_wait(&ctx->wave_bar[wave]); }
+
+template <class F>
+void launch(dim3 grid, dim3 block, F body);
+}  // namespace emu
+
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+template <class F>
+void emu::launch(dim3 grid, dim3 block, F body) {
+  const int nthr = int(block.x * block.y * block.z);
+  if (nthr % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+  BlockCtx c(nthr);
+  std::vector<std::thread> th;
+  th.reserve(nthr);
+  for (int tid = 0; tid < nthr; ++tid) {
+    th.emplace_back([&, tid]() {
+      emu::ctx = &c;
+      emu::lane = tid & 63;
+      emu::wave = tid >> 6;
+      threadIdx = dim3(tid % block.x, (tid / block.x) % block.y, tid / (block.x * block.y));
+      blockDim = block;
+      gridDim = grid;
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
+            blockIdx = dim3(bx, by, bz);
+            body();
+            pthread_barrier_wait(&c.block_bar);
+          }
+    });
+  }
+  for (auto& t : th) t.join();
+}
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  emu::launch((grid), (block), [&]() { (kern)(__VA_ARGS__); })
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu::ctx->block_bar); }
+
+static inline float __shfl(float v, int src) {
+  auto& w = emu::ctx->wbuf[emu::wave];
+  w.a[emu::lane] = v;
+  emu::wave_sync();
+  float r = w.a[src & 63];
+  emu::wave_sync();
+  return r;
+}
+static inline float __shfl_xor(float v, int mask) { return __shfl(v, emu::lane ^ mask); }
+static inline double __shfl_xor(double v, int mask) {
+  // two 32-bit halves, like the hardware
+  uint64_t u; memcpy(&u, &v, 8);
+  float lo, hi; uint32_t l = uint32_t(u), h = uint32_t(u >> 32);
+  memcpy(&lo, &l, 4); memcpy(&hi, &h, 4);
+  lo = __shfl_xor(lo, mask); hi = __shfl_xor(hi, mask);
+  memcpy(&l, &lo, 4); memcpy(&h, &hi, 4);
+  u = (uint64_t(h) << 32) | l; memcpy(&v, &u, 8);
+  return v;
+}
+
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15];
+// it receives D[row=4*(l>>4)+r][col=l&15], r=0..3; each output is a k-ordered
+// fmaf chain (cdna_hip_programming.md section 3).
+typedef float emu_f32x4 __attribute__((vector_size(16)));
+static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+  auto& w = emu::ctx->wbuf[emu::wave];
+  w.a[emu::lane] = a;
+  w.b[emu::lane] = b;
+  emu::wave_sync();
+  const int col = emu::lane & 15, rg = emu::lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * rg + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(w.a[row + 16 * k], w.b[col + 16 * k], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}

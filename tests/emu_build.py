@@ -1,0 +1,24 @@
+"""Build (if stale) and load the host-side kernel-test library: the product's
+onssen_hip.hip compiled with g++ against the mock HIP runtime in tests/emu."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "onssen_amd", "csrc", "onssen_hip.hip")
+HDRS = [os.path.join(ROOT, "tests", "emu", "include", "hip", "hip_runtime.h"),
+        os.path.join(ROOT, "include", "onssen_hip.h")]
+OUT = os.path.join(ROOT, "tests", "emu", "libonssen_emu.so")
+
+
+def build_emu():
+    newest = max(os.path.getmtime(f) for f in [SRC] + HDRS)
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-I",
+                               os.path.join(ROOT, "tests", "emu", "include"), "-pthread", "-shared", "-fPIC",
+                               SRC, "-o", OUT])
+    return OUT
+
+
+def load_emu():
+    from onssen_amd._abi import Lib
+    return Lib(build_emu())

@@ -1,0 +1,150 @@
+"""Host-side kernel tests: the product's HIP source compiled against the mock
+HIP runtime (tests/emu) and driven through the same C ABI / ctypes binding as
+the GPU library, checked against the NumPy oracle.  Sizes are tiny (every
+work-item is an OS thread)."""
+import numpy as np
+import pytest
+
+from onssen_amd import _abi
+from onssen_amd.synthetic import make_state_dict, synth_mixture
+from oracle import np_oracle as O
+from tests.emu_build import load_emu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return load_emu()
+
+
+def P(a):
+    return a.ctypes.data if a is not None else None
+
+
+def rand(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode,group", [(_abi.EPI_BIAS, 0), (_abi.EPI_L2NORM, 20), (_abi.EPI_SIGMOID, 0),
+                                        (_abi.EPI_L2NORM, 2)])
+def test_linear_epilogues_and_row_maps(lib, mode, group):
+    rng = np.random.default_rng(1)
+    Bb, Tt, K, N = 3, 47, 37, 100          # M = 141 (2 row blocks, ragged), N = 100 (2 col blocks, ragged)
+    x = rand(rng, Bb, Tt, K)               # batch-major A, odd K -> scalar load path
+    ldw = 40
+    W = np.zeros((N, ldw), np.float32)
+    W[:, :K] = rand(rng, N, K)
+    bias = rand(rng, N)
+    resid = rand(rng, Bb, Tt, N) if group == 2 else None
+    out = np.full((Bb, Tt, N), np.nan, np.float32)
+    # logical rows are time-major (m = t*B + b): A and C live batch-major
+    lib.linear(P(x), Tt * 0 + K, Tt * K, Bb, Tt * Bb, K, P(W), ldw, P(bias), N, mode, group, 1e-12,
+               P(resid), P(out), N, Tt * N, None)
+    ref = x.astype(np.float64) @ W[:, :K].T.astype(np.float64) + bias
+    if mode == _abi.EPI_L2NORM:
+        if resid is not None:
+            ref = ref + resid
+        r = ref.reshape(Bb, Tt, N // group, group)
+        ref = (r / np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), 1e-12)).reshape(Bb, Tt, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = 1 / (1 + np.exp(-ref))
+    assert not np.isnan(out).any()
+    np.testing.assert_allclose(out, ref, atol=2e-5)
+
+
+def test_linear_vector_path_time_major(lib):
+    rng = np.random.default_rng(2)
+    M, K, N = 130, 48, 160
+    A = rand(rng, M, K)
+    W = rand(rng, N, K)
+    bias = rand(rng, N)
+    out = np.zeros((M, N), np.float32)
+    lib.linear(P(A), 4 * K, K, 4, M, K, P(W), K, P(bias), N, _abi.EPI_BIAS, 0, 0.0, None, P(out), 4 * N, N, None)
+    np.testing.assert_allclose(out, A.astype(np.float64) @ W.T + bias, atol=2e-5)
+
+
+def _pack_lstm(lib, sd, prefix, in_dim, H, L, ug):
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    wih, whh, bias = [], [], []
+    for l in range(L):
+        bidir = 0 if l == 0 else 1
+        Kp = (in_dim + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a = np.zeros((2, NP, Kp), np.float32)
+        b = np.zeros((2, we), np.float32)
+        c = np.zeros((2, NP), np.float32)
+        for d, sfx in enumerate(("", "_reverse")):
+            g = lambda n: np.ascontiguousarray(sd[f"{prefix}{n}_l{l}{sfx}"])
+            w_ih, w_hh, b_ih, b_hh = g("weight_ih"), g("weight_hh"), g("bias_ih"), g("bias_hh")
+            lib.lstm_pack(P(w_ih), P(w_hh), P(b_ih), P(b_hh), w_ih.shape[1], bidir, H, ug, P(a[d]), P(b[d]),
+                          P(c[d]), None)
+        wih.append(a); whh.append(b); bias.append(c)
+    return Hp, NP, wih, whh, bias
+
+
+@pytest.mark.parametrize("H,ug,B", [(8, 8, 3), (12, 8, 2), (12, 12, 17), (20, 20, 2), (8, 4, 2)])
+def test_blstm_stack_matches_oracle(lib, H, ug, B):
+    F, L, T = 9, 2, 4
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(3)
+    x = rand(rng, B, T, F)
+    Hp, NP, wih, whh, bias = _pack_lstm(lib, sd, "rnn.", F, H, L, ug)
+    ws = np.zeros(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64, np.float32)
+    y = np.full((T, B, 2, Hp), np.nan, np.float32)
+    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh],
+                      [P(a) for a in bias], P(y), P(ws), ws.nbytes, None)
+    ref = O.blstm_stack(x, sd, "rnn.", L)                      # (B, T, 2H)
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    np.testing.assert_allclose(got, ref, atol=2e-6)
+    assert np.all(y[:, :, :, H:] == 0)                         # padded units stay exactly zero
+
+
+def test_head_pack_folds_batchnorm(lib):
+    H, Hp, N = 6, 8, 10
+    rng = np.random.default_rng(4)
+    w, b = rand(rng, N, 2 * H), rand(rng, N)
+    g, beta, mean = rand(rng, 2 * H), rand(rng, 2 * H), rand(rng, 2 * H)
+    var = rng.uniform(0.1, 1, 2 * H).astype(np.float32)
+    wp, bp = np.full((N, 2 * Hp), np.nan, np.float32), np.zeros(N, np.float32)
+    lib.head_pack(P(w), P(b), N, H, Hp, P(g), P(beta), P(mean), P(var), 1e-5, P(wp), P(bp), None)
+    r = rand(rng, 5, 2 * H)
+    ref = ((r - mean) / np.sqrt(var + 1e-5) * g + beta) @ w.T + b
+    rp = np.zeros((5, 2 * Hp), np.float32)
+    rp[:, :H], rp[:, Hp:Hp + H] = r[:, :H], r[:, H:]
+    np.testing.assert_allclose(rp @ wp.T + bp, ref, atol=1e-5)
+    wp2, bp2 = np.zeros_like(wp), np.zeros_like(bp)
+    lib.head_pack(P(w), P(b), N, H, Hp, None, None, None, None, 0.0, P(wp2), P(bp2), None)
+    np.testing.assert_array_equal(bp2, b)
+    np.testing.assert_array_equal(wp2[:, :H], w[:, :H])
+
+
+@pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 700), (512, 128, 1400)])
+def test_stft_logmag_matches_oracle(lib, n_fft, hop, n):
+    B = 2
+    wav = np.stack([synth_mixture(5 + b, n) for b in range(B)])
+    T, F = 1 + n // hop, n_fft // 2 + 1
+    lm = np.full((B, T, F), np.nan, np.float32)
+    ri = np.full((B, T, F, 2), np.nan, np.float32)
+    lib.stft_logmag(P(wav), B, n, n, n_fft, hop, 1e-7, P(lm), P(ri), None)
+    for b in range(B):
+        X = O.stft(wav[b], n_fft, hop)
+        np.testing.assert_allclose(ri[b, ..., 0] + 1j * ri[b, ..., 1], X, atol=1e-6 * np.abs(X).max())
+        np.testing.assert_allclose(10.0 ** lm[b].astype(np.float64), np.abs(X) + 1e-7, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("n_fft,hop,n,length", [(256, 64, 2000, 2000), (256, 64, 2000, 2300), (512, 128, 3000, 2900),
+                                                (256, 100, 1500, 1500)])
+def test_mask_istft_matches_oracle(lib, n_fft, hop, n, length):
+    rng = np.random.default_rng(6)
+    B, Cn = 2, 2
+    F = n_fft // 2 + 1
+    specs = [O.stft(synth_mixture(20 + b, n), n_fft, hop) for b in range(B)]
+    T = specs[0].shape[0]
+    ri = np.stack([np.stack([s.real, s.imag], -1) for s in specs]).astype(np.float32)
+    masks = rng.random((B, T, F, Cn)).astype(np.float32)       # interleaved like fc_mi's output
+    out = np.full((B, Cn, length), np.nan, np.float32)
+    lib.mask_istft(P(ri), P(masks), T * F * Cn, 1, F * Cn, Cn, B, Cn, T, n_fft, hop, length, P(out), None)
+    for b in range(B):
+        ref = O.mask_istft(specs[b], masks[b].transpose(2, 0, 1), hop, length)
+        np.testing.assert_allclose(out[b], ref, atol=2e-6)
+    out1 = np.zeros((B, 1, length), np.float32)
+    lib.mask_istft(P(ri), None, 0, 0, 0, 0, B, 1, T, n_fft, hop, length, P(out1), None)
+    np.testing.assert_allclose(out1[0, 0], O.istft(specs[0], hop, length), atol=2e-6)
