@@ -1,0 +1,313 @@
+#!/usr/bin/env python
+"""bench.py -- separation throughput of the HIP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic 8 kHz
+2-speaker mixtures that is already resident in HBM:
+    K1+K2  framed STFT 256/64 + log-magnitude
+    K3-K8  deep-clustering network (BASELINE configs[1]: 2 x BLSTM-600, fc_dc + per-bin L2 normalise)
+    K10    mask-apply + iSTFT overlap-add for 2 speakers (binary masks resident in HBM: the
+           K-means assignment is host-side and not part of the timed path)
+captured once in a hipGraph and replayed.  N>1: one process per GPU (launched by
+torch.distributed.run), every rank separates its own batch -- utterances are independent, so
+there is no data-path collective ("scaling": "weak").
+
+Prints ONE JSON line (rank 0): metric = real-time factor (audio seconds separated per wall
+second, whole job), plus frames/s, a roofline block for the dominant kernel and the CPU
+baseline (oracle restatement on the host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, NFFT, HOP, T_FRAMES = 8000, 256, 64, 400
+N_SAMPLES = 25536                                    # 1 + 25536 // 64 = 400 frames
+FP32_MFMA_PEAK_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    # name: (kind, hidden, layers, batch per GPU)
+    "dc_l2": ("deep_clustering", 600, 2, 32),   # BASELINE.json configs[1] -- the headline workload
+    "dc_l3": ("deep_clustering", 600, 3, 16),   # as-shipped egs/wsj0-2mix/deep_clustering/config.json
+    "chimera_l4": ("chimera", 600, 4, 64),      # BASELINE.json configs[2]
+}
+
+
+def flops_per_frame(kind, F, H, L, D=20, C=2):
+    """sum_layers 2*2*4H*(in_l+H) + heads 2*2H*N (2 FLOP per MAC, forward)."""
+    fl = 0
+    for l in range(L):
+        fl += 2 * 2 * 4 * H * ((F if l == 0 else 2 * H) + H)
+    fl += 2 * 2 * H * F * D
+    if kind == "chimera":
+        fl += 2 * 2 * H * F * C
+    return fl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="dc_l2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="override chunks per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from onssen_amd import nn as onn
+    from onssen_amd.features import mask_istft, stft_logmag
+    from onssen_amd.hip import get_lib
+    from onssen_amd.synthetic import make_state_dict, synth_batch
+    get_lib()   # fail loudly if the HIP library is missing
+
+    kind, H, L, B = CONFIGS[args.config]
+    if args.batch:
+        B = args.batch
+    F, D = NFFT // 2 + 1, 20
+    sd = make_state_dict(kind, F, H, L, D, 2, seed=0)
+    cls = onn.deep_clustering if kind == "deep_clustering" else onn.chimera
+    model = cls(F, H, L, D)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(dev).eval()
+
+    # synthetic mixtures: 8 structured utterances per rank tiled to the batch (values do not change timing)
+    base = synth_batch(1 + rank, min(B, 8), N_SAMPLES, SR)
+    wav_np = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
+    wav = torch.from_numpy(wav_np).to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(rank)
+    m0 = (torch.rand(B, T_FRAMES, F, generator=gen) > 0.5).float()
+    bin_masks = torch.stack([m0, 1 - m0], -1).to(dev)   # stand-in for the K-means assignment
+
+    def step():
+        logmag, ri = stft_logmag(wav, NFFT, HOP)
+        outs = model([logmag])
+        if kind == "chimera":
+            sig = mask_istft(ri, outs[1]._base, HOP, N_SAMPLES)
+        else:
+            sig = mask_istft(ri, bin_masks, HOP, N_SAMPLES)
+        return outs[0], sig
+
+    with torch.no_grad():
+        step()                                   # packs weights, allocates workspaces
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                step()
+            torch.cuda.current_stream().wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                emb, sig = step()
+        run = graph.replay if graph is not None else step
+
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+
+        # ---- per-kernel timing leg (HIP events on the launch stream), outside the timed region
+        roof = kernel_roofline(model, wav, dev, kind, F, H, L, B, D) if rank == 0 else None
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    frames = B * T_FRAMES * world * args.steps
+    audio_s = B * world * args.steps * (T_FRAMES * HOP / SR)
+    result = {
+        "metric": "real_time_factor",
+        "value": audio_s / elapsed,
+        "unit": "audio-seconds separated per wall-second (x real time), whole job",
+        "frames_per_s": frames / elapsed,
+        "sep_hours_per_s": audio_s / elapsed / 3600.0,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, 8 kHz STFT "
+                               f"{NFFT}/{HOP}, {B} x {T_FRAMES}-frame chunks per GPU; step = STFT+log-mag -> BLSTM "
+                               "-> fc_dc + L2-normalise -> mask-apply + iSTFT (2 speakers)",
+                   "chunks_per_gpu": B, "frames_per_chunk": T_FRAMES, "launch": "hipGraph replay" if graph else "eager",
+                   "parallelism": f"utterance-sharded x{world}, no data-path collective"},
+    }
+    if rank == 0:
+        result["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, kind, wav_np, bin_masks.cpu().numpy())
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
+    """Roofline block for the dominant kernel.  Both candidates are bound by the exact-fp32 MFMA
+    rate (157.3 TFLOP/s).  The recurrence (lstm_step_kernel, T launches per layer) is timed as the
+    event-bracketed span of a layer's T dependent launches divided by T, so the figure includes the
+    dependent-launch gap that the serial chain really pays (rocprof's per-kernel duration excludes
+    it; see DESIGN.md section 'Measurement')."""
+    from onssen_amd.features import stft_logmag
+    from onssen_amd.hip import get_lib
+    from onssen_amd.nn._core import _stream
+    lib = get_lib()
+    T = T_FRAMES
+    logmag, _ = stft_logmag(wav, NFFT, HOP)
+    pk = model._packed.get()
+    ug, Hp, NP = pk.ug, pk.Hp, pk.NP
+    y = torch.empty(T, B, 2, Hp, device=dev)
+    nbytes = lib.blstm_workspace_bytes(B, T, H, 1, ug)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # one layer (layer 1 shapes: in = 2H) as its own call: GEMM + T steps
+    xin = torch.randn(B, T, F, device=dev)
+    st = _stream()
+
+    def layer0():
+        lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [pk.wih[0].data_ptr()],
+                          [pk.whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(), st)
+
+    def gemm0():
+        lib.linear(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, pk.wih[0].data_ptr(), (F + 3) // 4 * 4,
+                   pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, ws.data_ptr(), B * 2 * NP, 2 * NP, st)
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_layer = timed(layer0)
+    t_gemm0 = timed(gemm0)
+    t_step = (t_layer - t_gemm0) / T
+    flop_step = 2.0 * 2 * B * 4 * H * H                      # both directions, 2 FLOP/MAC
+    # big GEMM (layer>=1 input projection): M = B*T, N = 8H, K = 2H
+    yin = torch.randn(T, B, 2 * Hp, device=dev)
+    if L > 1:
+        def gemm1():
+            lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,
+                       pk.bias[1].data_ptr(), 2 * NP, 0, 0, 0.0, None, ws.data_ptr(), B * 2 * NP, 2 * NP, st)
+        t_gemm1 = timed(gemm1)
+    else:
+        t_gemm1 = 0.0
+    flop_gemm1 = 2.0 * B * T * 8 * H * 2 * H
+    hd = model._head_dc if kind == "chimera" else model._head
+    hp = hd.get(Hp)
+    out = torch.empty(B, T, hp.N, device=dev)
+
+    def head():
+        lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hp.w.data_ptr(), 2 * Hp, hp.b.data_ptr(), hp.N,
+                   1, D, 1e-12, None, out.data_ptr(), hp.N, T * hp.N, st)
+    t_head = timed(head)
+    flop_head = 2.0 * B * T * hp.N * 2 * H
+    tot_rec = t_step * T * L
+    tot_gemm = t_gemm0 + (L - 1) * t_gemm1 + t_head
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        traffic = json.load(open(tf)).get("lstm_step_kernel_bytes_per_launch")
+    rec = {"kernel": "lstm_step_kernel", "bound": "mfma", "achieved": flop_step / t_step / 1e12,
+           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_step / t_step / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+           "traffic": traffic, "us_per_launch": t_step * 1e6, "launches_per_step": T * L,
+           "algorithmic_flop_per_launch": flop_step, "share_of_step_ms": tot_rec * 1e3,
+           "note": "duration = event-bracketed span of a layer's dependent launches / T (includes the launch gap)"}
+    gem = {"kernel": "linear_kernel", "bound": "mfma",
+           "achieved_by_call": {"wih_l0": 2.0 * B * T * 8 * H * F / t_gemm0 / 1e12,
+                                "wih_l1": (flop_gemm1 / t_gemm1 / 1e12) if L > 1 else None,
+                                "fc_dc_l2norm": flop_head / t_head / 1e12},
+           "ms_by_call": {"wih_l0": t_gemm0 * 1e3, "wih_l1": t_gemm1 * 1e3, "fc_dc_l2norm": t_head * 1e3},
+           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "share_of_step_ms": tot_gemm * 1e3}
+    rec["other_kernels"] = gem
+    if tot_gemm > tot_rec and L > 1:   # report whichever kernel owns more of the step
+        a = flop_gemm1 / t_gemm1 / 1e12
+        rec = {"kernel": "linear_kernel (layer-1 input projection)", "bound": "mfma", "achieved": a,
+               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+               "other_kernels": {"lstm_step_kernel": rec, "linear_kernel": gem}}
+    return rec
+
+
+def cpu_baseline(sd, kind, wav_np, masks_np):
+    """The oracle restatement (NumPy STFT/iSTFT + ATen-on-CPU network) timed on this host's cores on
+    a bounded sample of the same workload."""
+    from oracle import np_oracle as O
+    from oracle import torch_cpu as TC
+    n_thr = torch.get_num_threads()
+    Bs = min(len(wav_np), 8)                     # bounded sample: 8 chunks of the batch
+    wav_np, masks_np = wav_np[:Bs], masks_np[:Bs]
+
+    def once():
+        X = [O.stft(w, NFFT, HOP) for w in wav_np]
+        lm = np.stack([O.log_magnitude(x) for x in X])
+        if kind == "chimera":
+            _, a, b = TC.chimera_forward(sd, lm)
+            mk = np.stack([a.numpy(), b.numpy()], 1)
+        else:
+            TC.deep_clustering_forward(sd, lm)
+            mk = masks_np.transpose(0, 3, 1, 2)
+        for i in range(Bs):
+            O.mask_istft(X[i], mk[i], HOP, N_SAMPLES)
+
+    once()
+    ts = []
+    t_start = time.perf_counter()
+    while len(ts) < 10 and time.perf_counter() - t_start < 20.0:
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
+            "frames_per_s": Bs * T_FRAMES / med, "cores": n_thr, "kind": "port",
+            "sample": f"{Bs} of the batch's 400-frame chunks per pass, median of {len(ts)} passes "
+                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {n_thr} threads)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,15 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K11 glue  recurrent input of the phase network for all C speakers at once:
+ *   out[(s*B + b), t, :] = cat(x_mag[b,t,:] * mask[b,s,t,:], x_phase[b,t,:,:].view(2F))      (C*B, T, 3F)
+ * Replaces `mag_A = x_mag * mask_A; input_A = torch.cat((mag_A, x_phase.view(B,T,-1)), 2)` (and _B) at
+ * onssen/nn/phase_network.py:45-47,54.  mask element (b,s,t,f) at mask + b*m_sb + s*m_sc + t*m_st + f*m_sf.
+ */
+int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                           int64_t m_sf, const float* x_phase, int B, int C, int T, int F, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10  mask-apply + inverse STFT overlap-add.
  * Replaces `stft_est = stft_mix * mask; librosa.core.istft(stft_est[i].T, hop_length, length)` at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:42-45 and egs/wsj0-2mix/chimera/evaluate.py:40-43.

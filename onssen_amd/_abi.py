@@ -24,6 +24,7 @@ SIGNATURES = {
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _vp]),
+    "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
@@ -85,3 +86,7 @@ class Lib:
     def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
         self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,
                                                   length, out, stream), "onssen_mask_istft_f32")
+
+    def phase_input(self, x_mag, mask, m_sb, m_sc, m_st, m_sf, x_phase, B, Cn, T, F, out, stream):
+        self.check(self.dll.onssen_phase_input_f32(x_mag, mask, m_sb, m_sc, m_st, m_sf, x_phase, B, Cn, T, F, out,
+                                                   stream), "onssen_phase_input_f32")

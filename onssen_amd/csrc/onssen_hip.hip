@@ -112,6 +112,27 @@ __global__ void pack_head_kernel(const float* __restrict__ w, const float* __res
   if (tid == 0) b_p[n] = b[n] + red[0];
 }
 
+// K11 glue: phase-network recurrent input  cat(x_mag * mask_s, x_phase.view(B,T,2F)) for every speaker s,
+// stacked on the batch axis so that the shared-weight BLSTM runs once with batch C*B.
+__global__ void phase_input_kernel(const float* __restrict__ x_mag, const float* __restrict__ mask, long m_sb,
+                                   long m_sc, long m_st, long m_sf, const float* __restrict__ x_phase, int B, int C,
+                                   int T, int F, float* __restrict__ out) {
+  const long total = (long)C * B * T * 3 * F;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e % (3 * F));
+    long rest = e / (3 * F);
+    const int t = (int)(rest % T);
+    rest /= T;
+    const int b = (int)(rest % B), sidx = (int)(rest / B);
+    float v;
+    if (j < F)
+      v = x_mag[((long)b * T + t) * F + j] * mask[(long)b * m_sb + (long)sidx * m_sc + (long)t * m_st + (long)j * m_sf];
+    else
+      v = x_phase[((long)b * T + t) * 2 * F + (j - F)];
+    out[e] = v;
+  }
+}
+
 // =================================================================================================
 // K3/K7/K8/K9: exact-fp32 MFMA GEMM  C = epi(A W^T + bias)
 // =================================================================================================
@@ -765,6 +786,17 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
 #undef ONSSEN_STEPS
     if (rc != ONSSEN_OK) return rc;
   }
+  return ONSSEN_OK;
+}
+
+int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                           int64_t m_sf, const float* x_phase, int B, int C, int T, int F, float* out, void* stream) {
+  if (!x_mag || !mask || !x_phase || !out || B <= 0 || C <= 0 || T <= 0 || F <= 0) return ONSSEN_E_ARG;
+  const long total = (long)C * B * T * 3 * F;
+  const long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(phase_input_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream,
+                     x_mag, mask, (long)m_sb, (long)m_sc, (long)m_st, (long)m_sf, x_phase, B, C, T, F, out);
+  ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
 

@@ -1,0 +1,200 @@
+"""Shared host-side plumbing of the onssen_amd.nn modules: parameter
+containers with the reference's state_dict layout, weight packing for the HIP
+kernels, workspace caching and the launch sequences.
+
+PyTorch is used for device memory, streams and (training only) autograd; the
+inference arithmetic is in libonssen_hip.so.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _abi
+from ..hip import get_lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def default_unit_group():
+    """Hidden units per recurrence workgroup (ABI parameter `ug`)."""
+    return int(os.environ.get("ONSSEN_UG", "8"))
+
+
+class BLSTMParams(nn.Module):
+    """Parameter container with nn.LSTM(bidirectional=True)'s names, shapes
+    and default init, so reference checkpoints load unchanged:
+    weight_ih_l{k}[_reverse] (4H,in_k), weight_hh_l{k}[_reverse] (4H,H),
+    bias_ih_l{k}[_reverse], bias_hh_l{k}[_reverse] (4H); rows i,f,g,o."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.dropout = num_layers, float(dropout)
+        bound = 1.0 / math.sqrt(hidden_size)
+        for k in range(num_layers):
+            in_k = input_size if k == 0 else 2 * hidden_size
+            for sfx in ("", "_reverse"):
+                for name, shape in ((f"weight_ih_l{k}{sfx}", (4 * hidden_size, in_k)),
+                                    (f"weight_hh_l{k}{sfx}", (4 * hidden_size, hidden_size)),
+                                    (f"bias_ih_l{k}{sfx}", (4 * hidden_size,)),
+                                    (f"bias_hh_l{k}{sfx}", (4 * hidden_size,))):
+                    self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-bound, bound)))
+
+    def flatten_parameters(self):
+        """cuDNN weight-packing hint in the reference (deep_clustering.py:34); no-op here."""
+
+    def flat_weights(self):
+        out = []
+        for k in range(self.num_layers):
+            for sfx in ("", "_reverse"):
+                out += [getattr(self, f"weight_ih_l{k}{sfx}"), getattr(self, f"weight_hh_l{k}{sfx}"),
+                        getattr(self, f"bias_ih_l{k}{sfx}"), getattr(self, f"bias_hh_l{k}{sfx}")]
+        return out
+
+    def autograd_forward(self, x, training):
+        """Training path (needs autograd): the stock ATen LSTM op on the ROCm
+        device.  NOT the product's inference path -- see DESIGN.md 'scope'."""
+        B = x.shape[0]
+        z = x.new_zeros(2 * self.num_layers, B, self.hidden_size)
+        out, _, _ = torch._VF.lstm(x, (z, z), self.flat_weights(), True, self.num_layers,
+                                   self.dropout if training else 0.0, training, True, True)
+        return out
+
+
+def _version_key(tensors):
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+
+
+class PackedBLSTM:
+    """Device images of a BLSTMParams for the HIP kernels, rebuilt when any
+    parameter changes (in-place optimizer steps bump ``_version``)."""
+
+    def __init__(self, params: BLSTMParams, ug):
+        self.p, self.ug = params, ug
+        self.key = None
+
+    def get(self):
+        p, lib = self.p, get_lib()
+        flat = p.flat_weights()
+        key = _version_key(flat)
+        if key == self.key:
+            return self
+        dev = flat[0].device
+        H, L = p.hidden_size, p.num_layers
+        self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
+        self.wih, self.whh, self.bias = [], [], []
+        st = _stream()
+        for l in range(L):
+            in_l = p.input_size if l == 0 else 2 * H
+            Kp = (in_l + 3) // 4 * 4 if l == 0 else 2 * self.Hp
+            a = torch.empty(2, self.NP, Kp, device=dev, dtype=torch.float32)
+            b = torch.empty(2, we, device=dev, dtype=torch.float32)
+            c = torch.empty(2, self.NP, device=dev, dtype=torch.float32)
+            for d in range(2):
+                w_ih, w_hh, b_ih, b_hh = [t.detach().contiguous() for t in flat[(2 * l + d) * 4:(2 * l + d) * 4 + 4]]
+                lib.lstm_pack(w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), in_l,
+                              0 if l == 0 else 1, H, self.ug, a[d].data_ptr(), b[d].data_ptr(), c[d].data_ptr(), st)
+            self.wih.append(a), self.whh.append(b), self.bias.append(c)
+        self.key = key
+        return self
+
+
+class PackedHead:
+    """nn.Linear(2H -> N) re-laid for the [fwd(Hp)|rev(Hp)] activations, with
+    an optional eval-mode BatchNorm1d(2H) folded in."""
+
+    def __init__(self, linear: nn.Linear, bn, H):
+        self.lin, self.bn, self.H = linear, bn, H
+        self.key = None
+
+    def get(self, Hp):
+        lin, bn = self.lin, self.bn
+        ts = [lin.weight, lin.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        key = (_version_key(ts), Hp)
+        if key == self.key:
+            return self
+        lib, dev, N = get_lib(), lin.weight.device, lin.weight.shape[0]
+        self.w = torch.empty(N, 2 * Hp, device=dev, dtype=torch.float32)
+        self.b = torch.empty(N, device=dev, dtype=torch.float32)
+        w, b = lin.weight.detach().contiguous(), lin.bias.detach().contiguous()
+        if bn is not None:
+            g, be, mu, var = [t.detach().contiguous() for t in ts[2:]]
+            lib.head_pack(w.data_ptr(), b.data_ptr(), N, self.H, Hp, g.data_ptr(), be.data_ptr(), mu.data_ptr(),
+                          var.data_ptr(), float(bn.eps), self.w.data_ptr(), self.b.data_ptr(), _stream())
+        else:
+            lib.head_pack(w.data_ptr(), b.data_ptr(), N, self.H, Hp, None, None, None, None, 0.0,
+                          self.w.data_ptr(), self.b.data_ptr(), _stream())
+        self.N, self.key = N, key
+        return self
+
+
+class _Workspaces:
+    """Caller-owned scratch buffers, cached per shape so that steady-state
+    forwards allocate nothing (and stay hipGraph-capturable)."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, key, nbytes, device):
+        buf = self.cache.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.cache[key] = buf
+        return buf
+
+
+def require_device(x, who):
+    if not x.is_cuda:
+        raise RuntimeError(f"{who}: the HIP inference path needs tensors on a ROCm device (got {x.device}); "
+                           "onssen_amd has no CPU fallback")
+
+
+def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
+    """x (B,T,In) float32 cuda -> y (T,B,2,Hp) time-major (padded units are 0)."""
+    lib, pk = get_lib(), packed.get()
+    p = pk.p
+    B, T, In = x.shape
+    if In != p.input_size:
+        raise RuntimeError(f"input feature size {In} != {p.input_size}")
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    nbytes = lib.blstm_workspace_bytes(B, T, p.hidden_size, p.num_layers, pk.ug)
+    wsb = ws.get((tag, B, T), nbytes, x.device)
+    y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
+    lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
+                      [t.data_ptr() for t in pk.wih], [t.data_ptr() for t in pk.whh],
+                      [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), _stream())
+    return y
+
+
+def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_off=0, b_total=None):
+    """y (T, Btot, 2, Hp) time-major -> (B, T, N) batch-major with the fused
+    epilogue.  ``b_off``/``b_total`` select a batch slice of y (phase net)."""
+    lib = get_lib()
+    Btot = y.shape[1] if b_total is None else b_total
+    Hp = y.shape[3]
+    hd = head.get(Hp)
+    out = torch.empty(B, T, hd.N, device=y.device, dtype=torch.float32)
+    a_ptr = y.data_ptr() + b_off * 2 * Hp * 4
+    lib.linear(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.w.data_ptr(), 2 * Hp, hd.b.data_ptr(), hd.N,
+               mode, group, eps, resid.data_ptr() if resid is not None else None, out.data_ptr(), hd.N, T * hd.N,
+               _stream())
+    return out
+
+
+def use_hip_path(module):
+    """Inference (eval mode, no autograd graph needed) -> HIP kernels.
+    Anything that needs autograd or train-mode BatchNorm/dropout takes the
+    documented ATen training path."""
+    if module.training:
+        return False
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        return False
+    return True
+
+
+EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = _abi.EPI_BIAS, _abi.EPI_L2NORM, _abi.EPI_SIGMOID

@@ -1,0 +1,46 @@
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
+                    default_unit_group, require_device, run_blstm, run_head, use_hip_path)
+
+
+class chimera(nn.Module):
+    """Drop-in for onssen.nn.chimera (onssen/nn/chimera.py:5-46).
+
+    forward([x (B,T,F)]) -> [embedding (B,T,F,D), mask_A (B,T,F), mask_B (B,T,F)];
+    the masks are strided views of one (B,T,F,C) buffer exactly as upstream.
+    """
+
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, num_speaker=2):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.num_layers, self.embedding_dim, self.num_speaker = num_layers, embedding_dim, num_speaker
+        self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))
+        self.add_module("fc_dc", nn.Linear(hidden_dim * 2, input_dim * embedding_dim))
+        self.add_module("fc_mi", nn.Linear(hidden_dim * 2, input_dim * num_speaker))
+        self._packed = PackedBLSTM(self.rnn, default_unit_group())
+        self._head_dc = PackedHead(self.fc_dc, None, hidden_dim)
+        self._head_mi = PackedHead(self.fc_mi, None, hidden_dim)
+        self._ws = _Workspaces()
+
+    def forward(self, input):
+        assert len(input) == 1, "There must be one tensor in the input for the chimera network"
+        x = input[0].float()
+        batch_size, frame, frequency = x.size()
+        if not use_hip_path(self):
+            return self._autograd_forward(x)
+        require_device(x, "chimera")
+        y = run_blstm(self._packed, self._ws, x)
+        emb = run_head(self._head_dc, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
+        masks = run_head(self._head_mi, y, batch_size, frame, EPI_SIGMOID)
+        masks = masks.view(batch_size, frame, frequency, -1)
+        return [emb.view(batch_size, frame, frequency, -1), masks[:, :, :, 0], masks[:, :, :, 1]]
+
+    def _autograd_forward(self, x):
+        B, T, Fq = x.shape
+        r = self.rnn.autograd_forward(x, self.training)
+        e = F.normalize(self.fc_dc(r).reshape(B, T * Fq, -1), p=2, dim=-1).reshape(B, T, Fq, -1)
+        m = torch.sigmoid(self.fc_mi(r)).reshape(B, T, Fq, -1)
+        return [e, m[:, :, :, 0], m[:, :, :, 1]]

@@ -1,0 +1,46 @@
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, default_unit_group,
+                    require_device, run_blstm, run_head, use_hip_path)
+
+
+class deep_clustering(nn.Module):
+    """Drop-in for onssen.nn.deep_clustering (onssen/nn/deep_clustering.py:5-43):
+    same constructor, parameter names/shapes and list-in/list-out forward.
+
+    forward([x (B,T,F)]) -> [embedding (B,T,F,D)], unit L2 norm per TF bin.
+    In eval mode without autograd the arithmetic runs in libonssen_hip.so
+    (input-projection GEMM, per-step recurrence kernels, BatchNorm folded into
+    the fc_dc GEMM whose epilogue normalises each bin).
+    """
+
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3):
+        super().__init__()
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.num_layers, self.embedding_dim = num_layers, embedding_dim
+        self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))
+        self.add_module("bn", nn.BatchNorm1d(hidden_dim * 2))
+        self.add_module("fc_dc", nn.Linear(hidden_dim * 2, embedding_dim * input_dim))
+        self._packed = PackedBLSTM(self.rnn, default_unit_group())
+        self._head = PackedHead(self.fc_dc, self.bn, hidden_dim)
+        self._ws = _Workspaces()
+
+    def forward(self, input):
+        assert len(input) == 1, "There must be one tensor in the input for the deep clustering model"
+        x = input[0].float()
+        batch_size, frame, frequency = x.size()
+        if not use_hip_path(self):
+            return [self._autograd_forward(x)]
+        require_device(x, "deep_clustering")
+        y = run_blstm(self._packed, self._ws, x)
+        emb = run_head(self._head, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
+        return [emb.view(batch_size, frame, frequency, -1)]
+
+    def _autograd_forward(self, x):
+        B, T, Fq = x.shape
+        r = self.rnn.autograd_forward(x, self.training)
+        r = self.bn(r.permute(0, 2, 1)).permute(0, 2, 1)
+        e = F.normalize(self.fc_dc(r).view(B, T * Fq, -1), p=2, dim=-1)
+        return e.reshape(B, T, Fq, -1)

@@ -1,0 +1,249 @@
+"""Parity of the HIP path (through the C ABI / onssen_amd modules) against the
+oracle and the committed golden vectors.  Runs on the GPU box only (-m gpu);
+nothing here reads /root/reference.
+
+Tolerances (fp32 path): elementwise |a-b| <= 1e-5 + 1e-4*|b| on
+embeddings / masks, per-vector rel-L2 <= 1e-4; log-magnitude is compared
+through |X| (log10 of a near-zero bin amplifies fp32 round-off)."""
+import numpy as np
+import pytest
+import torch
+
+from onssen_amd import _abi
+from onssen_amd.synthetic import make_state_dict, synth_mixture
+from oracle import np_oracle as O
+from oracle import torch_cpu as TC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from onssen_amd.hip import get_lib
+    get_lib()   # fail loudly if libonssen_hip.so is missing
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-30)
+
+
+def build(kind, z_or_cfg, dev):
+    from onssen_amd import nn as onn
+    c = {k: (z_or_cfg[k].item() if hasattr(z_or_cfg[k], "item") else z_or_cfg[k]) for k in
+         ("F", "H", "L", "D", "C", "seed", "gain")}
+    sd = make_state_dict(kind, int(c["F"]), int(c["H"]), int(c["L"]), int(c["D"]), int(c["C"]), seed=int(c["seed"]),
+                         gain=float(c["gain"]))
+    cls = {"deep_clustering": onn.deep_clustering, "chimera": onn.chimera, "phase_net": onn.phase_net}[kind]
+    m = cls(int(c["F"]), int(c["H"]), int(c["L"]), int(c["D"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def logmag_input(seed, B, T):
+    return np.stack([O.log_magnitude(O.stft(synth_mixture(seed * 100 + b, (T - 1) * 64), 256, 64))
+                     for b in range(B)])
+
+
+# ---------------------------------------------------------------- kernels through the ABI
+@pytest.mark.parametrize("M,K,N,mode,group", [(1000, 1200, 2580, _abi.EPI_L2NORM, 20), (333, 129, 4800, _abi.EPI_BIAS, 0),
+                                              (257, 1200, 258, _abi.EPI_SIGMOID, 0), (128, 64, 80, _abi.EPI_BIAS, 0)])
+def test_linear_kernel(dev, M, K, N, mode, group):
+    from onssen_amd.hip import get_lib
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    ldw = (K + 3) // 4 * 4
+    W = torch.zeros(N, ldw)
+    W[:, :K] = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    get_lib().linear(Ad.data_ptr(), K, 0, 1, M, K, Wd.data_ptr(), ldw, bd.data_ptr(), N, mode, group, 1e-12, None,
+                     out.data_ptr(), N, 0, torch.cuda.current_stream().cuda_stream)
+    ref = A.double() @ W[:, :K].double().T + bias.double()
+    if mode == _abi.EPI_L2NORM:
+        r = ref.view(M, N // group, group)
+        ref = (r / r.norm(dim=-1, keepdim=True).clamp_min(1e-12)).view(M, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = torch.sigmoid(ref)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------- golden vectors of the reference
+@pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
+def test_dc_tiny_golden(dev, golden_dir, name):
+    z = np.load(f"{golden_dir}/{name}.npz")
+    m, _ = build("deep_clustering", z, dev)
+    with torch.no_grad():
+        emb, = m([torch.from_numpy(z["x"]).to(dev)])
+    emb = emb.cpu().numpy()
+    assert emb.shape == z["out_embedding"].shape
+    np.testing.assert_allclose(emb, z["out_embedding"], atol=1e-5, rtol=1e-4)
+    assert rel_l2(emb, z["out_embedding"]).max() < 1e-4
+
+
+def test_chimera_tiny_golden(dev, golden_dir):
+    z = np.load(f"{golden_dir}/g1_chimera_H32_L2.npz")
+    m, _ = build("chimera", z, dev)
+    with torch.no_grad():
+        e, a, b = m([torch.from_numpy(z["x"]).to(dev)])
+    assert a.shape == z["out_mask_A"].shape and not a.is_contiguous()   # strided views like upstream
+    np.testing.assert_allclose(e.cpu().numpy(), z["out_embedding"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(a.cpu().numpy(), z["out_mask_A"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(b.cpu().numpy(), z["out_mask_B"], atol=1e-5, rtol=1e-4)
+
+
+def test_phase_net_tiny_golden(dev, golden_dir):
+    z = np.load(f"{golden_dir}/g1_phase_net_H16_L2.npz")
+    m, _ = build("phase_net", z, dev)
+    with torch.no_grad():
+        outs = m([torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["x_phase"]).to(dev)])
+    for o, n in zip(outs, ["embedding", "mask_A", "mask_B", "phase_A", "phase_B"]):
+        tol = 1e-4 if n.startswith("phase") else 1e-5   # 2-vector normalisation amplifies round-off
+        np.testing.assert_allclose(o.cpu().numpy(), z["out_" + n], atol=tol, rtol=1e-4, err_msg=n)
+
+
+@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg1_dc_L3", "deep_clustering"),
+                                      ("cfg3_chimera_L4", "chimera")])
+def test_full_size_golden_subsample(dev, golden_dir, tag, kind):
+    """BASELINE configs at full width (H=600, T=400) against the reference's
+    strided output subsample and per-frame checksums."""
+    z = np.load(f"{golden_dir}/g2_{tag}.npz")
+    m, _ = build(kind, z, dev)
+    x = logmag_input(int(z["x_seed"]), int(z["B"]), int(z["T"]))
+    with torch.no_grad():
+        outs = m([torch.from_numpy(x).to(dev)])
+    emb = outs[0].cpu().numpy()
+    np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5, rtol=1e-4)
+    assert rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max() < 1e-4
+    np.testing.assert_allclose(emb.astype(np.float64).sum(axis=(2, 3)), z["emb_sum_per_frame"], atol=5e-3)
+    if kind == "chimera":
+        np.testing.assert_allclose(outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
+
+
+# ---------------------------------------------------------------- oracle at other shapes / edge cases
+@pytest.mark.parametrize("B,T,H,L", [(1, 400, 600, 2), (5, 37, 600, 2), (33, 21, 300, 3), (17, 1, 64, 2), (2, 50, 30, 1)])
+def test_dc_matches_oracle_ragged_shapes(dev, B, T, H, L):
+    cfg = dict(F=129, H=H, L=L, D=20, C=2, seed=3, gain=1.5)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = logmag_input(11, B, max(T, 3))[:, :T]
+    ref = TC.deep_clustering_forward(sd, x).numpy()
+    with torch.no_grad():
+        emb, = m([torch.from_numpy(x).to(dev)])
+    emb = emb.cpu().numpy()
+    np.testing.assert_allclose(emb, ref, atol=1e-5, rtol=1e-4)
+    assert rel_l2(emb, ref).max() < 1e-4
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=-1), 1.0, atol=1e-5)   # unit embeddings
+
+
+@pytest.mark.parametrize("ug", [4, 8, 12, 20])
+def test_unit_group_variants_agree(dev, monkeypatch, ug):
+    monkeypatch.setenv("ONSSEN_UG", str(ug))
+    cfg = dict(F=129, H=120, L=2, D=20, C=2, seed=8, gain=1.5)
+    m, sd = build("chimera", cfg, dev)
+    x = logmag_input(12, 18, 30)
+    ref = TC.chimera_forward(sd, x)
+    with torch.no_grad():
+        outs = m([torch.from_numpy(x).to(dev)])
+    for o, r in zip(outs, ref):
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=1e-5, rtol=1e-4)
+
+
+def test_deterministic_and_graph_replay(dev):
+    cfg = dict(F=129, H=64, L=2, D=20, C=2, seed=2, gain=1.0)
+    m, _ = build("deep_clustering", cfg, dev)
+    x = torch.from_numpy(logmag_input(13, 4, 40)).to(dev)
+    with torch.no_grad():
+        a = m([x])[0].clone()
+        b = m([x])[0].clone()
+        assert torch.equal(a, b)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m([x])
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m([x])[0]
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a)
+
+
+def test_weight_update_repacks(dev):
+    cfg = dict(F=129, H=16, L=1, D=20, C=2, seed=2, gain=1.0)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = torch.from_numpy(logmag_input(14, 2, 10)).to(dev)
+    with torch.no_grad():
+        a = m([x])[0].clone()
+        m.rnn.weight_hh_l0.mul_(0.5)
+        b = m([x])[0]
+    assert not torch.equal(a, b)
+    sd["rnn.weight_hh_l0"] = sd["rnn.weight_hh_l0"] * 0.5
+    np.testing.assert_allclose(b.cpu().numpy(), TC.deep_clustering_forward(sd, x.cpu().numpy()).numpy(), atol=1e-5)
+
+
+def test_cpu_tensor_fails_loudly(dev):
+    m, _ = build("deep_clustering", dict(F=129, H=8, L=1, D=20, C=2, seed=1, gain=1.0), dev)
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
+        m([torch.zeros(1, 4, 129)])
+    with pytest.raises(AssertionError, match="one tensor"), torch.no_grad():
+        m([torch.zeros(1, 4, 129), torch.zeros(1)])
+
+
+# ---------------------------------------------------------------- front end / back end
+@pytest.mark.parametrize("n_fft,hop,n,B", [(256, 64, 25536, 4), (512, 128, 16000, 3), (256, 64, 129, 1), (1024, 256, 9000, 2)])
+def test_stft_logmag(dev, n_fft, hop, n, B):
+    from onssen_amd.features import stft_logmag
+    wav = np.stack([synth_mixture(30 + b, n) for b in range(B)])
+    lm, ri = stft_logmag(torch.from_numpy(wav).to(dev), n_fft, hop)
+    lm, ri = lm.cpu().numpy(), ri.cpu().numpy()
+    for b in range(B):
+        X = O.stft(wav[b], n_fft, hop)
+        assert lm[b].shape == X.shape
+        got = ri[b, ..., 0] + 1j * ri[b, ..., 1]
+        assert np.abs(got - X).max() <= 2e-7 * np.abs(X).max() + 1e-9   # fp64 butterflies, complex64 rounding
+        np.testing.assert_allclose(10.0 ** lm[b].astype(np.float64), np.abs(X).astype(np.float64) + 1e-7,
+                                   rtol=2e-6, atol=1e-9)
+        big = np.abs(X) > 1e-3
+        np.testing.assert_allclose(lm[b][big], O.log_magnitude(X)[big], atol=2e-6)
+
+
+@pytest.mark.parametrize("n_fft,hop,n,length", [(256, 64, 25536, 25536), (256, 64, 5000, 5400), (512, 128, 16000, 15000),
+                                                (256, 100, 4000, 4000)])
+def test_mask_istft_and_roundtrip(dev, n_fft, hop, n, length):
+    from onssen_amd.features import mask_istft, stft_logmag
+    B = 2
+    wav = np.stack([synth_mixture(50 + b, n) for b in range(B)])
+    wd = torch.from_numpy(wav).to(dev)
+    _, ri = stft_logmag(wd, n_fft, hop)
+    T, F = ri.shape[1], ri.shape[2]
+    rng = np.random.default_rng(0)
+    m0 = rng.random((B, T, F)).astype(np.float32)
+    masks = torch.from_numpy(np.stack([m0, 1 - m0], -1)).to(dev)
+    out = mask_istft(ri, masks, hop, length).cpu().numpy()
+    for b in range(B):
+        X = O.stft(wav[b], n_fft, hop)
+        ref = O.mask_istft(X, np.stack([m0[b], 1 - m0[b]]), hop, length)
+        np.testing.assert_allclose(out[b], ref, atol=2e-6)
+    # size-independent properties: masks summing to one split the mixture; stft->istft is the identity
+    y = mask_istft(ri, None, hop, length).cpu().numpy()[:, 0]
+    np.testing.assert_allclose(out.sum(1), y, atol=2e-6)
+    k = min(n, length)
+    np.testing.assert_allclose(y[:, :k], wav[:, :k], atol=2e-6)
+
+
+def test_end_to_end_separation_chimera(dev):
+    from onssen_amd.separation import separate_chimera
+    m, sd = build("chimera", dict(F=129, H=48, L=2, D=20, C=2, seed=4, gain=1.5), dev)
+    wav = np.stack([synth_mixture(70 + b, 6400) for b in range(2)])
+    sig = separate_chimera(m, torch.from_numpy(wav).to(dev)).cpu().numpy()
+    for b in range(2):
+        X = O.stft(wav[b], 256, 64)
+        _, a, bb = O.chimera_forward(sd, O.log_magnitude(X)[None])
+        ref = O.mask_istft(X, np.stack([a[0], bb[0]]), 64, 6400)
+        np.testing.assert_allclose(sig[b], ref, atol=1e-5)

@@ -104,3 +104,19 @@ def test_istft_longer_than_signal_pads_with_zeros():
     X = O.stft(synth_mixture(1, 2000), 256, 64)
     y = O.istft(X, 64, 2600)
     assert y.shape == (2600,) and np.all(y[X.shape[0] * 64 + 128:] == 0)
+
+
+def test_torch_cpu_restatement_matches_reference_golden(golden_dir):
+    """oracle/torch_cpu.py (the timed cpu_baseline 'port') against the
+    reference's own outputs."""
+    from oracle import torch_cpu as TC
+    z, sd = load_case(f"{golden_dir}/g1_deep_clustering_H32_L2.npz")
+    np.testing.assert_allclose(TC.deep_clustering_forward(sd, z["x"]).numpy(), z["out_embedding"], atol=1e-6)
+    z, sd = load_case(f"{golden_dir}/g1_chimera_H32_L2.npz")
+    e, a, b = TC.chimera_forward(sd, z["x"])
+    np.testing.assert_allclose(e.numpy(), z["out_embedding"], atol=1e-6)
+    np.testing.assert_allclose(b.numpy(), z["out_mask_B"], atol=1e-6)
+    z, sd = load_case(f"{golden_dir}/g1_phase_net_H16_L2.npz")
+    outs = TC.phase_net_forward(sd, z["x"], z["x_phase"])
+    np.testing.assert_allclose(outs[3].numpy(), z["out_phase_A"], atol=1e-6)
+    np.testing.assert_allclose(outs[4].numpy(), z["out_phase_B"], atol=1e-6)
