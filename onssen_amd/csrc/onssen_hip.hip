@@ -18,6 +18,9 @@
 
 typedef float f32x4 __attribute__((vector_size(16)));
 
+// hipGetLastError() is sticky per thread: other libraries' failed probes (e.g. a device query before
+// the runtime is initialised) linger.  Every ABI entry clears it first, then checks its own launches.
+#define ONSSEN_CLEAR_ERROR() ((void)hipGetLastError())
 #define ONSSEN_LAUNCH_CHECK()                   \
   do {                                          \
     hipError_t e__ = hipGetLastError();         \
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 template <int MT, int NT>
 static int launch_steps(StepArgs sp, int T, hipStream_t st) {
   const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
+  ONSSEN_CLEAR_ERROR();
   for (int s = 0; s < T; ++s) {
     sp.step = s;
     hipLaunchKernelGGL((lstm_step_kernel<MT, NT>), grid, block, 0, st, sp);
@@ -624,6 +628,7 @@ const char* onssen_error_string(int code) {
 int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop, float eps,
                            float* logmag, float* stft_ri, void* stream) {
   if (!wav || !logmag || B <= 0 || hop <= 0 || n_samples <= n_fft / 2) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
   const long frames = (long)B * T;
   const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
@@ -662,6 +667,7 @@ int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih
   if (bidir_in && in_dim != 2 * H) return ONSSEN_E_ARG;
   const int Kp = bidir_in ? 2 * Hp : ceil_div(in_dim, 4) * 4;
   hipStream_t st = (hipStream_t)stream;
+  ONSSEN_CLEAR_ERROR();
   const long n1 = (long)NP * Kp;
   hipLaunchKernelGGL(pack_wih_kernel, dim3((unsigned)((n1 + 255) / 256 > 4096 ? 4096 : (n1 + 255) / 256)), dim3(256),
                      0, st, w_ih, b_ih, b_hh, in_dim, bidir_in, H, Hp, ug, Kp, wih_p, bias_p);
@@ -677,6 +683,7 @@ int onssen_head_pack_f32(const float* w, const float* b, int N, int H, int Hp, c
                          float* b_p, void* stream) {
   if (!w || !b || !w_p || !b_p || N <= 0 || H <= 0 || Hp < H || (Hp % 4) != 0) return ONSSEN_E_ARG;
   if (bn_gamma && (!bn_beta || !bn_mean || !bn_var)) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
   hipLaunchKernelGGL(pack_head_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, w, b, N, H, Hp,
                      bn_gamma, bn_beta, bn_mean, bn_var, bn_eps, w_p, b_p);
   ONSSEN_LAUNCH_CHECK();
@@ -693,6 +700,7 @@ int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, 
   } else if (resid) {
     return ONSSEN_E_ARG;
   }
+  ONSSEN_CLEAR_ERROR();
   LinearArgs p;
   p.A = A; p.a_s0 = (long)a_s0; p.a_s1 = (long)a_s1; p.W = W; p.bias = bias; p.resid = resid; p.C = C;
   p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N; p.K = K; p.ldw = ldw; p.group = group;
@@ -794,6 +802,7 @@ int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, 
   if (!x_mag || !mask || !x_phase || !out || B <= 0 || C <= 0 || T <= 0 || F <= 0) return ONSSEN_E_ARG;
   const long total = (long)C * B * T * 3 * F;
   const long nb = (total + 255) / 256;
+  ONSSEN_CLEAR_ERROR();
   hipLaunchKernelGGL(phase_input_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream,
                      x_mag, mask, (long)m_sb, (long)m_sc, (long)m_st, (long)m_sf, x_phase, B, C, T, F, out);
   ONSSEN_LAUNCH_CHECK();
@@ -811,6 +820,7 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
   const bool hop_aligned = (n_fft % hop) == 0 && ((n_fft / 2) % hop) == 0;
   const int FR = FB - halo - (hop_aligned ? 0 : 1);
   if (FR <= 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
   const dim3 grid((unsigned)ceil_div(length, FR * hop), (unsigned)C, (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)

@@ -12,6 +12,10 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libonssen_h
 def get_lib():
     global _LIB
     if _LIB is None:
+        # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Load torch first so
+        # that this process has ONE HIP runtime and our kernels launch on the streams torch hands us;
+        # dlopen-ing our library first would pull in a second runtime ("no ROCm-capable device").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise OnssenError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "

@@ -31,12 +31,19 @@ class chimera(nn.Module):
         batch_size, frame, frequency = x.size()
         if not use_hip_path(self):
             return self._autograd_forward(x)
+        emb, masks = self.embedding_and_masks(x)
+        return [emb, masks[:, :, :, 0], masks[:, :, :, 1]]
+
+    def embedding_and_masks(self, x):
+        """HIP inference path: x (B,T,F) -> (embedding (B,T,F,D), masks (B,T,F,C)); ``forward``
+        returns the per-speaker slices of ``masks`` like upstream (chimera.py:43-45)."""
+        x = x.float()
+        batch_size, frame, frequency = x.size()
         require_device(x, "chimera")
         y = run_blstm(self._packed, self._ws, x)
         emb = run_head(self._head_dc, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
         masks = run_head(self._head_mi, y, batch_size, frame, EPI_SIGMOID)
-        masks = masks.view(batch_size, frame, frequency, -1)
-        return [emb.view(batch_size, frame, frequency, -1), masks[:, :, :, 0], masks[:, :, :, 1]]
+        return emb.view(batch_size, frame, frequency, -1), masks.view(batch_size, frame, frequency, -1)
 
     def _autograd_forward(self, x):
         B, T, Fq = x.shape

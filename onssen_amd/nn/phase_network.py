@@ -39,10 +39,9 @@ class phase_net(nn.Module):
             return self._autograd_forward(x_mag.float(), x_phase.float())
         x_mag, x_phase = x_mag.float().contiguous(), x_phase.float().contiguous()
         require_device(x_mag, "phase_net")
-        [embedding, mask_A, mask_B] = self.chimera([x_mag])
-        B, T, Fq = mask_A.size()
-        masks = mask_A._base if mask_A._base is not None else torch.stack([mask_A, mask_B], -1)
-        C = masks.shape[-1]
+        embedding, masks = self.chimera.embedding_and_masks(x_mag)
+        mask_A, mask_B = masks[:, :, :, 0], masks[:, :, :, 1]
+        B, T, Fq, C = masks.size()
         # cat(x_mag*mask_s, x_phase.view(B,T,2F)) for both speakers, stacked on the batch axis:
         # the phase BLSTM shares its weights between A and B, so it runs once with batch 2B
         inp = torch.empty(C * B, T, 3 * Fq, device=x_mag.device, dtype=torch.float32)

@@ -13,8 +13,7 @@ from .features import mask_istft, stft_logmag
 def separate_chimera(model, wav, window_size=256, hop_size=64):
     """wav (B, n) cuda float32 -> (B, 2, n): masks straight from the network."""
     logmag, ri = stft_logmag(wav, window_size, hop_size)
-    _, mask_A, mask_B = model([logmag])
-    masks = mask_A._base if mask_A._base is not None else torch.stack([mask_A, mask_B], -1)
+    _, masks = model.embedding_and_masks(logmag)
     return mask_istft(ri, masks, hop_size, wav.shape[-1])
 
 

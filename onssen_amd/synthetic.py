@@ -87,7 +87,7 @@ def _speaker(rng, n, sr):
             sig += np.sin(k * ph + rng.uniform(0, 2 * np.pi)) / k
     env = 0.5 * (1 + np.sin(2 * np.pi * rng.uniform(3, 5) * t + rng.uniform(0, 2 * np.pi)))
     gate = np.repeat((rng.random(n // 800 + 1) > 0.2).astype(float), 800)[:n]
-    gate = np.convolve(gate, np.ones(160) / 160, mode="same")
+    gate = np.convolve(gate, np.ones(160) / 160, mode="same")[:n]   # 'same' returns max(len) samples
     return sig * env * gate
 
 

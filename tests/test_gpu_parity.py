@@ -199,7 +199,10 @@ def test_cpu_tensor_fails_loudly(dev):
 @pytest.mark.parametrize("n_fft,hop,n,B", [(256, 64, 25536, 4), (512, 128, 16000, 3), (256, 64, 129, 1), (1024, 256, 9000, 2)])
 def test_stft_logmag(dev, n_fft, hop, n, B):
     from onssen_amd.features import stft_logmag
-    wav = np.stack([synth_mixture(30 + b, n) for b in range(B)])
+    if n < 1000:   # shortest legal signal (reflect padding needs n > n_fft/2)
+        wav = np.random.default_rng(n).uniform(-0.5, 0.5, (B, n)).astype(np.float32)
+    else:
+        wav = np.stack([synth_mixture(30 + b, n) for b in range(B)])
     lm, ri = stft_logmag(torch.from_numpy(wav).to(dev), n_fft, hop)
     lm, ri = lm.cpu().numpy(), ri.cpu().numpy()
     for b in range(B):
@@ -231,9 +234,10 @@ def test_mask_istft_and_roundtrip(dev, n_fft, hop, n, length):
         ref = O.mask_istft(X, np.stack([m0[b], 1 - m0[b]]), hop, length)
         np.testing.assert_allclose(out[b], ref, atol=2e-6)
     # size-independent properties: masks summing to one split the mixture; stft->istft is the identity
+    # (over the signal's own support: the last reflected half-window divides by a vanishing window sum)
     y = mask_istft(ri, None, hop, length).cpu().numpy()[:, 0]
-    np.testing.assert_allclose(out.sum(1), y, atol=2e-6)
     k = min(n, length)
+    np.testing.assert_allclose(out.sum(1)[:, :k], y[:, :k], atol=2e-6)
     np.testing.assert_allclose(y[:, :k], wav[:, :k], atol=2e-6)
 
 
