@@ -177,33 +177,59 @@ def main():
 
 
 def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
-    """Roofline block for the dominant kernel.  Both candidates are bound by the exact-fp32 MFMA
-    rate (157.3 TFLOP/s).  The recurrence (lstm_step_kernel, T launches per layer) is timed as the
-    event-bracketed span of a layer's T dependent launches divided by T, so the figure includes the
-    dependent-launch gap that the serial chain really pays (rocprof's per-kernel duration excludes
-    it; see DESIGN.md section 'Measurement')."""
+    """Roofline block for the dominant kernel, timed live with HIP events on the launch stream
+    (each call captured in its own hipGraph and replayed, so host launch cost is excluded).
+
+    The recurrence and the GEMMs are both bound by the exact-fp32 MFMA rate (157.3 TFLOP/s dense).
+    Persistent form: lstm_persistent_kernel is ONE launch per layer whose duration is the event span
+    of a single-layer call minus its input-projection GEMM.  Launch-per-step form: the span of the T
+    dependent launches / T (includes the dependent-launch gap the serial chain really pays)."""
     from onssen_amd.features import stft_logmag
     from onssen_amd.hip import get_lib
-    from onssen_amd.nn._core import _stream
+    from onssen_amd.nn._core import _stream, recurrence_plan
     lib = get_lib()
     T = T_FRAMES
-    logmag, _ = stft_logmag(wav, NFFT, HOP)
-    pk = model._packed.get()
-    ug, Hp, NP = pk.ug, pk.Hp, pk.NP
+    ug, flags = recurrence_plan(B, H)
+    pk = model._packed.get(ug)
+    Hp, NP = pk.Hp, pk.NP
     y = torch.empty(T, B, 2, Hp, device=dev)
-    nbytes = lib.blstm_workspace_bytes(B, T, H, 1, ug)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    # one layer (layer 1 shapes: in = 2H) as its own call: GEMM + T steps
+    ws = torch.empty(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
     xin = torch.randn(B, T, F, device=dev)
+    yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     st = _stream   # evaluated at call time: under graph capture the current stream is the capture stream
+    lyr = 1 if L > 1 else 0          # time a layer with the steady-state shape (in = 2H) when there is one
 
-    def layer0():
-        lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [pk.wih[0].data_ptr()],
-                          [pk.whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(), st())
+    def layer():
+        if lyr == 0:
+            lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [pk.wih[0].data_ptr()],
+                              [pk.whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(),
+                              ws.numel(), flags, st())
+        else:   # feed y-shaped input through layer 1's weights: x (B,T,2Hp) strides of the time-major buffer
+            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih[1].data_ptr()],
+                              [pk.whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
+                              ws.numel(), flags, st())
+
+    gbuf = ws[512:]
+
+    def gemm_in():
+        if lyr == 0:
+            lib.linear(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, pk.wih[0].data_ptr(), (F + 3) // 4 * 4,
+                       pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
+        else:
+            lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,
+                       pk.bias[1].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
 
     def gemm0():
         lib.linear(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, pk.wih[0].data_ptr(), (F + 3) // 4 * 4,
-                   pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, ws.data_ptr(), B * 2 * NP, 2 * NP, st())
+                   pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
+
+    hd = model._head_dc if kind == "chimera" else model._head
+    hp = hd.get(Hp)
+    out = torch.empty(B, T, hp.N, device=dev)
+
+    def head():
+        lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hp.w.data_ptr(), 2 * Hp, hp.b.data_ptr(), hp.N,
+                   1, D, 1e-12, None, out.data_ptr(), hp.N, T * hp.N, st())
 
     def timed(fn, reps=5):
         fn()
@@ -226,52 +252,31 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e-3
 
-    t_layer = timed(layer0)
-    t_gemm0 = timed(gemm0)
-    t_step = (t_layer - t_gemm0) / T
-    flop_step = 2.0 * 2 * B * 4 * H * H                      # both directions, 2 FLOP/MAC
-    # big GEMM (layer>=1 input projection): M = B*T, N = 8H, K = 2H
-    yin = torch.randn(T, B, 2 * Hp, device=dev)
-    if L > 1:
-        def gemm1():
-            lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,
-                       pk.bias[1].data_ptr(), 2 * NP, 0, 0, 0.0, None, ws.data_ptr(), B * 2 * NP, 2 * NP, st())
-        t_gemm1 = timed(gemm1)
-    else:
-        t_gemm1 = 0.0
-    flop_gemm1 = 2.0 * B * T * 8 * H * 2 * H
-    hd = model._head_dc if kind == "chimera" else model._head
-    hp = hd.get(Hp)
-    out = torch.empty(B, T, hp.N, device=dev)
-
-    def head():
-        lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hp.w.data_ptr(), 2 * Hp, hp.b.data_ptr(), hp.N,
-                   1, D, 1e-12, None, out.data_ptr(), hp.N, T * hp.N, st())
-    t_head = timed(head)
+    t_layer, t_gin, t_g0, t_head = timed(layer), timed(gemm_in), timed(gemm0), timed(head)
+    t_rec = t_layer - t_gin                                    # recurrence of one layer (both directions)
+    flop_rec = 2.0 * 2 * B * 4 * H * H * T                     # h W_hh^T, both directions, 2 FLOP/MAC
+    flop_gin = 2.0 * B * T * 8 * H * (2 * H if lyr else F)
     flop_head = 2.0 * B * T * hp.N * 2 * H
-    tot_rec = t_step * T * L
-    tot_gemm = t_gemm0 + (L - 1) * t_gemm1 + t_head
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf)).get("lstm_step_kernel_bytes_per_launch")
-    rec = {"kernel": "lstm_step_kernel", "bound": "mfma", "achieved": flop_step / t_step / 1e12,
-           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop_step / t_step / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-           "traffic": traffic, "us_per_launch": t_step * 1e6, "launches_per_step": T * L,
-           "algorithmic_flop_per_launch": flop_step, "share_of_step_ms": tot_rec * 1e3,
-           "note": "duration = event-bracketed span of a layer's dependent launches / T (includes the launch gap)"}
-    gem = {"kernel": "linear_kernel", "bound": "mfma",
-           "achieved_by_call": {"wih_l0": 2.0 * B * T * 8 * H * F / t_gemm0 / 1e12,
-                                "wih_l1": (flop_gemm1 / t_gemm1 / 1e12) if L > 1 else None,
+        traffic = json.load(open(tf)).get("recurrence_hbm_bytes_per_launch")
+    persistent = bool(flags)
+    launches = 1 if persistent else T
+    rec = {"kernel": "lstm_persistent_kernel" if persistent else "lstm_step_kernel", "bound": "mfma",
+           "achieved": flop_rec / t_rec / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flop_rec / t_rec / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+           "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
+           "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
+           "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
+    gem = {"kernel": "linear_kernel", "bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "achieved_by_call": {"input_proj_l0": 2.0 * B * T * 8 * H * F / t_g0 / 1e12,
+                                "input_proj_l1": (flop_gin / t_gin / 1e12) if lyr else None,
                                 "fc_dc_l2norm": flop_head / t_head / 1e12},
-           "ms_by_call": {"wih_l0": t_gemm0 * 1e3, "wih_l1": t_gemm1 * 1e3, "fc_dc_l2norm": t_head * 1e3},
-           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "share_of_step_ms": tot_gemm * 1e3}
+           "ms_by_call": {"input_proj_l0": t_g0 * 1e3, "input_proj_l1": t_gin * 1e3 if lyr else None,
+                          "fc_dc_l2norm": t_head * 1e3},
+           "share_of_step_ms": (t_g0 + (L - 1) * t_gin * (1 if lyr else 0) + t_head) * 1e3}
     rec["other_kernels"] = gem
-    if tot_gemm > tot_rec and L > 1:   # report whichever kernel owns more of the step
-        a = flop_gemm1 / t_gemm1 / 1e12
-        rec = {"kernel": "linear_kernel (layer-1 input projection)", "bound": "mfma", "achieved": a,
-               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-               "other_kernels": {"lstm_step_kernel": rec, "linear_kernel": gem}}
     return rec
 
 

@@ -19,9 +19,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def default_unit_group():
-    """Hidden units per recurrence workgroup (ABI parameter `ug`)."""
-    return int(os.environ.get("ONSSEN_UG", "8"))
+def recurrence_plan(B, H):
+    """(ug, flags) for onssen_blstm_forward_f32.
+
+    Persistent form (one launch per layer, W_hh register-resident) whenever the shape allows it:
+    pick the unit-group size ug = 4*NT that minimises the per-workgroup MFMA tile count MT*NT while
+    one launch (2 directions x batch groups x H/ug workgroups) stays within the chip's 256 CUs.
+    ONSSEN_UG / ONSSEN_PERSISTENT override (used by the A/B benches and the tests)."""
+    env_ug, env_p = os.environ.get("ONSSEN_UG"), os.environ.get("ONSSEN_PERSISTENT")
+    persistent = (env_p != "0") and H <= 640
+    if env_ug:
+        ug = int(env_ug)
+        return ug, (_abi.BLSTM_PERSISTENT if persistent and ug <= 16 else 0)
+    if not persistent:
+        return 8, 0
+    best = None
+    for mt in (1, 2):
+        for nt in (1, 2, 3, 4):
+            if mt == 2 and nt == 4:
+                continue
+            ug = 4 * nt
+            nu = -(-H // ug)
+            nbg = -(-B // (16 * mt))
+            if 2 * nu > 256:
+                continue
+            launches = -(-nbg // max(1, 256 // (2 * nu)))
+            waste = (nu * ug) / H
+            cost = (launches * mt * nt * waste, -2 * nu * min(nbg, 256 // (2 * nu)))
+            if best is None or cost < best[0]:
+                best = (cost, ug)
+    return best[1], _abi.BLSTM_PERSISTENT
 
 
 class BLSTMParams(nn.Module):
@@ -73,7 +100,19 @@ class PackedBLSTM:
     """Device images of a BLSTMParams for the HIP kernels, rebuilt when any
     parameter changes (in-place optimizer steps bump ``_version``)."""
 
-    def __init__(self, params: BLSTMParams, ug):
+    def __init__(self, params: BLSTMParams):
+        self.p = params
+        self.cache = {}     # ug -> packed images (a batch-size class can prefer another unit-group size)
+
+    def get(self, ug):
+        img = self.cache.get(ug)
+        if img is None:
+            img = self.cache[ug] = _PackedImages(self.p, ug)
+        return img.get()
+
+
+class _PackedImages:
+    def __init__(self, params, ug):
         self.p, self.ug = params, ug
         self.key = None
 
@@ -155,9 +194,11 @@ def require_device(x, who):
 
 def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     """x (B,T,In) float32 cuda -> y (T,B,2,Hp) time-major (padded units are 0)."""
-    lib, pk = get_lib(), packed.get()
-    p = pk.p
+    lib = get_lib()
+    p = packed.p
     B, T, In = x.shape
+    ug, flags = recurrence_plan(B, p.hidden_size)
+    pk = packed.get(ug)
     if In != p.input_size:
         raise RuntimeError(f"input feature size {In} != {p.input_size}")
     if x.stride(2) != 1:
@@ -167,7 +208,12 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in pk.wih], [t.data_ptr() for t in pk.whh],
-                      [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), _stream())
+                      [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
+    if flags and os.environ.get("ONSSEN_CHECK") == "1":   # debug: synchronise and verify no exchange timed out
+        torch.cuda.synchronize()
+        head = wsb[:512].cpu().numpy()
+        if lib.blstm_status(head.ctypes.data) != 0:
+            raise _abi.OnssenError("persistent recurrence aborted (exchange timeout); outputs are invalid")
     return y
 
 

@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
-                    default_unit_group, require_device, run_blstm, run_head, use_hip_path)
+                    require_device, run_blstm, run_head, use_hip_path)
 
 
 class chimera(nn.Module):
@@ -20,7 +20,7 @@ class chimera(nn.Module):
         self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))
         self.add_module("fc_dc", nn.Linear(hidden_dim * 2, input_dim * embedding_dim))
         self.add_module("fc_mi", nn.Linear(hidden_dim * 2, input_dim * num_speaker))
-        self._packed = PackedBLSTM(self.rnn, default_unit_group())
+        self._packed = PackedBLSTM(self.rnn)
         self._head_dc = PackedHead(self.fc_dc, None, hidden_dim)
         self._head_mi = PackedHead(self.fc_mi, None, hidden_dim)
         self._ws = _Workspaces()

@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, default_unit_group,
+from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     require_device, run_blstm, run_head, use_hip_path)
 
 
@@ -23,7 +23,7 @@ class deep_clustering(nn.Module):
         self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))
         self.add_module("bn", nn.BatchNorm1d(hidden_dim * 2))
         self.add_module("fc_dc", nn.Linear(hidden_dim * 2, embedding_dim * input_dim))
-        self._packed = PackedBLSTM(self.rnn, default_unit_group())
+        self._packed = PackedBLSTM(self.rnn)
         self._head = PackedHead(self.fc_dc, self.bn, hidden_dim)
         self._ws = _Workspaces()
 

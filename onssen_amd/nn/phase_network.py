@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import get_lib
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream, default_unit_group,
+from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
                     require_device, run_blstm, run_head, use_hip_path)
 from .chimera import chimera
 
@@ -28,7 +28,7 @@ class phase_net(nn.Module):
         self.add_module("bn", nn.BatchNorm1d(hidden_dim * 2))
         self.add_module("fc_phase", nn.Linear(hidden_dim * 2, num_speaker * input_dim))
         self.add_module("chimera", chimera_net)
-        self._packed = PackedBLSTM(self.rnn, default_unit_group())
+        self._packed = PackedBLSTM(self.rnn)
         self._head = PackedHead(self.fc_phase, self.bn, hidden_dim)
         self._ws = _Workspaces()
 

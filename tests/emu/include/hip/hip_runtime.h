@@ -12,6 +12,9 @@
 // tests/test_emu_*.py are tiny.  Never shipped, never timed.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -74,11 +77,11 @@ void launch(dim3 grid, dim3 block, F body);
 
 inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+// Runs the workgroups [b_lo, b_hi) of the grid one after another, each as `nthr` OS threads.
 template <class F>
-void emu::launch(dim3 grid, dim3 block, F body) {
+static void emu_run_blocks(dim3 grid, dim3 block, F& body, unsigned b_lo, unsigned b_hi) {
   const int nthr = int(block.x * block.y * block.z);
-  if (nthr % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
-  BlockCtx c(nthr);
+  emu::BlockCtx c(nthr);
   std::vector<std::thread> th;
   th.reserve(nthr);
   for (int tid = 0; tid < nthr; ++tid) {
@@ -89,16 +92,44 @@ void emu::launch(dim3 grid, dim3 block, F body) {
       threadIdx = dim3(tid % block.x, (tid / block.x) % block.y, tid / (block.x * block.y));
       blockDim = block;
       gridDim = grid;
-      for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-          for (unsigned bx = 0; bx < grid.x; ++bx) {
-            blockIdx = dim3(bx, by, bz);
-            body();
-            pthread_barrier_wait(&c.block_bar);
-          }
+      for (unsigned b = b_lo; b < b_hi; ++b) {
+        blockIdx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
+        body();
+        pthread_barrier_wait(&c.block_bar);
+      }
     });
   }
   for (auto& t : th) t.join();
+}
+
+// Default: workgroups run one after another in this process (any host memory works).
+// ONSSEN_EMU_FORK=1: every workgroup runs CONCURRENTLY in its own forked process (its own copy of the
+// `__shared__` statics); kernels whose workgroups talk to each other inside a launch need this, and the
+// test must then keep all "device" buffers in MAP_SHARED memory.
+template <class F>
+void emu::launch(dim3 grid, dim3 block, F body) {
+  const int nthr = int(block.x * block.y * block.z);
+  if (nthr % 64 != 0) { fprintf(stderr, "emu: block size must be a multiple of 64\n"); abort(); }
+  const unsigned nblk = grid.x * grid.y * grid.z;
+  const char* fk = getenv("ONSSEN_EMU_FORK");
+  if (!(fk && fk[0] == '1') || nblk == 1) {
+    emu_run_blocks(grid, block, body, 0, nblk);
+    return;
+  }
+  std::vector<pid_t> kids;
+  for (unsigned b = 0; b < nblk; ++b) {
+    pid_t pid = fork();
+    if (pid == 0) {
+      emu_run_blocks(grid, block, body, b, b + 1);
+      _exit(0);
+    }
+    kids.push_back(pid);
+  }
+  for (pid_t k : kids) {
+    int st = 0;
+    waitpid(k, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "emu: workgroup process failed\n"); abort(); }
+  }
 }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
@@ -144,4 +175,31 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
   }
   emu::wave_sync();
   return c;
+}
+
+// ---- agent-scope atomics, waits, buffer resources (persistent-kernel hand-offs) -----------------
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+template <class T>
+static inline void emu_atomic_store(T* p, T v) {
+  static_assert(sizeof(T) == 4, "4-byte stores only");
+  uint32_t u; memcpy(&u, &v, 4);
+  __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_SEQ_CST);
+}
+#define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
+static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
+static inline void __builtin_amdgcn_s_waitcnt(int) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+struct __amdgpu_buffer_rsrc_t { char* base; int bytes; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
+  return {static_cast<char*>(p), bytes};
+}
+typedef unsigned int emu_u32x4 __attribute__((vector_size(16)));
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  emu_u32x4 v = {0, 0, 0, 0};
+  if ((long)voff + (long)soff + 16 <= (long)r.bytes) {   // out-of-range buffer loads return 0, like the hardware
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    memcpy(&v, r.base + voff + soff, 16);
+  }
+  return v;
 }
