@@ -261,9 +261,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         traffic = json.load(open(tf)).get("recurrence_hbm_bytes_per_launch")
-    persistent = bool(flags)
-    launches = 1 if persistent else T
-    rec = {"kernel": "lstm_persistent_kernel" if persistent else "lstm_step_kernel", "bound": "mfma",
+    launches = T
+    rec = {"kernel": "lstm_step_kernel", "bound": "mfma",
            "achieved": flop_rec / t_rec / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": flop_rec / t_rec / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,

@@ -35,10 +35,9 @@ extern "C" {
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
 #define ONSSEN_E_WORKSPACE (-2)   /* workspace too small */
 #define ONSSEN_E_ALIGN (-3)       /* pointer / stride alignment requirement violated */
-#define ONSSEN_E_TIMEOUT (-4)     /* a bounded device-side wait gave up (persistent recurrence) */
 
-/* flags of onssen_blstm_forward_f32 */
-#define ONSSEN_BLSTM_PERSISTENT 1 /* one launch per layer, W_hh register-resident, in-launch h exchange */
+/* flags of onssen_blstm_forward_f32: 0 in production.  Bits 8..11 switch off parts of the recurrence kernel
+ * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA. */
 
 /* epilogue modes of onssen_linear_f32 */
 #define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
@@ -110,15 +109,11 @@ int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, 
  *             directions back to back: wih [2*NP][Kp_l], whh [2][whh_elems], bias [2*NP]
  *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0
  *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned
- * flags = 0: one input-projection GEMM + T recurrence launches per layer (capture the call in a hipGraph
- *   to amortise launch cost).
- * flags = ONSSEN_BLSTM_PERSISTENT: one GEMM + one persistent recurrence launch per (layer, batch chunk);
- *   needs H <= 640, ug <= 16.  Workgroups exchange h_t inside the launch with bounded waits: if a wait
- *   gives up, the launch aborts and the first 512 bytes of `ws` record it -- copy them to the host after
- *   synchronising and pass them to onssen_blstm_status() (0 = ok, ONSSEN_E_TIMEOUT = outputs invalid).
+ * One input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph to
+ * amortise launch cost.  (A one-launch-per-layer persistent form with in-launch h exchange was built
+ * and measured slower than kernel boundaries on this chip -- DESIGN.md, "Recurrence: what was tried".)
  */
 size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug);
-int onssen_blstm_status(const void* ws_host_copy_of_first_512_bytes);
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,

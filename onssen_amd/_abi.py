@@ -9,8 +9,6 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
 ABI_VERSION = 2
-BLSTM_PERSISTENT = 1
-E_TIMEOUT = -4
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -25,7 +23,6 @@ SIGNATURES = {
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "onssen_blstm_status": (_i, [_vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -86,8 +83,6 @@ class Lib:
                                                      arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, flags, stream),
                    "onssen_blstm_forward_f32")
 
-    def blstm_status(self, first_512_bytes_host_ptr):
-        return int(self.dll.onssen_blstm_status(first_512_bytes_host_ptr))
 
     def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
         self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,

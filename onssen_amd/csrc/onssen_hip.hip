@@ -316,6 +316,7 @@ struct StepArgs {
   float* y;          // [T][B][2][Hp]   layer output (h_t)
   float* c;          // [2][B][Hp]      cell state
   int B, T, Hp, NP, KQ, NU, step;
+  int ablate;  // profiling only (flags >> 8): 1 = no h loads, 2 = no W loads, 4 = no MFMA, 8 = no epilogue math
 };
 
 namespace rec {
@@ -368,18 +369,18 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int b = b0 + mt * 16 + fi;
-          a[i][mt] = (qok && b < p.B && k < p.Hp)
+          a[i][mt] = (qok && b < p.B && k < p.Hp && !(p.ablate & 1))
                          ? *reinterpret_cast<const float4*>(p.y + ((long)(tprev * p.B + b) * 2 + dir) * p.Hp + k)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          w[i][nt] = qok ? *reinterpret_cast<const float4*>(wbase + ((long)q * NT + nt) * 256)
+          w[i][nt] = (qok && !(p.ablate & 2)) ? *reinterpret_cast<const float4*>(wbase + ((long)q * NT + nt) * 256)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < QB; ++i) {
-        if (qb + 4 * i < p.KQ) {  // wave-uniform: skip chunks past the end of K
+        if (qb + 4 * i < p.KQ && !(p.ablate & 4)) {  // wave-uniform: skip chunks past the end of K
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -431,181 +432,6 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
   }
 }
 
-
-// -------------------------------------------------------------------------------------------------
-// K4, persistent form: ONE launch runs all T steps of a layer.  The recurrent weights never leave
-// the register file (each wave keeps its K-slice of W_hh as MFMA B fragments for the whole sequence),
-// the cell state lives in registers, and the only per-step traffic is h_t itself.
-//
-// Workgroups that share (direction, 16*MT-row batch group) form an independent exchange group of NU
-// members.  h_t is published with write-through (sc1) stores into y[t] -- every y[t] is written
-// exactly once per launch, so there is no slot reuse and no consumer->producer acknowledgement --
-// followed by a drained arrival on the group's monotonic counter; consumers poll that one word
-// (relaxed, agent scope), then read y[t] with sc1 loads (cdna_hip_programming.md G16, recipe R1).
-// Every spin is bounded: on timeout the workgroup raises the launch's abort word and all
-// workgroups leave, so a lost peer costs milliseconds, not a hung GPU.
-// -------------------------------------------------------------------------------------------------
-struct PersistArgs {
-  const float* G;      // [T][B][2][NP]
-  const float* whh;    // [2][NU][KQ][NT][64][4]
-  float* y;            // [T][B][2][Hp]
-  unsigned* sync;      // [0..63] group arrival counters, [64] abort word   (zeroed before the launch)
-  int B, T, Hp, NP, KQ, NU, row0, nbg;
-  unsigned spin_limit;
-};
-
-typedef unsigned int u32x4 __attribute__((vector_size(16)));
-
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void lstm_persistent_kernel(PersistArgs p) {
-  using namespace rec;
-  constexpr int UG = 4 * NT;
-  constexpr int NE = 16 * MT * UG;
-  constexpr int EPT = (NE + 255) / 256;
-  __shared__ float red[4 * MT * NT * 4 * RLD];
-  __shared__ unsigned s_abort;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ugi = blockIdx.x, dir = blockIdx.y, bg = blockIdx.z;
-  const int b0 = p.row0 + bg * 16 * MT;
-  const int fi = lane & 15, fg = lane >> 4;
-  unsigned* counter = p.sync + dir * p.nbg + bg;
-  unsigned* abort_w = p.sync + 64;
-
-  // ---- resident recurrent weights: chunks q = wave, wave+4, ... (KQ <= 4*QB checked by the launcher)
-  float4 w[QB][NT];
-  {
-    const float* wbase = p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256 + lane * 4;
-#pragma unroll
-    for (int i = 0; i < QB; ++i) {
-      const int q = wave + 4 * i;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        w[i][nt] = (q < p.KQ) ? *reinterpret_cast<const float4*>(wbase + ((long)q * NT + nt) * 256)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  float cst[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
-  if (tid == 0) s_abort = 0;
-  __syncthreads();
-
-  for (int step = 0; step < p.T; ++step) {
-    const int t = dir == 0 ? step : p.T - 1 - step;
-    const int tprev = dir == 0 ? t - 1 : t + 1;
-    // input projection of this step: independent of the exchange, so issue it before waiting
-    float gpre[EPT][4];
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / UG, ju = e % UG, b = b0 + row;
-      const bool ok = (e < NE) && (b < p.B);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        gpre[i][g] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + g * UG + ju] : 0.0f;
-    }
-
-    if (step > 0) {
-      // ---- wait until every member of this group has published h_{step-1}
-      if (tid == 0) {
-        const unsigned target = (unsigned)p.NU * (unsigned)step;
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || spins > p.spin_limit) {
-              __hip_atomic_store(abort_w, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              s_abort = 1;
-              break;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (s_abort) break;   // block-uniform: every thread reads the same LDS word after the barrier
-
-      // ---- h_{prev} fragments straight from y[tprev] with sc1 (L1-bypassing) 16-byte loads
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.y + (long)tprev * p.B * 2 * p.Hp), 0, p.B * 2 * p.Hp * 4, 0x00020000);
-      float4 a[QB][MT];
-#pragma unroll
-      for (int i = 0; i < QB; ++i) {
-        const int q = wave + 4 * i;
-        const int k = 16 * q + 4 * fg;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int b = b0 + mt * 16 + fi;
-          // unconditional load: an out-of-range offset makes the buffer unit return zeros, so rows past B
-          // and the K tail cost no branch (a branch per load would serialise the ten loads behind waits)
-          const bool ok = q < p.KQ && b < p.B && k < p.Hp;
-          const int off = ok ? ((b * 2 + dir) * p.Hp + k) * 4 : 0x7ffffff0;
-          const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
-          a[i][mt] = make_float4(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]),
-                                 __builtin_bit_cast(float, r[2]), __builtin_bit_cast(float, r[3]));
-        }
-      }
-      f32x4 acc[MT][NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < QB; ++i) {
-        if (wave + 4 * i < p.KQ) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[i][mt], r), f4c(w[i][nt], r), acc[mt][nt], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wave * MT * NT + mt * NT + nt) * 4 + r) * RLD + lane] = acc[mt][nt][r];
-      __syncthreads();
-    }
-
-    // ---- fused cell update; h_t goes out write-through so that other XCDs can see it
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / UG, ju = e % UG, b = b0 + row;
-      if (e < NE && b < p.B) {
-        float pre[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float sacc = 0.0f;
-          if (step > 0) {
-            const int pl = g * UG + ju;
-            const int tile = (row >> 4) * NT + (pl >> 4);
-            const int src = (((row & 15) >> 2) << 4) + (pl & 15), r = row & 3;
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv) sacc += red[((wv * MT * NT + tile) * 4 + r) * RLD + src];
-          }
-          pre[g] = sacc + gpre[i][g];
-        }
-        const float ig = 1.0f / (1.0f + expf(-pre[0]));
-        const float fg2 = 1.0f / (1.0f + expf(-pre[1]));
-        const float gg = tanhf(pre[2]);
-        const float og = 1.0f / (1.0f + expf(-pre[3]));
-        const float cn = fg2 * cst[i] + ig * gg;
-        cst[i] = cn;
-        __hip_atomic_store(p.y + ((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju, og * tanhf(cn),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    // R1 publish: every storing wave drains its write-through stores, then ONE lane arrives
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 // =================================================================================================
 // K1+K2 / K10: fp64 radix-2 FFT helpers (one wavefront per frame, data in LDS)
@@ -774,23 +600,6 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 
 
 template <int MT, int NT>
-static int launch_persistent(PersistArgs pa, int nbg_max, hipStream_t st) {
-  // batch chunks of 16*MT*nbg_max rows, one launch each (every launch must be fully co-resident)
-  const int rows_per_launch = 16 * MT * nbg_max;
-  for (int r0 = 0; r0 < pa.B; r0 += rows_per_launch) {
-    const int rows = pa.B - r0 < rows_per_launch ? pa.B - r0 : rows_per_launch;
-    pa.row0 = r0;
-    pa.nbg = ceil_div(rows, 16 * MT);
-    hipError_t e = hipMemsetAsync(pa.sync, 0, 65 * sizeof(unsigned), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((lstm_persistent_kernel<MT, NT>), dim3((unsigned)pa.NU, 2, (unsigned)pa.nbg), dim3(256), 0, st,
-                       pa);
-  }
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ONSSEN_OK : (int)e;
-}
-
-template <int MT, int NT>
 static int launch_steps(StepArgs sp, int T, hipStream_t st) {
   const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
   ONSSEN_CLEAR_ERROR();
@@ -815,7 +624,6 @@ const char* onssen_error_string(int code) {
     case ONSSEN_E_ARG: return "onssen: invalid argument or unsupported shape";
     case ONSSEN_E_WORKSPACE: return "onssen: workspace too small";
     case ONSSEN_E_ALIGN: return "onssen: pointer or stride alignment requirement violated";
-    case ONSSEN_E_TIMEOUT: return "onssen: a persistent-kernel exchange timed out (launch aborted, outputs invalid)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "onssen: unknown error";
   }
 }
@@ -926,12 +734,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
-  return 512 + g + (L > 1 ? y : 0) + c;   // leading 512 B: exchange counters + abort word of the persistent form
-}
-
-int onssen_blstm_status(const void* ws_host_copy_of_first_512_bytes) {
-  if (!ws_host_copy_of_first_512_bytes) return ONSSEN_E_ARG;
-  return ((const unsigned*)ws_host_copy_of_first_512_bytes)[64] == 0 ? ONSSEN_OK : ONSSEN_E_TIMEOUT;
+  return 512 + g + (L > 1 ? y : 0) + c;   // leading 512 B reserved
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -947,8 +750,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   if (!aligned16(ws) || !aligned16(y)) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
-  unsigned* syncw = (unsigned*)wsp;
-  wsp += 512;
+  wsp += 512;   // reserved header
   float* G = (float*)wsp;
   wsp += align256((size_t)T * B * 2 * NP * sizeof(float));
   float* ybuf = nullptr;
@@ -958,12 +760,6 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   }
   float* cst = (float*)wsp;
   const int mt = B > 16 ? 2 : 1;
-  // persistent form: W_hh register-resident (KQ <= 4*QB chunks, ug <= 16), every launch fully co-resident
-  const int NU = Hp / ug;
-  const bool persistent = (flags & ONSSEN_BLSTM_PERSISTENT) != 0;
-  if (persistent && (KQ > 4 * rec::QB || ug > 16 || 2 * NU > 256)) return ONSSEN_E_ARG;
-  const int nbg_cap = 256 / (2 * NU) < 32 ? 256 / (2 * NU) : 32;   // co-resident batch groups (counters: 2*32)
-  const int pmt = (ceil_div(B, 16) <= nbg_cap || ug > 12) ? 1 : 2;
   for (int l = 0; l < L; ++l) {
     // the last layer writes `y`; the layers before it alternate so that each reads what the previous wrote
     float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;
@@ -979,33 +775,9 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              2 * NP, stream);
     }
     if (rc != ONSSEN_OK) return rc;
-    if (persistent) {
-      PersistArgs pa;
-      pa.G = G; pa.whh = whh_p_host[l]; pa.y = yout; pa.sync = syncw; pa.B = B; pa.T = T; pa.Hp = Hp; pa.NP = NP;
-      pa.KQ = KQ; pa.NU = NU; pa.row0 = 0; pa.nbg = 0; pa.spin_limit = 200000u;
-      ONSSEN_CLEAR_ERROR();
-#define ONSSEN_PERSIST(MT_, NT_) rc = launch_persistent<MT_, NT_>(pa, nbg_cap, st)
-      if (pmt == 1) {
-        switch (ug) {
-          case 4: ONSSEN_PERSIST(1, 1); break;
-          case 8: ONSSEN_PERSIST(1, 2); break;
-          case 12: ONSSEN_PERSIST(1, 3); break;
-          default: ONSSEN_PERSIST(1, 4); break;
-        }
-      } else {
-        switch (ug) {
-          case 4: ONSSEN_PERSIST(2, 1); break;
-          case 8: ONSSEN_PERSIST(2, 2); break;
-          default: ONSSEN_PERSIST(2, 3); break;
-        }
-      }
-#undef ONSSEN_PERSIST
-      if (rc != ONSSEN_OK) return rc;
-      continue;
-    }
     StepArgs sp;
     sp.G = G; sp.whh = whh_p_host[l]; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
-    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0;
+    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 15;
 #define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, T, st)
     if (mt == 1) {
       switch (ug) {

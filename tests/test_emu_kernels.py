@@ -157,39 +157,3 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     a = np.frombuffer(mmap.mmap(-1, max(n, 16)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
     a[...] = fill
     return a
-
-
-@pytest.mark.parametrize("H,ug,B,T", [(24, 8, 3, 5), (12, 12, 17, 4), (20, 4, 2, 3), (30, 16, 20, 3)])
-def test_blstm_persistent_matches_oracle(lib, monkeypatch, H, ug, B, T):
-    """The one-launch-per-layer recurrence: workgroups exchange h_t inside the launch, so the mock
-    runtime runs every workgroup concurrently (forked) over shared memory."""
-    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
-    F, L = 9, 2
-    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
-    rng = np.random.default_rng(3)
-    x = _shm((B, T, F))
-    x[...] = rand(rng, B, T, F)
-    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
-    wih, whh, bias = [], [], []
-    for l in range(L):
-        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
-        a, b, c = _shm((2, NP, Kp)), _shm((2, we)), _shm((2, NP))
-        for d, sfx in enumerate(("", "_reverse")):
-            srcs = []
-            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
-                v = sd[f"rnn.{n}_l{l}{sfx}"]
-                sv = _shm(v.shape)
-                sv[...] = v
-                srcs.append(sv)
-            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
-                          P(a[d]), P(b[d]), P(c[d]), None)
-        wih.append(a), whh.append(b), bias.append(c)
-    ws = _shm((lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64,))
-    y = _shm((T, B, 2, Hp), fill=np.nan)
-    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh],
-                      [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_PERSISTENT, None)
-    assert lib.blstm_status(P(ws)) == 0
-    ref = O.blstm_stack(np.array(x), sd, "rnn.", L)
-    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
-    np.testing.assert_allclose(got, ref, atol=2e-6)
-    assert np.all(np.array(y)[:, :, :, H:] == 0)
