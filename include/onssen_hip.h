@@ -36,8 +36,11 @@ extern "C" {
 #define ONSSEN_E_WORKSPACE (-2)   /* workspace too small */
 #define ONSSEN_E_ALIGN (-3)       /* pointer / stride alignment requirement violated */
 
-/* flags of onssen_blstm_forward_f32: 0 in production.  Bits 8..11 switch off parts of the recurrence kernel
- * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA. */
+/* flags of onssen_blstm_forward_f32 */
+#define ONSSEN_BLSTM_SPLIT_ROWS 1 /* 16 batch rows per recurrence workgroup instead of 32: more workgroups */
+/* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
+ * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
+ * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
 
 /* epilogue modes of onssen_linear_f32 */
 #define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
@@ -139,6 +142,10 @@ int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, 
 int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
                           int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
                           void* stream);
+
+/* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
+ * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */
+int onssen_debug_launch_chain(float* scratch, int n, int workgroups, void* stream);
 
 #ifdef __cplusplus
 }

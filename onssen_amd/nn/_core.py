@@ -23,7 +23,10 @@ def recurrence_plan(B, H):
     """(ug, flags) for onssen_blstm_forward_f32: hidden units per recurrence workgroup.  ONSSEN_UG
     overrides (A/B benches, tests); ONSSEN_ABLATE sets the profiling-only ablation bits."""
     ug = int(os.environ.get("ONSSEN_UG", "8"))
-    return ug, int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
+    flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
+    if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
+        flags |= _abi.BLSTM_SPLIT_ROWS
+    return ug, flags
 
 
 class BLSTMParams(nn.Module):

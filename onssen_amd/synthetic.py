@@ -98,7 +98,7 @@ def synth_mixture(seed, n_samples=25536, sr=8000, return_sources=False):
     s1 = _speaker(rng, n_samples, sr)
     s2 = _speaker(rng, n_samples, sr)
     s2 *= 10 ** (rng.uniform(-2.5, 2.5) / 20) * (np.std(s1) + 1e-9) / (np.std(s2) + 1e-9)
-    noise = rng.normal(0, 1, n_samples) * 1e-2 * np.std(s1 + s2)
+    noise = rng.normal(0, 1, n_samples) * max(1e-2 * np.std(s1 + s2), 1e-4)   # never an all-zero mixture
     mix = s1 + s2 + noise
     scale = 0.9 / np.max(np.abs(mix))
     if return_sources:

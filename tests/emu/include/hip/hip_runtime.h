@@ -203,3 +203,5 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
   }
   return v;
 }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

@@ -49,11 +49,11 @@ for ug in (8, 12, 4, 20, 16):
                    pk.bias[1].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, _stream())
     tg = timed(gemm)
     row = []
-    for ab in (0, 1, 2, 3, 4, 7):
+    for ab in (0, 16, 3, 4, 7, 15, 0x10000):
         def layer():
             lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih[1].data_ptr()],
                               [pk.whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(),
-                              ab << 8, _stream())
+                              (ab << 8) if ab < 0x10000 else 1, _stream())
         row.append((timed(layer) - tg) / T * 1e6)
-    print(f"B={B} ug={ug:2d} WGs={2 * (Hp // ug) * ((B + 31) // 32 if B > 16 else 1)}: us/step full={row[0]:.2f} no_h={row[1]:.2f} "
-          f"no_W={row[2]:.2f} no_h_no_W={row[3]:.2f} no_mfma={row[4]:.2f} nothing={row[5]:.2f}  (gemm {tg * 1e3:.2f} ms)")
+    print(f"B={B} ug={ug:2d} WGs={2 * (Hp // ug) * ((B + 31) // 32 if B > 16 else 1)}: us/step full={row[0]:.2f} libm_act={row[1]:.2f} "
+          f"no_loads={row[2]:.2f} no_mfma={row[3]:.2f} no_loads_mfma={row[4]:.2f} +no_G={row[5]:.2f} split_rows={row[6]:.2f} (gemm {tg * 1e3:.2f} ms)")
