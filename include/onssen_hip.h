@@ -38,6 +38,9 @@ extern "C" {
 
 /* flags of onssen_blstm_forward_f32 */
 #define ONSSEN_BLSTM_SPLIT_ROWS 1 /* 16 batch rows per recurrence workgroup instead of 32: more workgroups */
+#define ONSSEN_BLSTM_BF16X3 2     /* recurrent product h W_hh^T in split-bf16 (3 bf16 MFMAs per fp32 product,
+                                     ~1e-5 relative); whh_p_host[l] must then point to the images made by
+                                     onssen_lstm_pack_whh_bf16x3 ([2 directions][whh_x3_elems] uint16).  H <= 640. */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
@@ -79,6 +82,11 @@ int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_
  */
 int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int in_dim,
                          int bidir_in, int H, int ug, float* wih_p, float* whh_p, float* bias_p, void* stream);
+
+/* Split-bf16 image of one direction's W_hh (see ONSSEN_BLSTM_BF16X3): hi = bf16(w), lo = bf16(w - hi), in
+ * v_mfma_f32_16x16x32_bf16 B-fragment order [NU][KQ2][ug/4][hi|lo][64][8], KQ2 = ceil(Hp/32). */
+int onssen_lstm_geometry_x3(int H, int ug, int* KQ2, int* Hs, int64_t* whh_x3_elems);
+int onssen_lstm_pack_whh_bf16x3(const float* w_hh, int H, int ug, uint16_t* whh_x3, void* stream);
 
 /* Pack a head nn.Linear(2H -> N) for the [fwd(Hp) | rev(Hp)] activation layout, optionally folding an
  * eval-mode nn.BatchNorm1d(2H) that precedes it (onssen/nn/deep_clustering.py:36-39):

@@ -10,6 +10,7 @@ import ctypes as C
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
 ABI_VERSION = 2
 BLSTM_SPLIT_ROWS = 1
+BLSTM_BF16X3 = 2
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -20,6 +21,8 @@ SIGNATURES = {
     "onssen_error_string": (C.c_char_p, [_i]),
     "onssen_stft_logmag_f32": (_i, [_vp, _i, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "onssen_lstm_geometry": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
+    "onssen_lstm_geometry_x3": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
+    "onssen_lstm_pack_whh_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
@@ -57,6 +60,14 @@ class Lib:
         hp, np_, kq, we = _i(), _i(), _i(), _i64()
         self.check(self.dll.onssen_lstm_geometry(H, ug, hp, np_, kq, we), "onssen_lstm_geometry")
         return hp.value, np_.value, kq.value, we.value
+
+    def lstm_geometry_x3(self, H, ug):
+        kq2, hs, we = _i(), _i(), _i64()
+        self.check(self.dll.onssen_lstm_geometry_x3(H, ug, kq2, hs, we), "onssen_lstm_geometry_x3")
+        return kq2.value, hs.value, we.value
+
+    def lstm_pack_whh_bf16x3(self, w_hh, H, ug, out, stream):
+        self.check(self.dll.onssen_lstm_pack_whh_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whh_bf16x3")
 
     def blstm_workspace_bytes(self, B, T, H, L, ug):
         return int(self.dll.onssen_blstm_workspace_bytes(B, T, H, L, ug))

@@ -10,6 +10,7 @@
 //   mask_istft_kernel    K10     mask-apply + fp64 inverse FFT + gather overlap-add (no atomics)
 //   pack_* kernels       one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold)
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 
 #include <math.h>
 #include <stdint.h>
@@ -17,6 +18,25 @@
 #include "../../include/onssen_hip.h"
 
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+typedef short s16x8 __attribute__((vector_size(16)));       // 8 bf16 bit patterns = one MFMA A/B fragment
+typedef __bf16 bf16x8_t __attribute__((vector_size(16)));
+
+// ---- split-bf16 ("bf16x3") arithmetic ---------------------------------------------------------------
+// An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|).  A product
+// a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA pipe (each bf16 x bf16 product
+// is exact in fp32; accumulation is fp32), dropping only a_lo*b_lo ~ 2^-16 |ab|.  That keeps dot products
+// at ~1e-5 relative -- inside the 1e-4 parity budget -- at 3/16 of the exact-fp32 MFMA time.
+__device__ __forceinline__ void split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+  const __hip_bfloat16 h = __float2bfloat16(x);
+  const __hip_bfloat16 l = __float2bfloat16(x - __bfloat162float(h));
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
+                                                 0, 0);
+}
 
 // hipGetLastError() is sticky per thread: other libraries' failed probes (e.g. a device query before
 // the runtime is initialised) linger.  Every ABI entry clears it first, then checks its own launches.
@@ -79,6 +99,32 @@ __global__ void pack_whh_kernel(const float* __restrict__ w_hh, int H, int Hp, i
     const int u = ugi * UG + ju;
     const int k = 16 * q + 4 * (lane >> 4) + r;
     whh_p[e] = (u < H && k < H) ? w_hh[(long)(gate * H + u) * H + k] : 0.0f;
+  }
+}
+
+// split-bf16 MFMA B-fragment image of W_hh for v_mfma_f32_16x16x32_bf16: [ugi][q][nt][hi|lo][lane][8] with
+//   column = nt*16 + (lane&15),  k = 32q + 8(lane>>4) + j
+__global__ void pack_whh_bf16x3_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ2,
+                                       unsigned short* __restrict__ out) {
+  const int NTl = UG / 4, NU = Hp / UG;
+  const long total = (long)NU * KQ2 * NTl * 512;   // (lane, j) pairs; each writes hi and lo
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long rest = e >> 9;
+    const int nt = (int)(rest % NTl);
+    rest /= NTl;
+    const int q = (int)(rest % KQ2);
+    const int ugi = (int)(rest / KQ2);
+    const int pl = nt * 16 + (lane & 15);
+    const int gate = pl / UG, ju = pl % UG;
+    const int u = ugi * UG + ju;
+    const int k = 32 * q + 8 * (lane >> 4) + j;
+    const float v = (u < H && k < H) ? w_hh[(long)(gate * H + u) * H + k] : 0.0f;
+    unsigned short hi, lo;
+    split_bf16(v, hi, lo);
+    const long base = (((long)(ugi * KQ2 + q) * NTl + nt) * 2) * 512 + lane * 8 + j;
+    out[base] = hi;
+    out[base + 512] = lo;
   }
 }
 
@@ -315,6 +361,9 @@ struct StepArgs {
   const float* whh;  // [2][NU][KQ][NT][64][4]
   float* y;          // [T][B][2][Hp]   layer output (h_t)
   float* c;          // [2][B][Hp]      cell state
+  const unsigned short* whh_x3;  // split-bf16 image [2][NU][KQ2][NT][2][64][8]          (X3 kernels)
+  unsigned short* hs;            // split h hand-off [2 slots][B][2 dirs][hi|lo][Hs] bf16   (X3 kernels)
+  int KQ2, Hs;                   // 32-wide k-chunks, padded row length Hs = 32*KQ2
   int B, T, Hp, NP, KQ, NU, step;
   int ablate;  // profiling only (flags >> 8): 1 = no h loads, 2 = no W loads, 4 = no MFMA, 8 = no G / c loads
 };
@@ -322,6 +371,7 @@ struct StepArgs {
 namespace rec {
 constexpr int RLD = 72;  // LDS row stride of the per-wave partial accumulators (64 lanes + pad)
 constexpr int QB = 10;   // k-chunks (16 k each) a wave keeps in flight: 4 waves x 10 x 16 = 640 >= H
+constexpr int QB3 = 5;   // same for the split-bf16 form (32 k per chunk)
 }
 
 // Gate non-linearities on the hardware transcendental units: sigmoid(x) = rcp(1 + exp2(-x log2 e)),
@@ -333,7 +383,7 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
 }
 __device__ __forceinline__ float gate_tanh(float x) { return 2.0f * gate_sigmoid(2.0f * x) - 1.0f; }
 
-template <int MT, int NT>
+template <int MT, int NT, bool X3>
 __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
   using namespace rec;
   constexpr int UG = 4 * NT;          // hidden units per workgroup
@@ -346,18 +396,22 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
   const int tprev = dir == 0 ? t - 1 : t + 1;
   const bool first = p.step == 0;
 
-  // ---- issue the epilogue's global reads first: they are independent of the recurrent product
+  // ---- the epilogue's global reads (input projection, cell state) are independent of the recurrent
+  // product: they are issued right after the operand fetches so that their latency hides behind the MFMAs
   float gpre[EPT][4], cold[EPT];
+  auto load_epilogue_inputs = [&]() {
 #pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i;
-    const int row = e / UG, ju = e % UG, b = b0 + row;
-    const bool ok = (e < NE) && (b < p.B) && !(p.ablate & 8);
+    for (int i = 0; i < EPT; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / UG, ju = e % UG, b = b0 + row;
+      const bool ok = (e < NE) && (b < p.B) && !(p.ablate & 8);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      gpre[i][g] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + g * UG + ju] : 0.0f;
-    cold[i] = (ok && !first) ? p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] : 0.0f;
-  }
+      for (int g = 0; g < 4; ++g)
+        gpre[i][g] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + g * UG + ju] : 0.0f;
+      cold[i] = (ok && !first) ? p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] : 0.0f;
+    }
+  };
+  if (first) load_epilogue_inputs();
 
   if (!first) {
     f32x4 acc[MT][NT];
@@ -366,38 +420,92 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fi = lane & 15, fg = lane >> 4;
-    const float* wbase = p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256 + lane * 4;
-    // wave w owns k-chunks q = w, w+4, w+8, ...
-    for (int qb = wave; qb < p.KQ; qb += 4 * QB) {
-      float4 a[QB][MT], w[QB][NT];
+    // All operand fetches are raw buffer loads: one SGPR descriptor per operand, ONE per-lane byte offset,
+    // compile-time deltas per fragment.  Out-of-range offsets return zeros, so rows past B and chunks past
+    // the end of K need neither a branch nor address arithmetic per load -- with a single wave per SIMD the
+    // issue cost of ~40 loads was a visible slice of every time step.  (The range check covers the per-lane
+    // offset and the immediate, not the scalar offset, so everything goes into the former.)
+    constexpr unsigned kOOB = 0x7ffffff0u;
+    if constexpr (X3) {
+      // split-bf16 form: A = (h_hi, h_lo) written by the previous step's epilogue, B = (W_hi, W_lo)
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.whh_x3 + (long)(dir * p.NU + ugi) * p.KQ2 * NT * 1024), 0, p.KQ2 * NT * 2048, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.hs + (long)((p.step - 1) & 1) * p.B * 4 * p.Hs), 0, p.B * 4 * p.Hs * 2, 0x00020000);
+      const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 2048 + lane * 16);
+      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 + fi) * 2 + dir) * 2 * p.Hs + 32 * wave + 8 * fg) * 2);
+      const unsigned h_mt = 16 * 4 * p.Hs * 2, h_hl = p.Hs * 2;
+      for (int qb = 0; qb < p.KQ2; qb += 4 * QB3) {
+        u32x4 a[QB3][MT][2], w[QB3][NT][2];
 #pragma unroll
-      for (int i = 0; i < QB; ++i) {
-        const int q = qb + 4 * i;
-        const bool qok = q < p.KQ;
-        const int k = 16 * q + 4 * fg;
+        for (int i = 0; i < QB3; ++i) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int b = b0 + mt * 16 + fi;
-          a[i][mt] = (qok && b < p.B && k < p.Hp && !(p.ablate & 1))
-                         ? *reinterpret_cast<const float4*>(p.y + ((long)(tprev * p.B + b) * 2 + dir) * p.Hp + k)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+              a[i][mt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + hl * h_hl + (qb + 4 * i) * 64, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+              w[i][nt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + (nt * 2 + hl) * 1024 + (qb + 4 * i) * NT * 2048, 0, 0);
         }
+        if (qb == 0) load_epilogue_inputs();
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          w[i][nt] = (qok && !(p.ablate & 2)) ? *reinterpret_cast<const float4*>(wbase + ((long)q * NT + nt) * 256)
-                         : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < QB; ++i) {
-        if (qb + 4 * i < p.KQ && !(p.ablate & 4)) {  // wave-uniform: skip chunks past the end of K
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < QB3; ++i) {
+          if (qb + wave + 4 * i < p.KQ2 && !(p.ablate & 4)) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(a[i][mt], r), f4c(w[i][nt], r), acc[mt][nt], 0, 0, 0);
+              for (int nt = 0; nt < NT; ++nt) {
+                const s16x8 ah = __builtin_bit_cast(s16x8, a[i][mt][0]), al = __builtin_bit_cast(s16x8, a[i][mt][1]);
+                const s16x8 wh = __builtin_bit_cast(s16x8, w[i][nt][0]), wl = __builtin_bit_cast(s16x8, w[i][nt][1]);
+                acc[mt][nt] = mfma_bf16(al, wh, acc[mt][nt]);   // small terms first
+                acc[mt][nt] = mfma_bf16(ah, wl, acc[mt][nt]);
+                acc[mt][nt] = mfma_bf16(ah, wh, acc[mt][nt]);
+              }
+          }
+        }
+      }
+    } else {
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256), 0, p.KQ * NT * 1024, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.y + (long)tprev * p.B * 2 * p.Hp), 0, p.B * 2 * p.Hp * 4, 0x00020000);
+      const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 1024 + lane * 16);
+      const unsigned hv0 = (unsigned)((((b0 + fi) * 2 + dir) * p.Hp + 16 * wave + 4 * fg) * 4);
+      const unsigned h_mt = 16 * 2 * p.Hp * 4;
+      const int k0 = 16 * wave + 4 * fg;   // this lane's k within chunk q = wave (+16 per 4 chunks ... +64 per i)
+      for (int qb = 0; qb < p.KQ; qb += 4 * QB) {
+        u32x4 a[QB][MT], w[QB][NT];
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+          // the K tail of a row must read as zero (what follows in memory belongs to the other direction)
+          const unsigned hv = ((p.ablate & 1) || k0 + 16 * (qb + 4 * i) >= p.Hp) ? kOOB : hv0;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            a[i][mt] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + (qb + 4 * i) * 64, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            w[i][nt] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + nt * 1024 + (qb + 4 * i) * NT * 1024, 0, 0);
+        }
+        if (qb == 0) load_epilogue_inputs();
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+          if (qb + wave + 4 * i < p.KQ && !(p.ablate & 4)) {  // wave-uniform: skip chunks past the end of K
+            float4 af[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(float4, a[i][mt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = __builtin_bit_cast(float4, w[i][nt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(af[mt], r), f4c(wf[nt], r), acc[mt][nt], 0, 0, 0);
+          }
         }
       }
     }
@@ -444,6 +552,13 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
         og = gate_sigmoid(pre[3]);
         cn = fg2 * cold[i] + ig * gg;
         h = og * gate_tanh(cn);
+      }
+      if constexpr (X3) {   // hand h_t to the next step already split (3 VALU ops here vs hundreds in the consumer)
+        unsigned short hi, lo;
+        split_bf16(h, hi, lo);
+        unsigned short* dst = p.hs + ((long)(p.step & 1) * p.B * 4 + (long)(b * 2 + dir) * 2) * p.Hs + ugi * UG + ju;
+        dst[0] = hi;
+        dst[p.Hs] = lo;
       }
       p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] = cn;
       p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
@@ -619,12 +734,15 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 
 
 template <int MT, int NT>
-static int launch_steps(StepArgs sp, int T, hipStream_t st) {
+static int launch_steps(StepArgs sp, int T, bool x3, hipStream_t st) {
   const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
   ONSSEN_CLEAR_ERROR();
   for (int s = 0; s < T; ++s) {
     sp.step = s;
-    hipLaunchKernelGGL((lstm_step_kernel<MT, NT>), grid, block, 0, st, sp);
+    if (x3)
+      hipLaunchKernelGGL((lstm_step_kernel<MT, NT, true>), grid, block, 0, st, sp);
+    else
+      hipLaunchKernelGGL((lstm_step_kernel<MT, NT, false>), grid, block, 0, st, sp);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ONSSEN_OK : (int)e;
@@ -691,6 +809,30 @@ int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_
   if (NP) *NP = 4 * hp;
   if (KQ) *KQ = kq;
   if (whh_elems) *whh_elems = (int64_t)(hp / ug) * kq * (ug / 4) * 256;
+  return ONSSEN_OK;
+}
+
+int onssen_lstm_geometry_x3(int H, int ug, int* KQ2, int* Hs, int64_t* whh_x3_elems) {
+  int Hp;
+  if (onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK) return ONSSEN_E_ARG;
+  const int kq2 = ceil_div(Hp, 32);
+  if (KQ2) *KQ2 = kq2;
+  if (Hs) *Hs = 32 * kq2;
+  if (whh_x3_elems) *whh_x3_elems = (int64_t)(Hp / ug) * kq2 * (ug / 4) * 1024;
+  return ONSSEN_OK;
+}
+
+int onssen_lstm_pack_whh_bf16x3(const float* w_hh, int H, int ug, uint16_t* whh_x3, void* stream) {
+  int Hp, KQ2;
+  int64_t we;
+  if (!w_hh || !whh_x3 || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK ||
+      onssen_lstm_geometry_x3(H, ug, &KQ2, nullptr, &we) != ONSSEN_OK)
+    return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const long n = we / 2;
+  hipLaunchKernelGGL(pack_whh_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, w_hh, H, Hp, ug, KQ2, whh_x3);
+  ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
 
@@ -767,7 +909,8 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
-  return 512 + g + (L > 1 ? y : 0) + c;   // leading 512 B reserved
+  const size_t hs = align256((size_t)2 * B * 4 * (32 * ceil_div(Hp, 32)) * sizeof(uint16_t));   // split-bf16 h hand-off
+  return 512 + g + (L > 1 ? y : 0) + c + hs;   // leading 512 B reserved
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -792,6 +935,16 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     wsp += align256((size_t)T * B * 2 * Hp * sizeof(float));
   }
   float* cst = (float*)wsp;
+  wsp += align256((size_t)2 * B * Hp * sizeof(float));
+  const bool x3 = (flags & ONSSEN_BLSTM_BF16X3) != 0;
+  int KQ2 = 0, Hs = 0;
+  onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
+  if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
+  uint16_t* hsb = (uint16_t*)wsp;
+  if (x3) {   // the K padding [Hp, Hs) of the hand-off rows is never written by the kernels: keep it zero
+    hipError_t e = hipMemsetAsync(hsb, 0, (size_t)2 * B * 4 * Hs * sizeof(uint16_t), st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int mt = (B > 16 && !(flags & ONSSEN_BLSTM_SPLIT_ROWS)) ? 2 : 1;
   for (int l = 0; l < L; ++l) {
     // the last layer writes `y`; the layers before it alternate so that each reads what the previous wrote
@@ -809,9 +962,10 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     }
     if (rc != ONSSEN_OK) return rc;
     StepArgs sp;
-    sp.G = G; sp.whh = whh_p_host[l]; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
+    sp.G = G; sp.whh = x3 ? nullptr : whh_p_host[l]; sp.whh_x3 = x3 ? (const unsigned short*)whh_p_host[l] : nullptr;
+    sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
     sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 31;
-#define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, T, st)
+#define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, T, x3, st)
     if (mt == 1) {
       switch (ug) {
         case 4: ONSSEN_STEPS(1, 1); break;

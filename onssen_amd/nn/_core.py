@@ -19,11 +19,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def precision():
+    """Arithmetic of the MFMA contractions: "f32" = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32);
+    "bf16x3" = split-bf16 (3 bf16 MFMAs per fp32 product, ~1e-5 relative, fp32 accumulate)."""
+    p = os.environ.get("ONSSEN_PRECISION", "f32")
+    if p not in ("f32", "bf16x3"):
+        raise ValueError(f"ONSSEN_PRECISION={p!r}: expected 'f32' or 'bf16x3'")
+    return p
+
+
 def recurrence_plan(B, H):
     """(ug, flags) for onssen_blstm_forward_f32: hidden units per recurrence workgroup.  ONSSEN_UG
     overrides (A/B benches, tests); ONSSEN_ABLATE sets the profiling-only ablation bits."""
     ug = int(os.environ.get("ONSSEN_UG", "8"))
     flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
+    if precision() == "bf16x3" and H <= 640:
+        flags |= _abi.BLSTM_BF16X3
     if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
         flags |= _abi.BLSTM_SPLIT_ROWS
     return ug, flags
@@ -103,7 +114,8 @@ class _PackedImages:
         dev = flat[0].device
         H, L = p.hidden_size, p.num_layers
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
-        self.wih, self.whh, self.bias = [], [], []
+        self.wih, self.whh, self.bias, self.whh_x3 = [], [], [], []
+        _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
         for l in range(L):
             in_l = p.input_size if l == 0 else 2 * H
@@ -115,7 +127,11 @@ class _PackedImages:
                 w_ih, w_hh, b_ih, b_hh = [t.detach().contiguous() for t in flat[(2 * l + d) * 4:(2 * l + d) * 4 + 4]]
                 lib.lstm_pack(w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), in_l,
                               0 if l == 0 else 1, H, self.ug, a[d].data_ptr(), b[d].data_ptr(), c[d].data_ptr(), st)
-            self.wih.append(a), self.whh.append(b), self.bias.append(c)
+            b3 = torch.empty(2, we3, device=dev, dtype=torch.int16)
+            for d in range(2):
+                w_hh = flat[(2 * l + d) * 4 + 1].detach().contiguous()
+                lib.lstm_pack_whh_bf16x3(w_hh.data_ptr(), H, self.ug, b3[d].data_ptr(), st)
+            self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3)
         self.key = key
         return self
 
@@ -185,7 +201,8 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
-                      [t.data_ptr() for t in pk.wih], [t.data_ptr() for t in pk.whh],
+                      [t.data_ptr() for t in pk.wih],
+                      [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
     return y
 

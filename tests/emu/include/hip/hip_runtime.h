@@ -197,7 +197,9 @@ static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, 
 typedef unsigned int emu_u32x4 __attribute__((vector_size(16)));
 static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
   emu_u32x4 v = {0, 0, 0, 0};
-  if ((long)voff + (long)soff + 16 <= (long)r.bytes) {   // out-of-range buffer loads return 0, like the hardware
+  // raw-buffer range check like the hardware: on the (unsigned) per-lane offset only -- the scalar offset is
+  // added to the address afterwards and is NOT checked
+  if ((unsigned long)(unsigned)voff + 16 <= (unsigned long)r.bytes) {
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
     memcpy(&v, r.base + voff + soff, 16);
   }
@@ -205,3 +207,31 @@ static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rs
 }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+
+// ---- bf16: __bf16 is only ever used by the product as the element type of an 8-wide MFMA operand vector
+#define __bf16 short
+typedef short emu_s16x8 __attribute__((vector_size(16)));
+static inline float emu_bf16_to_f32(short b) {
+  uint32_t u = uint32_t(uint16_t(b)) << 16; float f; memcpy(&f, &u, 4); return f;
+}
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=8*(l>>4)+j] and B[k=8*(l>>4)+j][col=l&15], j=0..7;
+// products are exact in fp32, accumulation in fp32
+static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c, int, int, int) {
+  static thread_local int dummy; (void)dummy;
+  struct Buf { short a[64][8]; short b[64][8]; };
+  static Buf bufs[16];                      // one per wave of the running workgroup (statics are per process)
+  Buf& w = bufs[emu::wave];
+  for (int j = 0; j < 8; ++j) { w.a[emu::lane][j] = a[j]; w.b[emu::lane][j] = b[j]; }
+  emu::wave_sync();
+  const int col = emu::lane & 15, rg = emu::lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * rg + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g)
+      for (int j = 0; j < 8; ++j)
+        acc = fmaf(emu_bf16_to_f32(w.a[row + 16 * g][j]), emu_bf16_to_f32(w.b[col + 16 * g][j]), acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}

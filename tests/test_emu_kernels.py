@@ -157,3 +157,30 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     a = np.frombuffer(mmap.mmap(-1, max(n, 16)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
     a[...] = fill
     return a
+
+
+@pytest.mark.parametrize("H,ug,B", [(40, 8, 3), (12, 12, 17), (70, 4, 2)])
+def test_blstm_split_bf16_recurrence(lib, H, ug, B):
+    """ONSSEN_BLSTM_BF16X3: h W_hh^T as three bf16 MFMAs per fp32 product; ~1e-5 of the fp32 oracle."""
+    F, L, T = 9, 2, 6
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(3)
+    x = rand(rng, B, T, F)
+    Hp, NP, wih, whh, bias = _pack_lstm(lib, sd, "rnn.", F, H, L, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    whh3 = []
+    for l in range(L):
+        b3 = np.zeros((2, we3), np.uint16)
+        for d, sfx in enumerate(("", "_reverse")):
+            w_hh = np.ascontiguousarray(sd[f"rnn.weight_hh_l{l}{sfx}"])
+            lib.lstm_pack_whh_bf16x3(P(w_hh), H, ug, P(b3[d]), None)
+        whh3.append(b3)
+    ws = np.zeros(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64, np.float32)
+    y = np.full((T, B, 2, Hp), np.nan, np.float32)
+    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh3],
+                      [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3, None)
+    ref = O.blstm_stack(x, sd, "rnn.", L)
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    err = np.abs(got - ref).max()
+    assert err < 2e-5, err
+    assert np.all(y[:, :, :, H:] == 0)

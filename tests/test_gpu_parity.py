@@ -124,6 +124,24 @@ def test_full_size_golden_subsample(dev, golden_dir, tag, kind):
         np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg3_chimera_L4", "chimera")])
+def test_split_bf16_mode_meets_parity_budget(dev, golden_dir, monkeypatch, tag, kind):
+    """ONSSEN_PRECISION=bf16x3 (3 bf16 MFMAs per fp32 product in the recurrence): same reference
+    vectors, same tolerances as the exact-fp32 path."""
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    z = np.load(f"{golden_dir}/g2_{tag}.npz")
+    m, _ = build(kind, z, dev)
+    x = logmag_input(int(z["x_seed"]), int(z["B"]), int(z["T"]))
+    with torch.no_grad():
+        outs = m([torch.from_numpy(x).to(dev)])
+    emb = outs[0].cpu().numpy()
+    err = np.abs(emb[:, ::40, ::16, :] - z["emb_sub"]).max()
+    rl2 = rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max()
+    print(f"split-bf16 {tag}: max abs err {err:.3e}, max per-vector rel-L2 {rl2:.3e}")
+    np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5, rtol=1e-4)
+    assert rl2 < 1e-4
+
+
 # ---------------------------------------------------------------- oracle at other shapes / edge cases
 @pytest.mark.parametrize("B,T,H,L", [(1, 400, 600, 2), (5, 37, 600, 2), (33, 21, 300, 3), (17, 1, 64, 2), (2, 50, 30, 1),
                                      (70, 9, 128, 2)])

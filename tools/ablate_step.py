@@ -36,7 +36,7 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-for ug in (8, 12, 4, 20, 16):
+for ug in (8, 12, 16):
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
     y = torch.empty(T, B, 2, Hp, device=dev)
@@ -55,5 +55,13 @@ for ug in (8, 12, 4, 20, 16):
                               [pk.whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(),
                               (ab << 8) if ab < 0x10000 else 1, _stream())
         row.append((timed(layer) - tg) / T * 1e6)
+    x3 = []
+    for ab in (0, 3, 4):
+        def layer3():
+            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih[1].data_ptr()],
+                              [pk.whh_x3[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
+                              ws.numel(), (ab << 8) | 2, _stream())
+        x3.append((timed(layer3) - tg) / T * 1e6)
+    print(f"   split-bf16 recurrence ug={ug}: us/step full={x3[0]:.2f} no_loads={x3[1]:.2f} no_mfma={x3[2]:.2f}")
     print(f"B={B} ug={ug:2d} WGs={2 * (Hp // ug) * ((B + 31) // 32 if B > 16 else 1)}: us/step full={row[0]:.2f} libm_act={row[1]:.2f} "
           f"no_loads={row[2]:.2f} no_mfma={row[3]:.2f} no_loads_mfma={row[4]:.2f} +no_G={row[5]:.2f} split_rows={row[6]:.2f} (gemm {tg * 1e3:.2f} ms)")
