@@ -1,0 +1,120 @@
+"""Multi-process paths on CPU: world_size 2, gloo backend (the GPU run uses the same code over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from onssen_amd import dist as odist
+from onssen_amd import nn as onn
+from onssen_amd.loss import loss_dc
+from onssen_amd.synthetic import make_state_dict
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed=5, H=16, L=2):
+    sd = make_state_dict("deep_clustering", 129, H, L, 20, 2, seed=seed)
+    m = onn.deep_clustering(129, H, L, 20, dropout=0.0)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return m
+
+
+def _batch(seed, B, T=12):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, 129, generator=g)
+    lab = torch.randint(0, 2, (B, T, 129), generator=g)
+    one_hot = torch.stack([lab, 1 - lab], -1).double()
+    mag = torch.rand(B, T, 129, generator=g) + 0.1
+    return [x], [one_hot, mag]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    # ---- data-parallel training step: gradients after the exchange = mean of the per-rank gradients
+    m = _model().eval()                   # fixed BatchNorm statistics, dropout 0: the gradient parity contract
+    inp, lab = _batch(100 + rank, 2)
+    torch.mean(loss_dc(m(inp), lab)).backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    odist.allreduce_gradients(m, world)
+    synced = [p.grad.clone() for p in m.parameters()]
+    # ---- a full step keeps replicas identical
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    loss = odist.train_step(m, opt, loss_dc, inp, lab, world)
+    w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    # ---- utterance-sharded inference: gather(shards) == whole batch
+    n = 5
+    lo, hi = odist.shard_range(n, rank, world)
+    allx = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
+    got = odist.gather_utterances(allx[lo:hi] * 2, n, world)
+    if rank == 0:
+        out.put(dict(local0=[g.numpy() for g in local], synced=[g.numpy() for g in synced], loss=loss,
+                     same=bool(torch.equal(ws[0], ws[1])), gathered=got.numpy()))
+    else:
+        out.put(dict(local1=[g.numpy() for g in local]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allreduce_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in range(2):
+        res.update(q.get(timeout=240))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b, s in zip(res["local0"], res["local1"], res["synced"]):
+        np.testing.assert_allclose(s, (a + b) / 2, rtol=1e-5, atol=1e-7)
+    assert res["same"] and np.isfinite(res["loss"])
+    np.testing.assert_array_equal(res["gathered"], np.arange(15, dtype=np.float32).reshape(5, 3) * 2)
+
+
+def test_shard_range_covers_everything():
+    for n in (1, 7, 32, 33):
+        for w in (1, 2, 8):
+            spans = [odist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_gradient_buckets_partition_parameters():
+    m = _model(L=3)
+    buckets = odist.gradient_buckets(m)
+    ids = [id(p) for b in buckets for p in b]
+    assert sorted(ids) == sorted(id(p) for p in m.parameters()) and len(buckets) == 1 + 2 * 3
+
+
+def test_loss_dc_and_gradient_match_reference_fixture(golden_dir):
+    """Row H3: loss value, (B,B) shape quirk and gradient norm of the reference's loss_dc + autograd
+    (tools/gen_golden.py G4), reproduced through this package's training path on CPU."""
+    z = np.load(f"{golden_dir}/g4_loss_dc.npz")
+    m = _model(seed=int(z["seed"]), H=int(z["H"]), L=int(z["L"])).eval()
+    out = m([torch.from_numpy(z["x"])])
+    loss = loss_dc(out, [torch.from_numpy(z["one_hot"]), torch.from_numpy(z["mag"])])
+    assert tuple(loss.shape) == z["loss"].shape == (3, 3)
+    np.testing.assert_allclose(loss.detach().numpy(), z["loss"], rtol=1e-5)
+    torch.mean(loss).backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    np.testing.assert_allclose(gn.item(), float(z["grad_norm"]), rtol=1e-4)
+    np.testing.assert_allclose(m.fc_dc.bias.grad.numpy(), z["grad_fc_dc_bias"], rtol=1e-3, atol=1e-6)
