@@ -365,6 +365,7 @@ struct StepArgs {
   unsigned short* hs;            // split h hand-off [2 slots][B][2 dirs][hi|lo][Hs] bf16   (X3 kernels)
   int KQ2, Hs;                   // 32-wide k-chunks, padded row length Hs = 32*KQ2
   int B, T, Hp, NP, KQ, NU, step;
+  long long* dbg;  // profiling only: per-step timestamps of workgroup (0,0,0), or null
   int ablate;  // profiling only (flags >> 8): 1 = no h loads, 2 = no W loads, 4 = no MFMA, 8 = no G / c loads
 };
 
@@ -383,10 +384,26 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
 }
 __device__ __forceinline__ float gate_tanh(float x) { return 2.0f * gate_sigmoid(2.0f * x) - 1.0f; }
 
-template <int MT, int NT, bool X3>
-__global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
+// Arguments are 14 scalar dwords in order of first use so that, with -amdgpu-kernarg-preload-count, the
+// command processor delivers them in SGPRs at dispatch.  Every launch starts with cold scalar/L2 caches, so
+// each *dependent* s_load of a kernel argument is a ~1 us round trip to memory on the critical path of a
+// time step; the struct-by-value form paid three of them.  Everything else is derived from these.
+template <int MT, int NT, bool X3, bool DBG>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws, float* y, int step, int B, int NU,
+                                                        int T, unsigned g_off256, unsigned c_off256,
+                                                        unsigned hs_off256, int ablate_arg, long long* dbg_arg) {
   using namespace rec;
   constexpr int UG = 4 * NT;          // hidden units per workgroup
+  StepArgs p;
+  p.G = reinterpret_cast<const float*>(ws + (size_t)g_off256 * 256);
+  p.c = reinterpret_cast<float*>(ws + (size_t)c_off256 * 256);
+  p.hs = reinterpret_cast<unsigned short*>(ws + (size_t)hs_off256 * 256);
+  p.whh = static_cast<const float*>(w);
+  p.whh_x3 = static_cast<const unsigned short*>(w);
+  p.y = y; p.step = step; p.B = B; p.NU = NU; p.T = T;
+  p.Hp = NU * UG; p.NP = 4 * p.Hp; p.KQ = (p.Hp + 15) / 16; p.KQ2 = (p.Hp + 31) / 32; p.Hs = 32 * p.KQ2;
+  p.ablate = DBG ? ablate_arg : 0;
+  p.dbg = DBG ? dbg_arg : nullptr;
   constexpr int NE = 16 * MT * UG;    // (batch row, unit) elements per workgroup
   constexpr int EPT = (NE + 255) / 256;
   __shared__ float red[4 * MT * NT * 4 * RLD];
@@ -395,6 +412,8 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
   const int t = dir == 0 ? p.step : p.T - 1 - p.step;
   const int tprev = dir == 0 ? t - 1 : t + 1;
   const bool first = p.step == 0;
+  const bool stamp = p.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  if (stamp) { p.dbg[p.step * 8 + 0] = wall_clock64(); p.dbg[p.step * 8 + 1] = clock64(); }
 
   // ---- the epilogue's global reads (input projection, cell state) are independent of the recurrent
   // product: they are issued right after the operand fetches so that their latency hides behind the MFMAs
@@ -451,6 +470,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
               w[i][nt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + (nt * 2 + hl) * 1024 + (qb + 4 * i) * NT * 2048, 0, 0);
         }
         if (qb == 0) load_epilogue_inputs();
+        if (stamp) p.dbg[p.step * 8 + 2] = clock64();
 #pragma unroll
         for (int i = 0; i < QB3; ++i) {
           if (qb + wave + 4 * i < p.KQ2 && !(p.ablate & 4)) {
@@ -515,7 +535,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * MT * NT + mt * NT + nt) * 4 + r) * RLD + lane] = acc[mt][nt][r];
+    if (stamp) p.dbg[p.step * 8 + 3] = clock64();
     __syncthreads();
+    if (stamp) p.dbg[p.step * 8 + 4] = clock64();
   }
 
   // ---- fused cell update: one (batch row, hidden unit) per thread
@@ -564,6 +586,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(StepArgs p) {
       p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
     }
   }
+  if (stamp) { p.dbg[p.step * 8 + 5] = clock64(); p.dbg[p.step * 8 + 6] = wall_clock64(); }
 }
 
 
@@ -734,15 +757,23 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 
 
 template <int MT, int NT>
-static int launch_steps(StepArgs sp, int T, bool x3, hipStream_t st) {
+static int launch_steps(StepArgs sp, char* ws, int T, bool x3, hipStream_t st) {
   const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
+  const unsigned g_off = (unsigned)(((const char*)sp.G - ws) / 256), c_off = (unsigned)(((char*)sp.c - ws) / 256),
+                 hs_off = (unsigned)(((char*)sp.hs - ws) / 256);
   ONSSEN_CLEAR_ERROR();
   for (int s = 0; s < T; ++s) {
     sp.step = s;
-    if (x3)
-      hipLaunchKernelGGL((lstm_step_kernel<MT, NT, true>), grid, block, 0, st, sp);
-    else
-      hipLaunchKernelGGL((lstm_step_kernel<MT, NT, false>), grid, block, 0, st, sp);
+    const void* w = x3 ? (const void*)sp.whh_x3 : (const void*)sp.whh;
+#define ONSSEN_STEP_LAUNCH(X3_, DBG_)                                                                             \
+  hipLaunchKernelGGL((lstm_step_kernel<MT, NT, X3_, DBG_>), grid, block, 0, st, w, ws, sp.y, s, sp.B, sp.NU, T, g_off, \
+                     c_off, hs_off, sp.ablate, sp.dbg)
+    if (sp.ablate || sp.dbg) {
+      if (x3) ONSSEN_STEP_LAUNCH(true, true); else ONSSEN_STEP_LAUNCH(false, true);
+    } else {
+      if (x3) ONSSEN_STEP_LAUNCH(true, false); else ONSSEN_STEP_LAUNCH(false, false);
+    }
+#undef ONSSEN_STEP_LAUNCH
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ONSSEN_OK : (int)e;
@@ -910,7 +941,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
   const size_t hs = align256((size_t)2 * B * 4 * (32 * ceil_div(Hp, 32)) * sizeof(uint16_t));   // split-bf16 h hand-off
-  return 512 + g + (L > 1 ? y : 0) + c + hs;   // leading 512 B reserved
+  return 512 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 512 B reserved; trailing 64 KiB profiling area
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -923,7 +954,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   if (!x || !y || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || T <= 0 || in_dim <= 0 || L <= 0)
     return ONSSEN_E_ARG;
   if (ws_bytes < onssen_blstm_workspace_bytes(B, T, H, L, ug)) return ONSSEN_E_WORKSPACE;
-  if (!aligned16(ws) || !aligned16(y)) return ONSSEN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(y)) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
   wsp += 512;   // reserved header
@@ -941,6 +972,8 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
   if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
   uint16_t* hsb = (uint16_t*)wsp;
+  wsp += align256((size_t)2 * B * 4 * Hs * sizeof(uint16_t));
+  long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)wsp : nullptr;
   if (x3) {   // the K padding [Hp, Hs) of the hand-off rows is never written by the kernels: keep it zero
     hipError_t e = hipMemsetAsync(hsb, 0, (size_t)2 * B * 4 * Hs * sizeof(uint16_t), st);
     if (e != hipSuccess) return (int)e;
@@ -963,9 +996,9 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     if (rc != ONSSEN_OK) return rc;
     StepArgs sp;
     sp.G = G; sp.whh = x3 ? nullptr : whh_p_host[l]; sp.whh_x3 = x3 ? (const unsigned short*)whh_p_host[l] : nullptr;
-    sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
-    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 31;
-#define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, T, x3, st)
+    sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.dbg = dbg; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
+    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 63;
+#define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, (char*)ws, T, x3, st)
     if (mt == 1) {
       switch (ug) {
         case 4: ONSSEN_STEPS(1, 1); break;

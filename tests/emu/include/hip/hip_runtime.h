@@ -235,3 +235,5 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu
   emu::wave_sync();
   return c;
 }
+static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }

@@ -20,6 +20,13 @@ def P(a):
     return a.ctypes.data if a is not None else None
 
 
+def aligned_f32(n, align=256):
+    """float32 scratch whose address is `align`-byte aligned (workspaces must be 256-byte aligned)."""
+    raw = np.zeros(n + align // 4, np.float32)
+    off = (-raw.ctypes.data % align) // 4
+    return raw[off:off + n]
+
+
 def rand(rng, *shape):
     return rng.standard_normal(shape).astype(np.float32)
 
@@ -87,7 +94,7 @@ def test_blstm_stack_matches_oracle(lib, H, ug, B):
     rng = np.random.default_rng(3)
     x = rand(rng, B, T, F)
     Hp, NP, wih, whh, bias = _pack_lstm(lib, sd, "rnn.", F, H, L, ug)
-    ws = np.zeros(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64, np.float32)
+    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64)
     y = np.full((T, B, 2, Hp), np.nan, np.float32)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, 0, None)
@@ -175,7 +182,7 @@ def test_blstm_split_bf16_recurrence(lib, H, ug, B):
             w_hh = np.ascontiguousarray(sd[f"rnn.weight_hh_l{l}{sfx}"])
             lib.lstm_pack_whh_bf16x3(P(w_hh), H, ug, P(b3[d]), None)
         whh3.append(b3)
-    ws = np.zeros(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64, np.float32)
+    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64)
     y = np.full((T, B, 2, Hp), np.nan, np.float32)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3, None)
