@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 SR, NFFT, HOP, T_FRAMES = 8000, 256, 64, 400
 N_SAMPLES = 25536                                    # 1 + 25536 // 64 = 400 frames
+BF16_MFMA_PEAK_TFLOPS = 2500.0                       # dense bf16 MFMA (2:1-sparse marketing figure excluded)
 FP32_MFMA_PEAK_TFLOPS = 157.3                        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 HBM_PEAK_GBS = 8000.0
 
@@ -62,8 +63,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override chunks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "f32"), choices=["f32", "bf16x3"],
+                    help="f32 = exact-fp32 MFMA; bf16x3 = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate)")
     args = ap.parse_args()
 
+    os.environ["ONSSEN_PRECISION"] = args.precision
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,7 +164,8 @@ def main():
         "sep_hours_per_s": audio_s / elapsed / 3600.0,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.precision == "f32" else "f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, 8 kHz STFT "
                                f"{NFFT}/{HOP}, {B} x {T_FRAMES}-frame chunks per GPU; step = STFT+log-mag -> BLSTM "
                                "-> fc_dc + L2-normalise -> mask-apply + iSTFT (2 speakers)",
@@ -192,6 +197,16 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     ug, flags = recurrence_plan(B, H)
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
+    x3 = bool(flags & 2)
+    wih = pk.wih_x3 if x3 else pk.wih
+    whh = pk.whh_x3 if x3 else pk.whh
+
+    def lin(A, a_s0, a_s1, K, Wf, ldf, W3, ld3, bias, N, mode, group, out_ptr, c_s0, c_s1):
+        if x3:
+            lib.linear_bf16x3(A, a_s0, a_s1, B, T * B, K, W3, ld3, bias, N, mode, group, 1e-12, None, out_ptr, c_s0, c_s1,
+                              st())
+        else:
+            lib.linear(A, a_s0, a_s1, B, T * B, K, Wf, ldf, bias, N, mode, group, 1e-12, None, out_ptr, c_s0, c_s1, st())
     y = torch.empty(T, B, 2, Hp, device=dev)
     ws = torch.empty(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
     xin = torch.randn(B, T, F, device=dev)
@@ -201,35 +216,36 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
 
     def layer():
         if lyr == 0:
-            lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [pk.wih[0].data_ptr()],
-                              [pk.whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(),
+            lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [wih[0].data_ptr()],
+                              [whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(),
                               ws.numel(), flags, st())
         else:   # feed y-shaped input through layer 1's weights: x (B,T,2Hp) strides of the time-major buffer
-            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih[1].data_ptr()],
-                              [pk.whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
+            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [wih[1].data_ptr()],
+                              [whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
                               ws.numel(), flags, st())
 
     gbuf = ws[512:]
+    F4, F32 = (F + 3) // 4 * 4, (F + 31) // 32 * 32
+    K1, K132 = 2 * Hp, (2 * Hp + 31) // 32 * 32
+
+    def gemm0():
+        lin(xin.data_ptr(), xin.stride(1), xin.stride(0), F, pk.wih[0].data_ptr(), F4, pk.wih_x3[0].data_ptr(), F32,
+            pk.bias[0].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
 
     def gemm_in():
         if lyr == 0:
-            lib.linear(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, pk.wih[0].data_ptr(), (F + 3) // 4 * 4,
-                       pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
+            gemm0()
         else:
-            lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,
-                       pk.bias[1].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
-
-    def gemm0():
-        lib.linear(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, pk.wih[0].data_ptr(), (F + 3) // 4 * 4,
-                   pk.bias[0].data_ptr(), 2 * NP, 0, 0, 0.0, None, gbuf.data_ptr(), B * 2 * NP, 2 * NP, st())
+            lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, pk.wih[1].data_ptr(), K1, pk.wih_x3[1].data_ptr(), K132,
+                pk.bias[1].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
 
     hd = model._head_dc if kind == "chimera" else model._head
     hp = hd.get(Hp)
     out = torch.empty(B, T, hp.N, device=dev)
 
     def head():
-        lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hp.w.data_ptr(), 2 * Hp, hp.b.data_ptr(), hp.N,
-                   1, D, 1e-12, None, out.data_ptr(), hp.N, T * hp.N, st())
+        lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, hp.w.data_ptr(), K1, hp.planes.data_ptr(), hp.ld3, hp.b.data_ptr(),
+            hp.N, 1, D, out.data_ptr(), hp.N, T * hp.N)
 
     def timed(fn, reps=5):
         fn()
@@ -262,13 +278,17 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     if os.path.exists(tf):
         traffic = json.load(open(tf)).get("recurrence_hbm_bytes_per_launch")
     launches = T
+    # ceiling for ALGORITHMIC (fp32-equivalent) FLOPs: the exact-fp32 MFMA rate, or a third of the dense bf16
+    # MFMA rate when every product is three bf16 MFMAs
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
     rec = {"kernel": "lstm_step_kernel", "bound": "mfma",
-           "achieved": flop_rec / t_rec / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": flop_rec / t_rec / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+           "achieved": flop_rec / t_rec / 1e12, "peak": peak, "unit": "TFLOP/s",
+           "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
+           "peak_note": "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
            "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
-    gem = {"kernel": "linear_kernel", "bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+    gem = {"kernel": "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
            "achieved_by_call": {"input_proj_l0": 2.0 * B * T * 8 * H * F / t_g0 / 1e12,
                                 "input_proj_l1": (flop_gin / t_gin / 1e12) if lyr else None,
                                 "fc_dc_l2norm": flop_head / t_head / 1e12},

@@ -40,7 +40,10 @@ extern "C" {
 #define ONSSEN_BLSTM_SPLIT_ROWS 1 /* 16 batch rows per recurrence workgroup instead of 32: more workgroups */
 #define ONSSEN_BLSTM_BF16X3 2     /* recurrent product h W_hh^T in split-bf16 (3 bf16 MFMAs per fp32 product,
                                      ~1e-5 relative); whh_p_host[l] must then point to the images made by
-                                     onssen_lstm_pack_whh_bf16x3 ([2 directions][whh_x3_elems] uint16).  H <= 640. */
+                                     onssen_lstm_pack_whh_bf16x3 ([2 directions][whh_x3_elems] uint16), and
+                                     wih_p_host[l] to onssen_linear_pack_bf16x3 planes of the [2*NP][K_l] matrix
+                                     (ld = K_l rounded up to 32): the input projections run split-bf16 too.
+                                     H <= 640. */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
@@ -110,6 +113,17 @@ int onssen_head_pack_f32(const float* w, const float* b, int N, int H, int Hp, c
 int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, int K, const float* W, int ldw,
                       const float* bias, int N, int mode, int group, float eps, const float* resid, float* C,
                       int64_t c_s0, int64_t c_s1, void* stream);
+
+/* Split-bf16 form of onssen_linear_f32: every fp32 product is a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16
+ * MFMA pipe with fp32 accumulation (~1e-5 relative on a dot product; measured 1e-6 abs on the network
+ * outputs).  A is plain fp32 and split on the fly; the weights are pre-split by onssen_linear_pack_bf16x3 into
+ * `w_planes` = [N][ldw] bf16 hi plane followed by the [N][ldw] lo plane, ldw a multiple of 32 (zero beyond K).
+ * Same row maps, epilogues and argument meaning as onssen_linear_f32; L2NORM `group` must divide 160.
+ */
+int onssen_linear_pack_bf16x3(const float* w, int N, int K, int ld_in, int ld_out, uint16_t* w_planes, void* stream);
+int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, int K, const uint16_t* w_planes,
+                         int ldw, const float* bias, int N, int mode, int group, float eps, const float* resid,
+                         float* C, int64_t c_s0, int64_t c_s1, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3+K4  stacked bidirectional LSTM, eval semantics (zero initial state, no dropout).

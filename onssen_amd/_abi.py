@@ -26,6 +26,8 @@ SIGNATURES = {
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
+    "onssen_linear_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "onssen_linear_bf16x3": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -88,6 +90,15 @@ class Lib:
     def linear(self, A, a_s0, a_s1, R, M, K, W, ldw, bias, N, mode, group, eps, resid, Cp, c_s0, c_s1, stream):
         self.check(self.dll.onssen_linear_f32(A, a_s0, a_s1, R, M, K, W, ldw, bias, N, mode, group, eps, resid, Cp,
                                               c_s0, c_s1, stream), "onssen_linear_f32")
+
+    def linear_pack_bf16x3(self, w, N, K, ld_in, ld_out, planes, stream):
+        self.check(self.dll.onssen_linear_pack_bf16x3(w, N, K, ld_in, ld_out, planes, stream),
+                   "onssen_linear_pack_bf16x3")
+
+    def linear_bf16x3(self, A, a_s0, a_s1, R, M, K, planes, ldw, bias, N, mode, group, eps, resid, Cp, c_s0, c_s1,
+                      stream):
+        self.check(self.dll.onssen_linear_bf16x3(A, a_s0, a_s1, R, M, K, planes, ldw, bias, N, mode, group, eps, resid,
+                                                 Cp, c_s0, c_s1, stream), "onssen_linear_bf16x3")
 
     def blstm_forward(self, x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_ptrs, whh_ptrs, bias_ptrs, y, ws, ws_bytes,
                       flags, stream):

@@ -353,6 +353,224 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
   }
 }
 
+
+// =================================================================================================
+// K3/K7/K8/K9, split-bf16 form:  C = epi(A W^T + bias) with every fp32 product evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+// 256x160x32 tile, 8 waves (4 along M x 2 along N, 64x80 per wave = 4x5 MFMA tiles, 60 MFMAs per k-step).
+// A arrives as fp32 and is split while it is staged into LDS (3 VALU ops per element, hidden behind the
+// MFMAs); W is pre-split at pack time ([N][ldw] hi plane, then lo plane).  Epilogues as linear_kernel;
+// the tile is 160 = 2 x lcm(16,20) columns wide so that a TF bin's 20 embedding outputs never straddle tiles.
+// =================================================================================================
+namespace lx3 {
+constexpr int BM = 256, BN = 160, BK = 32;
+constexpr int LD = 40;                       // LDS row stride in bf16 elements: 32 + 8 pad (80 B rows)
+constexpr int QR = 64, CLD = 164;            // epilogue: 64-row quarters of the C tile, padded stride
+constexpr int STAGE_BYTES = (2 * BM + 2 * BN) * LD * 2;
+constexpr int EPI_BYTES = QR * CLD * 4;
+constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+}  // namespace lx3
+
+struct LinearX3Args {
+  const float* A;
+  long a_s0, a_s1;
+  const unsigned short* Whi;
+  const unsigned short* Wlo;
+  const float* bias;
+  const float* resid;
+  float* C;
+  long c_s0, c_s1;
+  int R, M, N, K, ldw, group;
+  float eps;
+};
+
+__device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) { return (unsigned)a | ((unsigned)b << 16); }
+
+template <bool A_VEC, int MODE>
+__global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
+  using namespace lx3;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __shared__ long c_rowoff[BM];
+  unsigned short* Ahi = reinterpret_cast<unsigned short*>(smem_raw);
+  unsigned short* Alo = Ahi + BM * LD;
+  unsigned short* Bhi = Alo + BM * LD;
+  unsigned short* Blo = Bhi + BN * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+
+  // ---- staging coordinates.  A: 256 rows x 8 float4 per k-step -> 4 per thread; W: 160 rows x 4 x 16 B per plane
+  const int akq = tid & 7;
+  long a_off[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int m = m0 + (tid >> 3) + 64 * it;
+    a_ok[it] = m < p.M;
+    a_off[it] = a_ok[it] ? (long)(m / p.R) * p.a_s0 + (long)(m % p.R) * p.a_s1 : 0;
+  }
+  const int wc = tid & 3;                  // 16-byte chunk within the 64-byte row of a W plane tile
+  long w_off[3];
+  bool w_ok[3];
+  int w_row[3], w_plane[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int idx = (tid >> 2) + 128 * it;          // 0..383: (plane, row)
+    w_plane[it] = idx >= BN;
+    w_row[it] = idx - (w_plane[it] ? BN : 0);
+    w_ok[it] = idx < 2 * BN && (n0 + w_row[it] < p.N);
+    w_off[it] = w_ok[it] ? (long)(n0 + w_row[it]) * p.ldw : 0;
+  }
+
+  float4 ra[4];
+  u32x4 rw[3];
+  auto g_load = [&](int k0) {
+    const int k = k0 + 4 * akq;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_ok[it]) {
+        const float* src = p.A + a_off[it] + k;
+        if (A_VEC) {
+          if (k < p.K) v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k + 0 < p.K) v.x = src[0];
+          if (k + 1 < p.K) v.y = src[1];
+          if (k + 2 < p.K) v.z = src[2];
+          if (k + 3 < p.K) v.w = src[3];
+        }
+      }
+      ra[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      u32x4 u = {0u, 0u, 0u, 0u};
+      if (w_ok[it] && k0 + 8 * wc < p.ldw)
+        u = *reinterpret_cast<const u32x4*>((w_plane[it] ? p.Wlo : p.Whi) + w_off[it] + k0 + 8 * wc);
+      rw[it] = u;
+    }
+  };
+  auto s_store = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = (tid >> 3) + 64 * it;
+      unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
+      split_bf16(ra[it].x, h0, l0);
+      split_bf16(ra[it].y, h1, l1);
+      split_bf16(ra[it].z, h2, l2);
+      split_bf16(ra[it].w, h3, l3);
+      *reinterpret_cast<uint2*>(Ahi + row * LD + 4 * akq) = make_uint2(pack2(h0, h1), pack2(h2, h3));
+      *reinterpret_cast<uint2*>(Alo + row * LD + 4 * akq) = make_uint2(pack2(l0, l1), pack2(l2, l3));
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int idx = (tid >> 2) + 128 * it;
+      if (idx < 2 * BN)
+        *reinterpret_cast<u32x4*>((w_plane[it] ? Blo : Bhi) + w_row[it] * LD + 8 * wc) = rw[it];
+    }
+  };
+
+  f32x4 acc[4][5];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (p.K + BK - 1) / BK;
+  const int fi = lane & 15, fg = lane >> 4;
+  g_load(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    s_store();
+    __syncthreads();
+    if (kb + 1 < nkb) g_load((kb + 1) * BK);     // in flight behind the MFMAs of this step
+    s16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int off = (wm * 64 + mt * 16 + fi) * LD + 8 * fg;
+      ah[mt] = *reinterpret_cast<const s16x8*>(Ahi + off);
+      al[mt] = *reinterpret_cast<const s16x8*>(Alo + off);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      const int off = (wn * 80 + nt * 16 + fi) * LD + 8 * fg;
+      const s16x8 bh = *reinterpret_cast<const s16x8*>(Bhi + off);
+      const s16x8 bl = *reinterpret_cast<const s16x8*>(Blo + off);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[mt][nt] = mfma_bf16(al[mt], bh, acc[mt][nt]);   // small terms first
+        acc[mt][nt] = mfma_bf16(ah[mt], bl, acc[mt][nt]);
+        acc[mt][nt] = mfma_bf16(ah[mt], bh, acc[mt][nt]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue in four 64-row quarters (a full 256x160 fp32 tile would not fit in LDS next to nothing)
+  float* Cs = reinterpret_cast<float*>(smem_raw);
+  if (tid < BM) {
+    const int m = m0 + tid;
+    c_rowoff[tid] = (m < p.M) ? (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1 : -1;
+  }
+  for (int q = 0; q < 4; ++q) {
+    __syncthreads();
+    if (wm == q) {
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const int col = wn * 80 + nt * 16 + fi;
+        const float bv1 = (n0 + col < p.N) ? p.bias[n0 + col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(mt * 16 + 4 * fg + r) * CLD + col] = acc[mt][nt][r] + bv1;
+      }
+    }
+    __syncthreads();
+    if (MODE == ONSSEN_EPI_L2NORM) {
+      if (p.resid) {
+        for (int e = tid; e < QR * BN; e += 512) {
+          const int row = e / BN, col = e % BN;
+          const long off = c_rowoff[q * QR + row];
+          if (off >= 0 && n0 + col < p.N) Cs[row * CLD + col] += p.resid[off + n0 + col];
+        }
+        __syncthreads();
+      }
+      const int ng = BN / p.group, items = QR * ng, sub = tid & 3;
+      for (int it = tid >> 2; it < items; it += 128) {
+        float* v = Cs + (it / ng) * CLD + (it % ng) * p.group;
+        float s = 0.0f;
+        for (int d = sub; d < p.group; d += 4) s += v[d] * v[d];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float den = fmaxf(sqrtf(s), p.eps);
+        for (int d = sub; d < p.group; d += 4) v[d] = v[d] / den;
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < QR * BN; e += 512) {
+      const int row = e / BN, col = e % BN;
+      const long off = c_rowoff[q * QR + row];
+      if (off >= 0 && n0 + col < p.N) {
+        float v = Cs[row * CLD + col];
+        if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        p.C[off + n0 + col] = v;
+      }
+    }
+  }
+}
+
+// fp32 [N][ld_in] (K valid columns) -> split-bf16 planes [N][ld_out] hi, [N][ld_out] lo (zero beyond K)
+__global__ void pack_w_bf16x3_kernel(const float* __restrict__ w, int N, int K, int ld_in, int ld_out,
+                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+  const long total = (long)N * ld_out;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / ld_out), k = (int)(e % ld_out);
+    unsigned short h, l;
+    split_bf16(k < K ? w[(long)n * ld_in + k] : 0.0f, h, l);
+    hi[e] = h;
+    lo[e] = l;
+  }
+}
+
 // =================================================================================================
 // K4: one LSTM time step, both directions
 // =================================================================================================
@@ -932,6 +1150,49 @@ int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, 
   return ONSSEN_OK;
 }
 
+int onssen_linear_pack_bf16x3(const float* w, int N, int K, int ld_in, int ld_out, uint16_t* planes, void* stream) {
+  if (!w || !planes || N <= 0 || K <= 0 || ld_in < K || ld_out < K || (ld_out % 32) != 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const long n = (long)N * ld_out;
+  hipLaunchKernelGGL(pack_w_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, w, N, K, ld_in, ld_out, planes, planes + n);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, int K, const uint16_t* w_planes,
+                         int ldw, const float* bias, int N, int mode, int group, float eps, const float* resid,
+                         float* C, int64_t c_s0, int64_t c_s1, void* stream) {
+  if (!A || !w_planes || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0 || ldw < K) return ONSSEN_E_ARG;
+  if ((ldw % 32) != 0 || !aligned16(w_planes)) return ONSSEN_E_ALIGN;
+  if (mode == ONSSEN_EPI_L2NORM) {
+    if (group <= 0 || (lx3::BN % group) != 0 || (N % group) != 0) return ONSSEN_E_ARG;
+  } else if (resid) {
+    return ONSSEN_E_ARG;
+  }
+  ONSSEN_CLEAR_ERROR();
+  LinearX3Args p;
+  p.A = A; p.a_s0 = (long)a_s0; p.a_s1 = (long)a_s1; p.Whi = w_planes; p.Wlo = w_planes + (size_t)N * ldw;
+  p.bias = bias; p.resid = resid; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
+  p.K = K; p.ldw = ldw; p.group = group; p.eps = eps;
+  const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
+  const dim3 grid((unsigned)ceil_div(N, lx3::BN), (unsigned)ceil_div(M, lx3::BM)), block(512);
+  hipStream_t st = (hipStream_t)stream;
+#define ONSSEN_LINX3(VEC, MODE_) hipLaunchKernelGGL((linear_x3_kernel<VEC, MODE_>), grid, block, 0, st, p)
+  if (mode == ONSSEN_EPI_BIAS) {
+    if (a_vec) ONSSEN_LINX3(true, ONSSEN_EPI_BIAS); else ONSSEN_LINX3(false, ONSSEN_EPI_BIAS);
+  } else if (mode == ONSSEN_EPI_L2NORM) {
+    if (a_vec) ONSSEN_LINX3(true, ONSSEN_EPI_L2NORM); else ONSSEN_LINX3(false, ONSSEN_EPI_L2NORM);
+  } else if (mode == ONSSEN_EPI_SIGMOID) {
+    if (a_vec) ONSSEN_LINX3(true, ONSSEN_EPI_SIGMOID); else ONSSEN_LINX3(false, ONSSEN_EPI_SIGMOID);
+  } else {
+    return ONSSEN_E_ARG;
+  }
+#undef ONSSEN_LINX3
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
@@ -984,7 +1245,12 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;
     const float* yin = ((L - 1 - l) % 2 == 0) ? ybuf : y;
     int rc;
-    if (l == 0) {
+    if (x3) {   // wih_p_host[l]: split-bf16 planes [2][2*NP][ld], ld = K rounded up to 32
+      const int K = l == 0 ? in_dim : 2 * Hp, ld = ceil_div(K, 32) * 32;
+      rc = onssen_linear_bf16x3(l == 0 ? x : yin, l == 0 ? xs_t : (int64_t)B * 2 * Hp, l == 0 ? xs_b : 2 * Hp, B, T * B,
+                                K, (const uint16_t*)wih_p_host[l], ld, bias_p_host[l], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f,
+                                nullptr, G, (int64_t)B * 2 * NP, 2 * NP, stream);
+    } else if (l == 0) {
       const int Kp = ceil_div(in_dim, 4) * 4;
       rc = onssen_linear_f32(x, xs_t, xs_b, B, T * B, in_dim, wih_p_host[0], Kp, bias_p_host[0], 2 * NP,
                              ONSSEN_EPI_BIAS, 0, 0.f, nullptr, G, (int64_t)B * 2 * NP, 2 * NP, stream);

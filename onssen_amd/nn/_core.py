@@ -114,7 +114,7 @@ class _PackedImages:
         dev = flat[0].device
         H, L = p.hidden_size, p.num_layers
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
-        self.wih, self.whh, self.bias, self.whh_x3 = [], [], [], []
+        self.wih, self.whh, self.bias, self.whh_x3, self.wih_x3 = [], [], [], [], []
         _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
         for l in range(L):
@@ -131,7 +131,11 @@ class _PackedImages:
             for d in range(2):
                 w_hh = flat[(2 * l + d) * 4 + 1].detach().contiguous()
                 lib.lstm_pack_whh_bf16x3(w_hh.data_ptr(), H, self.ug, b3[d].data_ptr(), st)
-            self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3)
+            ld = (in_l if l == 0 else 2 * self.Hp)
+            ld = (ld + 31) // 32 * 32
+            a3 = torch.empty(2, 2 * self.NP, ld, device=dev, dtype=torch.int16)     # hi plane, lo plane
+            lib.linear_pack_bf16x3(a.data_ptr(), 2 * self.NP, in_l if l == 0 else 2 * self.Hp, Kp, ld, a3.data_ptr(), st)
+            self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
         self.key = key
         return self
 
@@ -161,6 +165,9 @@ class PackedHead:
         else:
             lib.head_pack(w.data_ptr(), b.data_ptr(), N, self.H, Hp, None, None, None, None, 0.0,
                           self.w.data_ptr(), self.b.data_ptr(), _stream())
+        self.ld3 = (2 * Hp + 31) // 32 * 32
+        self.planes = torch.empty(2, N, self.ld3, device=dev, dtype=torch.int16)
+        lib.linear_pack_bf16x3(self.w.data_ptr(), N, 2 * Hp, 2 * Hp, self.ld3, self.planes.data_ptr(), _stream())
         self.N, self.key = N, key
         return self
 
@@ -201,7 +208,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
-                      [t.data_ptr() for t in pk.wih],
+                      [t.data_ptr() for t in (pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih)],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
     return y
@@ -216,9 +223,13 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
     hd = head.get(Hp)
     out = torch.empty(B, T, hd.N, device=y.device, dtype=torch.float32)
     a_ptr = y.data_ptr() + b_off * 2 * Hp * 4
-    lib.linear(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.w.data_ptr(), 2 * Hp, hd.b.data_ptr(), hd.N,
-               mode, group, eps, resid.data_ptr() if resid is not None else None, out.data_ptr(), hd.N, T * hd.N,
-               _stream())
+    rp = resid.data_ptr() if resid is not None else None
+    if precision() == "bf16x3" and (mode != EPI_L2NORM or 160 % group == 0):
+        lib.linear_bf16x3(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.planes.data_ptr(), hd.ld3, hd.b.data_ptr(),
+                          hd.N, mode, group, eps, rp, out.data_ptr(), hd.N, T * hd.N, _stream())
+    else:
+        lib.linear(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.w.data_ptr(), 2 * Hp, hd.b.data_ptr(), hd.N,
+                   mode, group, eps, rp, out.data_ptr(), hd.N, T * hd.N, _stream())
     return out
 
 

@@ -31,6 +31,8 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct double2 { double x, y; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return {x, y}; }

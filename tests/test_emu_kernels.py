@@ -175,19 +175,56 @@ def test_blstm_split_bf16_recurrence(lib, H, ug, B):
     x = rand(rng, B, T, F)
     Hp, NP, wih, whh, bias = _pack_lstm(lib, sd, "rnn.", F, H, L, ug)
     _, _, we3 = lib.lstm_geometry_x3(H, ug)
-    whh3 = []
+    whh3, wih3 = [], []
     for l in range(L):
         b3 = np.zeros((2, we3), np.uint16)
         for d, sfx in enumerate(("", "_reverse")):
             w_hh = np.ascontiguousarray(sd[f"rnn.weight_hh_l{l}{sfx}"])
             lib.lstm_pack_whh_bf16x3(P(w_hh), H, ug, P(b3[d]), None)
         whh3.append(b3)
+        K = F if l == 0 else 2 * Hp
+        ld = (K + 31) // 32 * 32
+        pl = np.zeros((2, 2 * NP, ld), np.uint16)           # hi plane, lo plane of the [2*NP][K] projection matrix
+        lib.linear_pack_bf16x3(P(wih[l]), 2 * NP, K, wih[l].shape[-1], ld, P(pl), None)
+        wih3.append(pl)
     ws = aligned_f32(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64)
     y = np.full((T, B, 2, Hp), np.nan, np.float32)
-    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh3],
+    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3, None)
     ref = O.blstm_stack(x, sd, "rnn.", L)
     got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
     err = np.abs(got - ref).max()
     assert err < 2e-5, err
     assert np.all(y[:, :, :, H:] == 0)
+
+
+@pytest.mark.parametrize("mode,group,K", [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40),
+                                          (_abi.EPI_L2NORM, 2, 33)])
+def test_linear_split_bf16(lib, mode, group, K):
+    """onssen_linear_bf16x3 (256x160x32 tile): ragged M/N/K, both A load paths, all epilogues."""
+    rng = np.random.default_rng(7)
+    Bb, Tt, N = 3, 91, 180           # M = 273 (2 row blocks), N = 180 (2 column blocks)
+    x = rand(rng, Bb, Tt, K)
+    W = rand(rng, N, K)
+    bias = rand(rng, N)
+    ld = (K + 31) // 32 * 32
+    planes = np.zeros((2, N, ld), np.uint16)
+    lib.linear_pack_bf16x3(P(W), N, K, K, ld, P(planes), None)
+    hi = (planes[0].astype(np.uint32) << 16).view(np.float32)
+    lo = (planes[1].astype(np.uint32) << 16).view(np.float32)
+    assert np.abs(hi[:, :K] + lo[:, :K] - W).max() <= 2 ** -16 * np.abs(W).max() and not planes[:, :, K:].any()
+    resid = rand(rng, Bb, Tt, N) if group == 2 else None
+    out = np.full((Bb, Tt, N), np.nan, np.float32)
+    lib.linear_bf16x3(P(x), K, Tt * K, Bb, Tt * Bb, K, P(planes), ld, P(bias), N, mode, group, 1e-12, P(resid), P(out),
+                      N, Tt * N, None)
+    ref = x.astype(np.float64) @ W.T.astype(np.float64) + bias
+    if mode == _abi.EPI_L2NORM:
+        if resid is not None:
+            ref = ref + resid
+        r = ref.reshape(Bb, Tt, N // group, group)
+        ref = (r / np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), 1e-12)).reshape(Bb, Tt, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = 1 / (1 + np.exp(-ref))
+    assert not np.isnan(out).any()
+    # |x|,|w| ~ N(0,1): ~1e-5 relative of sqrt(K)-sized sums; normalising a short 2-vector amplifies it
+    np.testing.assert_allclose(out, ref, atol=2e-3 if group == 2 else 3e-4, rtol=1e-4)

@@ -71,6 +71,34 @@ def test_linear_kernel(dev, M, K, N, mode, group):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,K,N,mode,group", [(1000, 1200, 2580, _abi.EPI_L2NORM, 20), (333, 129, 4800, _abi.EPI_BIAS, 0),
+                                              (257, 1200, 258, _abi.EPI_SIGMOID, 0), (12800, 1200, 4800, _abi.EPI_BIAS, 0)])
+def test_linear_split_bf16_kernel(dev, M, K, N, mode, group):
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    ld = (K + 31) // 32 * 32
+    planes = torch.empty(2, N, ld, device=dev, dtype=torch.int16)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.linear_pack_bf16x3(Wd.data_ptr(), N, K, K, ld, planes.data_ptr(), st)
+    out = torch.full((M, N), float("nan"), device=dev)
+    lib.linear_bf16x3(Ad.data_ptr(), K, 0, 1, M, K, planes.data_ptr(), ld, bd.data_ptr(), N, mode, group, 1e-12, None,
+                      out.data_ptr(), N, 0, st)
+    ref = A.double() @ W.double().T + bias.double()
+    if mode == _abi.EPI_L2NORM:
+        r = ref.view(M, N // group, group)
+        ref = (r / r.norm(dim=-1, keepdim=True).clamp_min(1e-12)).view(M, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = torch.sigmoid(ref)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"split-bf16 GEMM M={M} K={K} N={N} mode={mode}: max abs err {err:.3e}")
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-5, rtol=1e-4)
+
+
 # ---------------------------------------------------------------- golden vectors of the reference
 @pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
 def test_dc_tiny_golden(dev, golden_dir, name):
@@ -124,10 +152,11 @@ def test_full_size_golden_subsample(dev, golden_dir, tag, kind):
         np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg3_chimera_L4", "chimera")])
+@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg1_dc_L3", "deep_clustering"),
+                                      ("cfg3_chimera_L4", "chimera")])
 def test_split_bf16_mode_meets_parity_budget(dev, golden_dir, monkeypatch, tag, kind):
-    """ONSSEN_PRECISION=bf16x3 (3 bf16 MFMAs per fp32 product in the recurrence): same reference
-    vectors, same tolerances as the exact-fp32 path."""
+    """ONSSEN_PRECISION=bf16x3 (3 bf16 MFMAs per fp32 product in every contraction: input projections,
+    recurrence, heads): same reference vectors, same tolerances as the exact-fp32 path."""
     monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
     z = np.load(f"{golden_dir}/g2_{tag}.npz")
     m, _ = build(kind, z, dev)
