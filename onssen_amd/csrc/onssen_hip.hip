@@ -580,7 +580,8 @@ struct StepArgs {
   float* y;          // [T][B][2][Hp]   layer output (h_t)
   float* c;          // [2][B][Hp]      cell state
   const unsigned short* whh_x3;  // split-bf16 image [2][NU][KQ2][NT][2][64][8]          (X3 kernels)
-  unsigned short* hs;            // split h hand-off [2 slots][B][2 dirs][hi|lo][Hs] bf16   (X3 kernels)
+  unsigned short* hs;            // split h hand-off in A-fragment order:
+                                 //   [2 slots][2 dirs][ceil(B/16)][KQ2][hi|lo][64 lanes][8] bf16   (X3 kernels)
   int KQ2, Hs;                   // 32-wide k-chunks, padded row length Hs = 32*KQ2
   int B, T, Hp, NP, KQ, NU, step;
   long long* dbg;  // profiling only: per-step timestamps of workgroup (0,0,0), or null
@@ -667,11 +668,15 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
       // split-bf16 form: A = (h_hi, h_lo) written by the previous step's epilogue, B = (W_hi, W_lo)
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.whh_x3 + (long)(dir * p.NU + ugi) * p.KQ2 * NT * 1024), 0, p.KQ2 * NT * 2048, 0x00020000);
+      // the hand-off image is stored in A-fragment order, so each of these loads is one contiguous KiB per wave
+      // (a row-major image costs 16 half-used cache lines per load and was the slowest fetch of the step)
+      const int nmt = (p.B + 15) >> 4;
+      const long hdir = (long)nmt * p.KQ2 * 1024;                     // uint16 elements per (slot, direction)
       const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.hs + (long)((p.step - 1) & 1) * p.B * 4 * p.Hs), 0, p.B * 4 * p.Hs * 2, 0x00020000);
+          (void*)(p.hs + ((long)((p.step - 1) & 1) * 2 + dir) * hdir), 0, (int)(hdir * 2), 0x00020000);
       const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 2048 + lane * 16);
-      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 + fi) * 2 + dir) * 2 * p.Hs + 32 * wave + 8 * fg) * 2);
-      const unsigned h_mt = 16 * 4 * p.Hs * 2, h_hl = p.Hs * 2;
+      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 >> 4) * p.KQ2 + wave) * 2048) + lane * 16);
+      const unsigned h_mt = p.KQ2 * 2048, h_hl = 1024;
       for (int qb = 0; qb < p.KQ2; qb += 4 * QB3) {
         u32x4 a[QB3][MT][2], w[QB3][NT][2];
 #pragma unroll
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl)
-              a[i][mt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + hl * h_hl + (qb + 4 * i) * 64, 0, 0);
+              a[i][mt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + hl * h_hl + (qb + 4 * i) * 2048, 0, 0);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -796,9 +801,11 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
       if constexpr (X3) {   // hand h_t to the next step already split (3 VALU ops here vs hundreds in the consumer)
         unsigned short hi, lo;
         split_bf16(h, hi, lo);
-        unsigned short* dst = p.hs + ((long)(p.step & 1) * p.B * 4 + (long)(b * 2 + dir) * 2) * p.Hs + ugi * UG + ju;
+        const int k = ugi * UG + ju, nmt = (p.B + 15) >> 4;
+        unsigned short* dst = p.hs + ((((long)(p.step & 1) * 2 + dir) * nmt + (b >> 4)) * p.KQ2 + (k >> 5)) * 1024 +
+                              ((b & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
         dst[0] = hi;
-        dst[p.Hs] = lo;
+        dst[512] = lo;
       }
       p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] = cn;
       p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
@@ -1201,7 +1208,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
-  const size_t hs = align256((size_t)2 * B * 4 * (32 * ceil_div(Hp, 32)) * sizeof(uint16_t));   // split-bf16 h hand-off
+  const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 1024 * sizeof(uint16_t));   // split-bf16 h hand-off
   return 512 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 512 B reserved; trailing 64 KiB profiling area
 }
 
@@ -1233,10 +1240,11 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
   if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
   uint16_t* hsb = (uint16_t*)wsp;
-  wsp += align256((size_t)2 * B * 4 * Hs * sizeof(uint16_t));
+  const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 16) * KQ2 * 1024 * sizeof(uint16_t);
+  wsp += align256(hs_bytes);
   long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)wsp : nullptr;
-  if (x3) {   // the K padding [Hp, Hs) of the hand-off rows is never written by the kernels: keep it zero
-    hipError_t e = hipMemsetAsync(hsb, 0, (size_t)2 * B * 4 * Hs * sizeof(uint16_t), st);
+  if (x3) {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
+    hipError_t e = hipMemsetAsync(hsb, 0, hs_bytes, st);
     if (e != hipSuccess) return (int)e;
   }
   const int mt = (B > 16 && !(flags & ONSSEN_BLSTM_SPLIT_ROWS)) ? 2 : 1;

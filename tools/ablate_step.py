@@ -58,7 +58,7 @@ for ug in (8, 12, 16):
     x3 = []
     for ab in (0, 3, 4):
         def layer3():
-            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih[1].data_ptr()],
+            lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih_x3[1].data_ptr()],
                               [pk.whh_x3[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
                               ws.numel(), (ab << 8) | 2, _stream())
         x3.append((timed(layer3) - tg) / T * 1e6)
