@@ -422,9 +422,11 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
     w_off[it] = w_ok[it] ? (long)(n0 + w_row[it]) * p.ldw : 0;
   }
 
-  float4 ra[4];
-  u32x4 rw[3];
-  auto g_load = [&](int k0) {
+  // two register sets: tile kb+2 is requested while tile kb is being multiplied, so a global load has two
+  // k-steps (~2 x 60 MFMAs per wave) to land before it is split into LDS
+  float4 ra0[4], ra1[4];
+  u32x4 rw0[3], rw1[3];
+  auto g_load = [&](float4 (&ra)[4], u32x4 (&rw)[3], int k0) {
     const int k = k0 + 4 * akq;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
       rw[it] = u;
     }
   };
-  auto s_store = [&]() {
+  auto s_store = [&](const float4 (&ra)[4], const u32x4 (&rw)[3]) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = (tid >> 3) + 64 * it;
@@ -478,11 +480,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
 
   const int nkb = (p.K + BK - 1) / BK;
   const int fi = lane & 15, fg = lane >> 4;
-  g_load(0);
-  for (int kb = 0; kb < nkb; ++kb) {
-    s_store();
-    __syncthreads();
-    if (kb + 1 < nkb) g_load((kb + 1) * BK);     // in flight behind the MFMAs of this step
+  auto compute = [&]() {
     s16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -502,7 +500,22 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
         acc[mt][nt] = mfma_bf16(ah[mt], bh, acc[mt][nt]);
       }
     }
+  };
+  g_load(ra0, rw0, 0);
+  if (nkb > 1) g_load(ra1, rw1, BK);
+  for (int kb = 0; kb < nkb; kb += 2) {
+    s_store(ra0, rw0);
     __syncthreads();
+    if (kb + 2 < nkb) g_load(ra0, rw0, (kb + 2) * BK);
+    compute();
+    __syncthreads();
+    if (kb + 1 < nkb) {
+      s_store(ra1, rw1);
+      __syncthreads();
+      if (kb + 3 < nkb) g_load(ra1, rw1, (kb + 3) * BK);
+      compute();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue in four 64-row quarters (a full 256x160 fp32 tile would not fit in LDS next to nothing)
