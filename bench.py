@@ -40,6 +40,7 @@ CONFIGS = {
     "dc_l2": ("deep_clustering", 600, 2, 32),   # BASELINE.json configs[1] -- the headline workload
     "dc_l3": ("deep_clustering", 600, 3, 16),   # as-shipped egs/wsj0-2mix/deep_clustering/config.json
     "chimera_l4": ("chimera", 600, 4, 64),      # BASELINE.json configs[2]
+    "phase_l4": ("phase_net", 600, 4, 32),      # BASELINE.json configs[4]: 16 kHz STFT 512/128, 1 s chunks
 }
 
 
@@ -91,9 +92,13 @@ def main():
     kind, H, L, B = CONFIGS[args.config]
     if args.batch:
         B = args.batch
+    global SR, NFFT, HOP, T_FRAMES, N_SAMPLES
+    if kind == "phase_net":
+        SR, NFFT, HOP, N_SAMPLES = 16000, 512, 128, 16000
+        T_FRAMES = 1 + N_SAMPLES // HOP
     F, D = NFFT // 2 + 1, 20
     sd = make_state_dict(kind, F, H, L, D, 2, seed=0)
-    cls = onn.deep_clustering if kind == "deep_clustering" else onn.chimera
+    cls = {"deep_clustering": onn.deep_clustering, "chimera": onn.chimera, "phase_net": onn.phase_net}[kind]
     model = cls(F, H, L, D)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.to(dev).eval()
@@ -108,7 +113,10 @@ def main():
 
     def step():
         logmag, ri = stft_logmag(wav, NFFT, HOP)
-        if kind == "chimera":
+        if kind == "phase_net":
+            emb, mA, mB, pA, pB = model([logmag, ri])
+            sig = mask_istft(ri, mA._base.view(B, T_FRAMES, F, 2), HOP, N_SAMPLES)
+        elif kind == "chimera":
             emb, masks = model.embedding_and_masks(logmag)
             sig = mask_istft(ri, masks, HOP, N_SAMPLES)
         else:
@@ -151,7 +159,8 @@ def main():
             elapsed = float(te.item())
 
         # ---- per-kernel timing leg (HIP events on the launch stream), outside the timed region
-        roof = kernel_roofline(model, wav, dev, kind, F, H, L, B, D) if rank == 0 else None
+        roof = (kernel_roofline(model.chimera if kind == "phase_net" else model, wav, dev,
+                                "chimera" if kind == "phase_net" else kind, F, H, L, B, D) if rank == 0 else None)
 
     ms_per_step = 1e3 * elapsed / args.steps
     frames = B * T_FRAMES * world * args.steps
@@ -174,10 +183,11 @@ def main():
     }
     if rank == 0:
         result["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kind != "phase_net":
             result["cpu_baseline"] = cpu_baseline(sd, kind, wav_np, bin_masks.cpu().numpy())
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()   # rank 0 finishes its per-kernel timing leg before anyone tears the group down
         dist.destroy_process_group()
 
 

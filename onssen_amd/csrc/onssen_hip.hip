@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/onssen_hip.h"
 
@@ -363,12 +364,12 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
 // the tile is 160 = 2 x lcm(16,20) columns wide so that a TF bin's 20 embedding outputs never straddle tiles.
 // =================================================================================================
 namespace lx3 {
-constexpr int BM = 256, BN = 160, BK = 32;
+constexpr int BN = 160, BK = 32;
 constexpr int LD = 40;                       // LDS row stride in bf16 elements: 32 + 8 pad (80 B rows)
-constexpr int QR = 64, CLD = 164;            // epilogue: 64-row quarters of the C tile, padded stride
-constexpr int STAGE_BYTES = (2 * BM + 2 * BN) * LD * 2;
+constexpr int QR = 64, CLD = 164;            // epilogue: 64-row slices of the C tile, padded stride
 constexpr int EPI_BYTES = QR * CLD * 4;
-constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+constexpr int stage_bytes(int bm) { return (2 * bm + 2 * BN) * LD * 2; }
+constexpr int smem_bytes(int bm) { return stage_bytes(bm) > EPI_BYTES ? stage_bytes(bm) : EPI_BYTES; }
 }  // namespace lx3
 
 struct LinearX3Args {
@@ -386,10 +387,15 @@ struct LinearX3Args {
 
 __device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) { return (unsigned)a | ((unsigned)b << 16); }
 
-template <bool A_VEC, int MODE>
-__global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
+// WM = waves along M (64 rows each): WM=4 -> 256x160 tile, 512 threads, one workgroup per CU; WM=2 -> 128x160
+// tile, 256 threads, 46 KB of LDS: three workgroups per CU sit in different phases, so one's MFMAs cover
+// another's staging without any intra-workgroup choreography.
+template <bool A_VEC, int MODE, int WM>
+__global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
   using namespace lx3;
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  constexpr int BM = 64 * WM, NTHR = 128 * WM;
+  constexpr int WIT = (2 * BN * 4 + NTHR - 1) / NTHR;      // 16-byte W chunks per thread per k-step
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[smem_bytes(BM)];
   __shared__ long c_rowoff[BM];
   unsigned short* Ahi = reinterpret_cast<unsigned short*>(smem_raw);
   unsigned short* Alo = Ahi + BM * LD;
@@ -397,7 +403,16 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
   unsigned short* Blo = Bhi + BN * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  // XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (speed only, never correctness), so give
+  // every XCD a contiguous run of tiles -- neighbours then share their A row panel in that XCD's private L2
+  int n0, m0;
+  {
+    const int nbx = gridDim.x, nwg = nbx * gridDim.y, bid = blockIdx.y * nbx + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    n0 = (wg % nbx) * BN;
+    m0 = (wg / nbx) * BM;
+  }
 
   // ---- staging coordinates.  A: 256 rows x 8 float4 per k-step -> 4 per thread; W: 160 rows x 4 x 16 B per plane
   const int akq = tid & 7;
@@ -405,17 +420,17 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
   bool a_ok[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int m = m0 + (tid >> 3) + 64 * it;
+    const int m = m0 + (tid >> 3) + (NTHR / 8) * it;
     a_ok[it] = m < p.M;
     a_off[it] = a_ok[it] ? (long)(m / p.R) * p.a_s0 + (long)(m % p.R) * p.a_s1 : 0;
   }
   const int wc = tid & 3;                  // 16-byte chunk within the 64-byte row of a W plane tile
-  long w_off[3];
-  bool w_ok[3];
-  int w_row[3], w_plane[3];
+  long w_off[WIT];
+  bool w_ok[WIT];
+  int w_row[WIT], w_plane[WIT];
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
-    const int idx = (tid >> 2) + 128 * it;          // 0..383: (plane, row)
+  for (int it = 0; it < WIT; ++it) {
+    const int idx = (tid >> 2) + (NTHR / 4) * it;   // (plane, row)
     w_plane[it] = idx >= BN;
     w_row[it] = idx - (w_plane[it] ? BN : 0);
     w_ok[it] = idx < 2 * BN && (n0 + w_row[it] < p.N);
@@ -425,8 +440,8 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
   // two register sets: tile kb+2 is requested while tile kb is being multiplied, so a global load has two
   // k-steps (~2 x 60 MFMAs per wave) to land before it is split into LDS
   float4 ra0[4], ra1[4];
-  u32x4 rw0[3], rw1[3];
-  auto g_load = [&](float4 (&ra)[4], u32x4 (&rw)[3], int k0) {
+  u32x4 rw0[WIT], rw1[WIT];
+  auto g_load = [&](float4 (&ra)[4], u32x4 (&rw)[WIT], int k0) {
     const int k = k0 + 4 * akq;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -445,17 +460,17 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
       ra[it] = v;
     }
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < WIT; ++it) {
       u32x4 u = {0u, 0u, 0u, 0u};
       if (w_ok[it] && k0 + 8 * wc < p.ldw)
         u = *reinterpret_cast<const u32x4*>((w_plane[it] ? p.Wlo : p.Whi) + w_off[it] + k0 + 8 * wc);
       rw[it] = u;
     }
   };
-  auto s_store = [&](const float4 (&ra)[4], const u32x4 (&rw)[3]) {
+  auto s_store = [&](const float4 (&ra)[4], const u32x4 (&rw)[WIT]) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      const int row = (tid >> 3) + 64 * it;
+      const int row = (tid >> 3) + (NTHR / 8) * it;
       unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
       split_bf16(ra[it].x, h0, l0);
       split_bf16(ra[it].y, h1, l1);
@@ -465,8 +480,8 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
       *reinterpret_cast<uint2*>(Alo + row * LD + 4 * akq) = make_uint2(pack2(l0, l1), pack2(l2, l3));
     }
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int idx = (tid >> 2) + 128 * it;
+    for (int it = 0; it < WIT; ++it) {
+      const int idx = (tid >> 2) + (NTHR / 4) * it;
       if (idx < 2 * BN)
         *reinterpret_cast<u32x4*>((w_plane[it] ? Blo : Bhi) + w_row[it] * LD + 8 * wc) = rw[it];
     }
@@ -502,17 +517,27 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
     }
   };
   g_load(ra0, rw0, 0);
-  if (nkb > 1) g_load(ra1, rw1, BK);
-  for (int kb = 0; kb < nkb; kb += 2) {
-    s_store(ra0, rw0);
-    __syncthreads();
-    if (kb + 2 < nkb) g_load(ra0, rw0, (kb + 2) * BK);
-    compute();
-    __syncthreads();
-    if (kb + 1 < nkb) {
-      s_store(ra1, rw1);
+  if constexpr (WM == 4) {          // one fat workgroup per CU: prefetch two k-steps ahead
+    if (nkb > 1) g_load(ra1, rw1, BK);
+    for (int kb = 0; kb < nkb; kb += 2) {
+      s_store(ra0, rw0);
       __syncthreads();
-      if (kb + 3 < nkb) g_load(ra1, rw1, (kb + 3) * BK);
+      if (kb + 2 < nkb) g_load(ra0, rw0, (kb + 2) * BK);
+      compute();
+      __syncthreads();
+      if (kb + 1 < nkb) {
+        s_store(ra1, rw1);
+        __syncthreads();
+        if (kb + 3 < nkb) g_load(ra1, rw1, (kb + 3) * BK);
+        compute();
+        __syncthreads();
+      }
+    }
+  } else {                          // several workgroups per CU hide each other's latencies: one register set
+    for (int kb = 0; kb < nkb; ++kb) {
+      s_store(ra0, rw0);
+      __syncthreads();
+      if (kb + 1 < nkb) g_load(ra0, rw0, (kb + 1) * BK);
       compute();
       __syncthreads();
     }
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
     const int m = m0 + tid;
     c_rowoff[tid] = (m < p.M) ? (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1 : -1;
   }
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < WM; ++q) {
     __syncthreads();
     if (wm == q) {
 #pragma unroll
@@ -540,7 +565,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
     __syncthreads();
     if (MODE == ONSSEN_EPI_L2NORM) {
       if (p.resid) {
-        for (int e = tid; e < QR * BN; e += 512) {
+        for (int e = tid; e < QR * BN; e += NTHR) {
           const int row = e / BN, col = e % BN;
           const long off = c_rowoff[q * QR + row];
           if (off >= 0 && n0 + col < p.N) Cs[row * CLD + col] += p.resid[off + n0 + col];
@@ -548,7 +573,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
         __syncthreads();
       }
       const int ng = BN / p.group, items = QR * ng, sub = tid & 3;
-      for (int it = tid >> 2; it < items; it += 128) {
+      for (int it = tid >> 2; it < items; it += NTHR / 4) {
         float* v = Cs + (it / ng) * CLD + (it % ng) * p.group;
         float s = 0.0f;
         for (int d = sub; d < p.group; d += 4) s += v[d] * v[d];
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(512) void linear_x3_kernel(LinearX3Args p) {
       }
       __syncthreads();
     }
-    for (int e = tid; e < QR * BN; e += 512) {
+    for (int e = tid; e < QR * BN; e += NTHR) {
       const int row = e / BN, col = e % BN;
       const long off = c_rowoff[q * QR + row];
       if (off >= 0 && n0 + col < p.N) {
@@ -1196,9 +1221,16 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
   p.bias = bias; p.resid = resid; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.K = K; p.ldw = ldw; p.group = group; p.eps = eps;
   const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
-  const dim3 grid((unsigned)ceil_div(N, lx3::BN), (unsigned)ceil_div(M, lx3::BM)), block(512);
+  // tile height: 128 rows x 3 co-resident workgroups per CU, or 256 rows x 1 (ONSSEN_X3_WM=2|4 overrides)
+  static const int wm_env = getenv("ONSSEN_X3_WM") ? atoi(getenv("ONSSEN_X3_WM")) : 0;
+  const int wmv = wm_env == 4 ? 4 : (wm_env == 2 ? 2 : 2);
+  const dim3 grid((unsigned)ceil_div(N, lx3::BN), (unsigned)ceil_div(M, 64 * wmv)), block(128 * wmv);
   hipStream_t st = (hipStream_t)stream;
-#define ONSSEN_LINX3(VEC, MODE_) hipLaunchKernelGGL((linear_x3_kernel<VEC, MODE_>), grid, block, 0, st, p)
+#define ONSSEN_LINX3(VEC, MODE_)                                                              \
+  do {                                                                                        \
+    if (wmv == 4) hipLaunchKernelGGL((linear_x3_kernel<VEC, MODE_, 4>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((linear_x3_kernel<VEC, MODE_, 2>), grid, block, 0, st, p);          \
+  } while (0)
   if (mode == ONSSEN_EPI_BIAS) {
     if (a_vec) ONSSEN_LINX3(true, ONSSEN_EPI_BIAS); else ONSSEN_LINX3(false, ONSSEN_EPI_BIAS);
   } else if (mode == ONSSEN_EPI_L2NORM) {
