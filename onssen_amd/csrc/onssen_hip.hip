@@ -751,21 +751,22 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
     } else {
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256), 0, p.KQ * NT * 1024, 0x00020000);
+      // fp32 hand-off image in A-fragment order (same reason as the split-bf16 form): [slot][dir][m-tile][q][lane][4]
+      const int nmt = (p.B + 15) >> 4;
+      const long hdir = (long)nmt * p.KQ * 256;                       // floats per (slot, direction)
       const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.y + (long)tprev * p.B * 2 * p.Hp), 0, p.B * 2 * p.Hp * 4, 0x00020000);
+          (void*)(reinterpret_cast<float*>(p.hs) + ((long)((p.step - 1) & 1) * 2 + dir) * hdir), 0, (int)(hdir * 4),
+          0x00020000);
       const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 1024 + lane * 16);
-      const unsigned hv0 = (unsigned)((((b0 + fi) * 2 + dir) * p.Hp + 16 * wave + 4 * fg) * 4);
-      const unsigned h_mt = 16 * 2 * p.Hp * 4;
-      const int k0 = 16 * wave + 4 * fg;   // this lane's k within chunk q = wave (+16 per 4 chunks ... +64 per i)
+      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 >> 4) * p.KQ + wave) * 1024) + lane * 16);
+      const unsigned h_mt = p.KQ * 1024;
       for (int qb = 0; qb < p.KQ; qb += 4 * QB) {
         u32x4 a[QB][MT], w[QB][NT];
 #pragma unroll
         for (int i = 0; i < QB; ++i) {
-          // the K tail of a row must read as zero (what follows in memory belongs to the other direction)
-          const unsigned hv = ((p.ablate & 1) || k0 + 16 * (qb + 4 * i) >= p.Hp) ? kOOB : hv0;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            a[i][mt] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + (qb + 4 * i) * 64, 0, 0);
+            a[i][mt] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + (qb + 4 * i) * 1024, 0, 0);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             w[i][nt] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + nt * 1024 + (qb + 4 * i) * NT * 1024, 0, 0);
@@ -844,6 +845,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
                               ((b & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
         dst[0] = hi;
         dst[512] = lo;
+      } else {
+        const int k = ugi * UG + ju, nmt = (p.B + 15) >> 4;
+        reinterpret_cast<float*>(p.hs)[((((long)(p.step & 1) * 2 + dir) * nmt + (b >> 4)) * p.KQ + (k >> 4)) * 256 +
+                                       ((b & 15) + 16 * ((k >> 2) & 3)) * 4 + (k & 3)] = h;
       }
       p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] = cn;
       p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
@@ -1253,7 +1258,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
-  const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 1024 * sizeof(uint16_t));   // split-bf16 h hand-off
+  const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
   return 512 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 512 B reserved; trailing 64 KiB profiling area
 }
 
@@ -1285,10 +1290,10 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
   if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
   uint16_t* hsb = (uint16_t*)wsp;
-  const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 16) * KQ2 * 1024 * sizeof(uint16_t);
+  const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 16) * KQ2 * 2048;   // split-bf16 image; >= the fp32 image (2*KQ2 >= KQ)
   wsp += align256(hs_bytes);
   long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)wsp : nullptr;
-  if (x3) {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
+  {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
     hipError_t e = hipMemsetAsync(hsb, 0, hs_bytes, st);
     if (e != hipSuccess) return (int)e;
   }
