@@ -383,6 +383,8 @@ struct LinearX3Args {
   long c_s0, c_s1;
   int R, M, N, K, ldw, group;
   float eps;
+  int c_vec;    // C rows 16-byte aligned and N % 4 == 0
+  int ablate;   // profiling only (ONSSEN_X3_ABLATE): 1 no global loads, 2 no split/LDS store, 4 no MFMA, 8 no fragment reads
 };
 
 __device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) { return (unsigned)a | ((unsigned)b << 16); }
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
   float4 ra0[4], ra1[4];
   u32x4 rw0[WIT], rw1[WIT];
   auto g_load = [&](float4 (&ra)[4], u32x4 (&rw)[WIT], int k0) {
+    if (p.ablate & 1) return;
     const int k = k0 + 4 * akq;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
     }
   };
   auto s_store = [&](const float4 (&ra)[4], const u32x4 (&rw)[WIT]) {
+    if (p.ablate & 2) return;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = (tid >> 3) + (NTHR / 8) * it;
@@ -497,17 +501,22 @@ __global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
   const int fi = lane & 15, fg = lane >> 4;
   auto compute = [&]() {
     s16x8 ah[4], al[4];
+    const int fsel = (p.ablate & 8) ? 0 : 1;     // profiling: all fragments from one LDS address
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int off = (wm * 64 + mt * 16 + fi) * LD + 8 * fg;
+      const int off = fsel * ((wm * 64 + mt * 16 + fi) * LD + 8 * fg);
       ah[mt] = *reinterpret_cast<const s16x8*>(Ahi + off);
       al[mt] = *reinterpret_cast<const s16x8*>(Alo + off);
     }
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) {
-      const int off = (wn * 80 + nt * 16 + fi) * LD + 8 * fg;
+      const int off = fsel * ((wn * 80 + nt * 16 + fi) * LD + 8 * fg);
       const s16x8 bh = *reinterpret_cast<const s16x8*>(Bhi + off);
       const s16x8 bl = *reinterpret_cast<const s16x8*>(Blo + off);
+      if (p.ablate & 4) {
+        acc[0][nt][0] += (float)(bh[0] + bl[0] + ah[0][0] + al[0][0]);   // keep the reads live
+        continue;
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         acc[mt][nt] = mfma_bf16(al[mt], bh, acc[mt][nt]);   // small terms first
@@ -584,13 +593,28 @@ __global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
       }
       __syncthreads();
     }
-    for (int e = tid; e < QR * BN; e += NTHR) {
-      const int row = e / BN, col = e % BN;
-      const long off = c_rowoff[q * QR + row];
-      if (off >= 0 && n0 + col < p.N) {
-        float v = Cs[row * CLD + col];
-        if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-        p.C[off + n0 + col] = v;
+    if (p.c_vec) {   // rows 16-byte aligned and N % 4 == 0: 16-byte stores, a quarter of the store instructions
+      for (int e = tid; e < QR * (BN / 4); e += NTHR) {
+        const int row = e / (BN / 4), col = 4 * (e % (BN / 4));
+        const long off = c_rowoff[q * QR + row];
+        if (off >= 0 && n0 + col < p.N) {
+          float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + col);
+          if (MODE == ONSSEN_EPI_SIGMOID) {
+            v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+            v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+          }
+          *reinterpret_cast<float4*>(p.C + off + n0 + col) = v;
+        }
+      }
+    } else {
+      for (int e = tid; e < QR * BN; e += NTHR) {
+        const int row = e / BN, col = e % BN;
+        const long off = c_rowoff[q * QR + row];
+        if (off >= 0 && n0 + col < p.N) {
+          float v = Cs[row * CLD + col];
+          if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+          p.C[off + n0 + col] = v;
+        }
       }
     }
   }
@@ -1225,10 +1249,13 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
   p.A = A; p.a_s0 = (long)a_s0; p.a_s1 = (long)a_s1; p.Whi = w_planes; p.Wlo = w_planes + (size_t)N * ldw;
   p.bias = bias; p.resid = resid; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.K = K; p.ldw = ldw; p.group = group; p.eps = eps;
+  static const int x3_ablate = getenv("ONSSEN_X3_ABLATE") ? atoi(getenv("ONSSEN_X3_ABLATE")) : 0;
+  p.ablate = x3_ablate;
+  p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
-  // tile height: 128 rows x 3 co-resident workgroups per CU, or 256 rows x 1 (ONSSEN_X3_WM=2|4 overrides)
+  // tile height: 256 rows x 1 workgroup per CU (default), or 128 rows x 2 co-resident (ONSSEN_X3_WM=2)
   static const int wm_env = getenv("ONSSEN_X3_WM") ? atoi(getenv("ONSSEN_X3_WM")) : 0;
-  const int wmv = wm_env == 4 ? 4 : (wm_env == 2 ? 2 : 2);
+  const int wmv = wm_env == 2 ? 2 : 4;   // measured: the 256-row tile re-reads W half as often and wins end to end
   const dim3 grid((unsigned)ceil_div(N, lx3::BN), (unsigned)ceil_div(M, 64 * wmv)), block(128 * wmv);
   hipStream_t st = (hipStream_t)stream;
 #define ONSSEN_LINX3(VEC, MODE_)                                                              \
