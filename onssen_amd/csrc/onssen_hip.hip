@@ -384,6 +384,7 @@ struct LinearX3Args {
   int R, M, N, K, ldw, group;
   float eps;
   int c_vec;    // C rows 16-byte aligned and N % 4 == 0
+  int tile_group;  // N-tiles walked together (L2 blocking)
   int ablate;   // profiling only (ONSSEN_X3_ABLATE): 1 no global loads, 2 no split/LDS store, 4 no MFMA, 8 no fragment reads
 };
 
@@ -412,8 +413,22 @@ __global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
     const int nbx = gridDim.x, nwg = nbx * gridDim.y, bid = blockIdx.y * nbx + blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    n0 = (wg % nbx) * BN;
-    m0 = (wg / nbx) * BM;
+    // ... and walk the tiles in column groups of GN: the group's W panels (GN x ~0.8 MB split-bf16 at K=1200)
+    // stay resident in the XCD's 4 MB L2 while the row panels of A stream past them
+    const int GN = p.tile_group, nby = gridDim.y;
+    const int gfull = nbx / GN, nfull = gfull * GN * nby;
+    int tn, tm;
+    if (wg < nfull) {
+      const int rem = wg % (nby * GN);
+      tn = (wg / (nby * GN)) * GN + rem % GN;
+      tm = rem / GN;
+    } else {
+      const int gl = nbx - gfull * GN, rem = wg - nfull;
+      tn = gfull * GN + rem % gl;
+      tm = rem / gl;
+    }
+    n0 = tn * BN;
+    m0 = tm * BM;
   }
 
   // ---- staging coordinates.  A: 256 rows x 8 float4 per k-step -> 4 per thread; W: 160 rows x 4 x 16 B per plane
@@ -1251,6 +1266,8 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
   p.K = K; p.ldw = ldw; p.group = group; p.eps = eps;
   static const int x3_ablate = getenv("ONSSEN_X3_ABLATE") ? atoi(getenv("ONSSEN_X3_ABLATE")) : 0;
   p.ablate = x3_ablate;
+  static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
+  p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
   // tile height: 256 rows x 1 workgroup per CU (default), or 128 rows x 2 co-resident (ONSSEN_X3_WM=2)
