@@ -154,6 +154,31 @@ int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, 
                            int64_t m_sf, const float* x_phase, int B, int C, int T, int F, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N3  training-label features of a chunk from the complex STFTs of mixture and sources ((B,T,F,2) float32 each,
+ * as written by onssen_stft_logmag_f32) and the mixture's log-magnitude (B,T,F).
+ * Replaces get_one_hot / get_cos_difference / np.abs in onssen/data/feature_utils.py:77-95 and
+ * onssen/data/wsj0_2mix.py:130-152:
+ *   one_hot (B,T,F,2) float32: e_argmax(|s1|,|s2|) (speaker 0 on ties), all-zero where
+ *           feature < max_over_the_chunk(feature) - db_threshold/20;   utt_max (B) scratch
+ *   mag_mix, mag_s1, mag_s2 (B,T,F);  cos_s1, cos_s2 (B,T,F) = cos(angle(mix) - angle(s)), both NULL to skip
+ */
+int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* stft_s2, const float* feature_mix, int B,
+                      int T, int F, float db_threshold, float* utt_max, float* one_hot, float* mag_mix, float* mag_s1,
+                      float* mag_s2, float* cos_s1, float* cos_s2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * N2  deep-clustering back end: per utterance, 2-means over the D-dimensional embeddings of the bins with
+ * feature >= max(feature) - db_threshold/20, then binary masks (B,T,F,2): mask[...,0] = label, mask[...,1] =
+ * 1 - label on active bins, 0 in both on silent bins.
+ * Replaces `KMeans(n_clusters=2, random_state=0).fit_predict(emb)` + the mask fill at
+ * egs/wsj0-2mix/deep_clustering/evaluate.py:36-41 (sklearn on the host upstream).  Deterministic farthest-point
+ * initialisation and `iters` Lloyd iterations; cluster numbering is arbitrary, as it is upstream.  D <= 32.
+ */
+size_t onssen_dc_cluster_workspace_bytes(int B, int D);
+int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
+                          int iters, float* masks, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10  mask-apply + inverse STFT overlap-add.
  * Replaces `stft_est = stft_mix * mask; librosa.core.istft(stft_est[i].T, hop_length, length)` at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:42-45 and egs/wsj0-2mix/chimera/evaluate.py:40-43.

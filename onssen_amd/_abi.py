@@ -32,6 +32,9 @@ SIGNATURES = {
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
+    "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
+    "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
@@ -115,3 +118,11 @@ class Lib:
     def phase_input(self, x_mag, mask, m_sb, m_sc, m_st, m_sf, x_phase, B, Cn, T, F, out, stream):
         self.check(self.dll.onssen_phase_input_f32(x_mag, mask, m_sb, m_sc, m_st, m_sf, x_phase, B, Cn, T, F, out,
                                                    stream), "onssen_phase_input_f32")
+
+    def labels(self, mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, stream):
+        self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
+                                              cos_s1, cos_s2, stream), "onssen_labels_f32")
+
+    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream),
+                   "onssen_dc_cluster_f32")

@@ -648,6 +648,176 @@ __global__ void pack_w_bf16x3_kernel(const float* __restrict__ w, int N, int K, 
   }
 }
 
+
+// =================================================================================================
+// N3: training-label features from the three complex STFTs (mix, s1, s2) of a chunk
+// (onssen/data/feature_utils.py:77-95 get_cos_difference / get_one_hot, wsj0_2mix.py:130-152)
+// =================================================================================================
+__global__ void utt_max_kernel(const float* __restrict__ x, long per_utt, float* __restrict__ out) {
+  __shared__ float red[256];
+  const float* p = x + (long)blockIdx.x * per_utt;
+  float m = -INFINITY;
+  for (long i = threadIdx.x; i < per_utt; i += 256) m = fmaxf(m, p[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ void labels_kernel(const float* __restrict__ mix, const float* __restrict__ s1, const float* __restrict__ s2,
+                              const float* __restrict__ feat, const float* __restrict__ fmax, long per_utt, long total,
+                              float db_threshold, float* __restrict__ one_hot, float* __restrict__ mag_mix,
+                              float* __restrict__ mag_s1, float* __restrict__ mag_s2, float* __restrict__ cos_s1,
+                              float* __restrict__ cos_s2) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const float xr = mix[2 * e], xi = mix[2 * e + 1];
+    const float ar = s1[2 * e], ai = s1[2 * e + 1], br = s2[2 * e], bi = s2[2 * e + 1];
+    const float m1 = hypotf(ar, ai), m2 = hypotf(br, bi);
+    mag_mix[e] = hypotf(xr, xi);
+    mag_s1[e] = m1;
+    mag_s2[e] = m2;
+    // np.argmax takes the first maximum: speaker 0 on ties; bins below max(feature) - dB/20 are silent (all-zero label)
+    const bool active = !(feat[e] < fmax[e / per_utt] - db_threshold / 20.0f);
+    const int who = (m2 > m1) ? 1 : 0;
+    one_hot[2 * e] = (active && who == 0) ? 1.0f : 0.0f;
+    one_hot[2 * e + 1] = (active && who == 1) ? 1.0f : 0.0f;
+    if (cos_s1) {
+      const float am = atan2f(xi, xr);
+      cos_s1[e] = cosf(am - atan2f(ai, ar));
+      cos_s2[e] = cosf(am - atan2f(bi, br));
+    }
+  }
+}
+
+
+// =================================================================================================
+// N2: deep-clustering back end on the device -- 2-means over the embeddings of the active TF bins
+// (egs/wsj0-2mix/deep_clustering/evaluate.py:36-41: threshold at max - 40/20, KMeans(n_clusters=2), binary masks)
+// Deterministic: farthest-point initialisation, fixed iteration count, per-block partial sums reduced in a
+// fixed order (no float atomics).  Workspace per utterance: [0] feature max, [1..2D] centroids,
+// then NBLK x 2 x (D+1) partial sums.
+// =================================================================================================
+namespace km {
+constexpr int NBLK = 64, DMAX = 32;
+}
+
+// one workgroup per utterance: c0 = embedding of the loudest active bin, c1 = active embedding farthest from c0
+__global__ void kmeans2_init_kernel(const float* __restrict__ emb, const float* __restrict__ feat, long per_utt, int D,
+                                    float db, float* __restrict__ ws, long ws_stride) {
+  __shared__ float rv[256];
+  __shared__ long ri[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* f = feat + (long)b * per_utt;
+  const float* e = emb + (long)b * per_utt * D;
+  float* w = ws + (long)b * ws_stride;
+  float best = -INFINITY;
+  long bi = 0;
+  for (long i = tid; i < per_utt; i += 256)
+    if (f[i] > best) { best = f[i]; bi = i; }
+  rv[tid] = best; ri[tid] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s && (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid]))) {
+      rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s];
+    }
+    __syncthreads();
+  }
+  const float fmax = rv[0];
+  const long i0 = ri[0];
+  __syncthreads();
+  const float thr = fmax - db / 20.0f;
+  float worst = INFINITY;
+  long wi = i0;
+  for (long i = tid; i < per_utt; i += 256) {
+    if (f[i] >= thr) {
+      float dot = 0.0f;
+      for (int d = 0; d < D; ++d) dot += e[i * D + d] * e[i0 * D + d];
+      if (dot < worst) { worst = dot; wi = i; }
+    }
+  }
+  rv[tid] = worst; ri[tid] = wi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s && (rv[tid + s] < rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid]))) {
+      rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s];
+    }
+    __syncthreads();
+  }
+  const long i1 = ri[0];
+  if (tid == 0) w[0] = fmax;
+  for (int d = tid; d < D; d += 256) {
+    w[1 + d] = e[i0 * D + d];
+    w[1 + D + d] = e[i1 * D + d];
+  }
+}
+
+// assignment + per-block partial sums (MODE 0), or assignment + mask write (MODE 1)
+template <int MODE>
+__global__ void kmeans2_assign_kernel(const float* __restrict__ emb, const float* __restrict__ feat, long per_utt, int D,
+                                      float db, float* __restrict__ ws, long ws_stride, float* __restrict__ masks) {
+  using namespace km;
+  __shared__ float part[MODE == 0 ? 2 * (DMAX + 1) * 256 : 1];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* f = feat + (long)b * per_utt;
+  const float* e = emb + (long)b * per_utt * D;
+  float* w = ws + (long)b * ws_stride;
+  const float thr = w[0] - db / 20.0f;
+  float c0[DMAX], c1[DMAX], s0[DMAX], s1[DMAX];
+  float n0 = 0.f, n1 = 0.f, q0 = 0.f, q1 = 0.f;
+  for (int d = 0; d < D; ++d) {
+    c0[d] = w[1 + d]; c1[d] = w[1 + D + d];
+    q0 += c0[d] * c0[d]; q1 += c1[d] * c1[d];
+    s0[d] = 0.f; s1[d] = 0.f;
+  }
+  for (long i = (long)blockIdx.x * 256 + tid; i < per_utt; i += (long)gridDim.x * 256) {
+    const bool active = f[i] >= thr;
+    float d0 = q0, d1 = q1;               // ||e - c||^2 = ||e||^2 - 2 e.c + ||c||^2 ; ||e||^2 is common
+    if (active)
+      for (int d = 0; d < D; ++d) { const float v = e[i * D + d]; d0 -= 2.f * v * c0[d]; d1 -= 2.f * v * c1[d]; }
+    const int lab = (d1 < d0) ? 1 : 0;
+    if (MODE == 1) {
+      masks[2 * ((long)b * per_utt + i)] = active ? (float)lab : 0.0f;          // mask[0] = label
+      masks[2 * ((long)b * per_utt + i) + 1] = active ? (float)(1 - lab) : 0.0f;  // mask[1] = 1 - label
+    } else if (active) {
+      if (lab) { n1 += 1.f; for (int d = 0; d < D; ++d) s1[d] += e[i * D + d]; }
+      else     { n0 += 1.f; for (int d = 0; d < D; ++d) s0[d] += e[i * D + d]; }
+    }
+  }
+  if (MODE == 0) {
+    // all 2(D+1) accumulators go to LDS at once; thread k then adds up column k (one barrier in total)
+    float* out = w + 1 + 2 * D + (long)blockIdx.x * 2 * (D + 1);
+    const int na = 2 * (D + 1);
+    for (int k = 0; k < na; ++k) {
+      const int c = k / (D + 1), d = k % (D + 1);
+      part[k * 256 + tid] = d == D ? (c ? n1 : n0) : (c ? s1[d] : s0[d]);
+    }
+    __syncthreads();
+    if (tid < na) {
+      float acc = 0.f;
+      for (int j = 0; j < 256; ++j) acc += part[tid * 256 + j];
+      out[tid] = acc;
+    }
+  }
+}
+
+__global__ void kmeans2_update_kernel(int D, int nblk, float* __restrict__ ws, long ws_stride) {
+  float* w = ws + (long)blockIdx.x * ws_stride;
+  const int k = threadIdx.x;                 // 2*D threads: (cluster, dim)
+  if (k < 2 * D) {
+    const int c = k / D, d = k % D;
+    float s = 0.f, n = 0.f;
+    for (int j = 0; j < nblk; ++j) {
+      const float* pj = w + 1 + 2 * D + (long)j * 2 * (D + 1) + c * (D + 1);
+      s += pj[d];
+      n += pj[D];
+    }
+    if (n > 0.f) w[1 + c * D + d] = s / n;   // an empty cluster keeps its centroid
+  }
+}
+
 // =================================================================================================
 // K4: one LSTM time step, both directions
 // =================================================================================================
@@ -1398,6 +1568,50 @@ int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, 
   ONSSEN_CLEAR_ERROR();
   hipLaunchKernelGGL(phase_input_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream,
                      x_mag, mask, (long)m_sb, (long)m_sc, (long)m_st, (long)m_sf, x_phase, B, C, T, F, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* stft_s2, const float* feature_mix, int B,
+                      int T, int F, float db_threshold, float* utt_max, float* one_hot, float* mag_mix, float* mag_s1,
+                      float* mag_s2, float* cos_s1, float* cos_s2, void* stream) {
+  if (!stft_mix || !stft_s1 || !stft_s2 || !feature_mix || !utt_max || !one_hot || !mag_mix || !mag_s1 || !mag_s2 ||
+      B <= 0 || T <= 0 || F <= 0 || ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
+    return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const long per_utt = (long)T * F, total = per_utt * B;
+  hipLaunchKernelGGL(utt_max_kernel, dim3((unsigned)B), dim3(256), 0, st, feature_mix, per_utt, utt_max);
+  const long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(labels_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, st, stft_mix, stft_s1, stft_s2,
+                     feature_mix, utt_max, per_utt, total, db_threshold, one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+size_t onssen_dc_cluster_workspace_bytes(int B, int D) {
+  if (B <= 0 || D <= 0 || D > km::DMAX) return 0;
+  return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1)) * sizeof(float);
+}
+
+int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
+                          int iters, float* masks, void* ws, size_t ws_bytes, void* stream) {
+  if (!emb || !feature || !masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0)
+    return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, D)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1);
+  float* w = (float*)ws;
+  hipLaunchKernelGGL(kmeans2_init_kernel, dim3((unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w,
+                     stride);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL((kmeans2_assign_kernel<0>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D,
+                       db_threshold, w, stride, (float*)nullptr);
+    hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(128), 0, st, D, km::NBLK, w, stride);
+  }
+  hipLaunchKernelGGL((kmeans2_assign_kernel<1>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D,
+                     db_threshold, w, stride, masks);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

@@ -1,0 +1,68 @@
+"""Synthetic wsj0-2mix-style loader with the reference's yield contract.
+
+The reference's ``wsj0_2mix_dataloader(model_name, feature_options, partition, device)``
+(onssen/data/wsj0_2mix.py:26-37) globs the licensed WSJ0 corpus, runs three librosa STFTs per sample on
+the host and yields ``(input_list, label_list)``.  There is no corpus here, so utterances come from
+``onssen_amd.synthetic`` -- and the features are computed on the GPU: one batched STFT launch for
+(mix, s1, s2), a random 400-frame crop, then the label kernel (wsj0_2mix.py:103-158).  Same keys of
+``feature_options``, same list layouts per ``model_name``:
+
+    "dc"        [feature_mix] , [one_hot, mag_mix]
+    "chimera"   [feature_mix] , [one_hot, mag_mix, mag_s1, mag_s2]
+    "chimera++" [feature_mix] , [one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2]
+    "phase"     [feature_mix, phase_mix] , [one_hot, mag_mix, mag_s1, mag_s2, phase_s1, phase_s2]
+"""
+import numpy as np
+import torch
+
+from ..features import stft_logmag, training_labels
+from ..synthetic import synth_mixture
+
+
+class SyntheticWsj02mix:
+    def __init__(self, model_name, feature_options, partition="tr", device="cuda:0", num_batches=8, seed=0):
+        fo = feature_options
+        g = (lambda k: fo[k]) if isinstance(fo, dict) else (lambda k: getattr(fo, k))
+        self.model_name = model_name
+        self.batch_size, self.frame_length = int(g("batch_size")), int(g("frame_length"))
+        self.sampling_rate, self.window_size, self.hop_size = int(g("sampling_rate")), int(g("window_size")), int(g("hop_size"))
+        self.db_threshold = float(g("db_threshold"))
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.num_batches = num_batches
+        self.seed = seed + {"tr": 0, "cv": 10_000, "tt": 20_000}.get(partition, 30_000)
+        self.n_samples = self.hop_size * (self.frame_length + 40)     # a little longer than one chunk: crops differ
+
+    def __len__(self):
+        return self.num_batches
+
+    def __iter__(self):
+        rng = np.random.default_rng(self.seed)
+        B, L = self.batch_size, self.frame_length
+        for it in range(self.num_batches):
+            trip = [synth_mixture(self.seed + it * B + b, self.n_samples, self.sampling_rate, return_sources=True)
+                    for b in range(B)]
+            wav = torch.from_numpy(np.stack([np.stack(t) for t in trip])).to(self.device)     # (B, 3, n)
+            logmag, ri = stft_logmag(wav.view(3 * B, -1), self.window_size, self.hop_size)
+            T, F = logmag.shape[1], logmag.shape[2]
+            logmag, ri = logmag.view(B, 3, T, F), ri.view(B, 3, T, F, 2)
+            start = int(rng.integers(0, T - L))            # np.random.randint crop (wsj0_2mix.py:125-128)
+            feat = logmag[:, 0, start:start + L].contiguous()
+            mix, s1, s2 = (ri[:, i, start:start + L].contiguous() for i in range(3))
+            with_cos = self.model_name == "chimera++"
+            out = training_labels(mix, s1, s2, feat, self.db_threshold, with_cos=with_cos)
+            one_hot, mm, m1, m2 = out[:4]
+            if self.model_name == "dc":
+                yield [feat], [one_hot, mm]
+            elif self.model_name == "chimera":
+                yield [feat], [one_hot, mm, m1, m2]
+            elif self.model_name == "chimera++":
+                yield [feat], [one_hot, mm, m1, m2, out[4], out[5]]
+            elif self.model_name == "phase":
+                yield [feat, mix], [one_hot, mm, m1, m2, s1, s2]
+            else:
+                raise ValueError(f"unknown model_name {self.model_name!r}")
+
+
+def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
+    """Same call signature as onssen.data.wsj0_2mix_dataloader (wsj0_2mix.py:26)."""
+    return SyntheticWsj02mix(model_name, feature_options, partition, device)

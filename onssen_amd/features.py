@@ -58,3 +58,23 @@ def mask_istft(stft_ri, masks, hop_size=64, length=None):
     lib.mask_istft(stft_ri.data_ptr(), masks.data_ptr(), masks.stride(0), masks.stride(3), masks.stride(1),
                    masks.stride(2), B, C, T, n_fft, hop_size, length, out.data_ptr(), _stream())
     return out
+
+
+def training_labels(stft_mix, stft_s1, stft_s2, feature_mix, db_threshold=40.0, with_cos=False):
+    """Label-side features of a batch of chunks on the GPU: counterparts of get_one_hot,
+    np.abs and get_cos_difference (onssen/data/feature_utils.py:77-95, wsj0_2mix.py:130-152).
+    Inputs: (B,T,F,2) float32 STFTs as returned by stft_logmag, feature_mix (B,T,F).
+    Returns one_hot (B,T,F,2) float32, mag_mix, mag_s1, mag_s2 (B,T,F) [, cos_s1, cos_s2]."""
+    if not stft_mix.is_cuda:
+        raise RuntimeError("training_labels: needs tensors on a ROCm device; onssen_amd has no CPU fallback")
+    B, T, F, _ = stft_mix.shape
+    dev = stft_mix.device
+    stft_mix, stft_s1, stft_s2 = stft_mix.contiguous(), stft_s1.contiguous(), stft_s2.contiguous()
+    feature_mix = feature_mix.contiguous()
+    mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    one_hot, mm, m1, m2, umax = mk(B, T, F, 2), mk(B, T, F), mk(B, T, F), mk(B, T, F), mk(B)
+    c1, c2 = (mk(B, T, F), mk(B, T, F)) if with_cos else (None, None)
+    get_lib().labels(stft_mix.data_ptr(), stft_s1.data_ptr(), stft_s2.data_ptr(), feature_mix.data_ptr(), B, T, F,
+                     float(db_threshold), umax.data_ptr(), one_hot.data_ptr(), mm.data_ptr(), m1.data_ptr(),
+                     m2.data_ptr(), c1.data_ptr() if with_cos else None, c2.data_ptr() if with_cos else None, _stream())
+    return (one_hot, mm, m1, m2, c1, c2) if with_cos else (one_hot, mm, m1, m2)

@@ -17,25 +17,39 @@ def separate_chimera(model, wav, window_size=256, hop_size=64):
     return mask_istft(ri, masks, hop_size, wav.shape[-1])
 
 
+def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
+    """Binary deep-clustering masks (B,T,F,2) on the device: threshold at max - db/20, 2-means on the active
+    bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host)."""
+    from .hip import get_lib
+    lib = get_lib()
+    B, T, F, D = emb.shape
+    emb, logmag = emb.contiguous(), logmag.contiguous()
+    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, D)
+    ws = torch.empty(nb, dtype=torch.uint8, device=emb.device)
+    masks = torch.empty(B, T, F, 2, device=emb.device, dtype=torch.float32)
+    lib.dc_cluster(emb.data_ptr(), logmag.data_ptr(), B, T, F, D, float(db_threshold), iters, masks.data_ptr(),
+                   ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+    return masks
+
+
 @torch.no_grad()
-def separate_dc(model, wav, window_size=256, hop_size=64, num_spk=2, db_threshold=40.0):
-    """Deep-clustering back end: bins with feature >= max - 40/20 are clustered
-    with KMeans(n_clusters=num_spk, random_state=0) on the host (sklearn, as
-    upstream; 'next' row N2 moves it on-device), binary masks, silent bins 0 in
-    both masks; mask-apply + iSTFT on the GPU."""
-    from sklearn.cluster import KMeans
+def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, host_kmeans=False):
+    """Deep-clustering separation, waveform in -> (B, 2, n) waveforms out, entirely on the GPU
+    (STFT -> network -> threshold + 2-means -> binary masks -> mask-apply + iSTFT).  ``host_kmeans=True``
+    clusters with sklearn KMeans(n_clusters=2, random_state=0) on the host exactly as upstream does
+    (egs/wsj0-2mix/deep_clustering/evaluate.py:36-38); the two differ only in the arbitrary cluster
+    numbering and in bins that sit between the clusters."""
     logmag, ri = stft_logmag(wav, window_size, hop_size)
     emb, = model([logmag])
+    if not host_kmeans:
+        return mask_istft(ri, dc_masks(emb, logmag, db_threshold), hop_size, wav.shape[-1])
+    from sklearn.cluster import KMeans
     B, T, F, D = emb.shape
-    masks = torch.zeros(B, T, F, num_spk, device=wav.device, dtype=torch.float32)
+    masks = torch.zeros(B, T, F, 2, device=wav.device, dtype=torch.float32)
     for b in range(B):   # upstream evaluates with batch 1 (evaluate.py:34-35)
         feat = logmag[b]
         act = feat >= (feat.max() - db_threshold / 20.0)
-        e = emb[b][act].cpu().numpy()
-        label = KMeans(n_clusters=num_spk, random_state=0, n_init=10).fit_predict(e)
-        lab = torch.from_numpy(label.astype(np.int64)).to(wav.device)
-        m = torch.zeros(int(act.sum()), num_spk, device=wav.device)
-        m[:, 0] = lab.float()
-        m[:, 1] = 1.0 - lab.float()
-        masks[b][act] = m
+        label = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(emb[b][act].cpu().numpy())
+        lab = torch.from_numpy(label.astype(np.int64)).to(wav.device).float()
+        masks[b][act] = torch.stack([lab, 1.0 - lab], -1)
     return mask_istft(ri, masks, hop_size, wav.shape[-1])

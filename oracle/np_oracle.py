@@ -62,6 +62,22 @@ def phase_re_im(spec):
     return np.stack([np.real(spec), np.imag(spec)], axis=-1).astype(np.float32)
 
 
+def cos_difference(stft_1, stft_2):
+    """onssen/data/feature_utils.py:67-80: cos(angle(stft_1) - angle(stft_2))."""
+    return np.cos(np.angle(stft_1) - np.angle(stft_2))
+
+
+def one_hot_labels(feature_mix, mag_s1, mag_s2, db_threshold):
+    """onssen/data/feature_utils.py:83-95 get_one_hot: e_argmax over the two source magnitudes (first
+    maximum on ties), all-zero on bins with feature < max(feature) - db_threshold/20.  float64 (T,F,2)."""
+    vals = np.argmax(np.asarray([mag_s1, mag_s2]), axis=0)
+    Y = np.zeros(mag_s1.shape + (2,))
+    Y[vals == 0, 0] = 1
+    Y[vals == 1, 1] = 1
+    Y[feature_mix < (np.max(feature_mix) - db_threshold / 20)] = 0
+    return Y
+
+
 # --------------------------------------------------------------------------
 # Back end  (egs/wsj0-2mix/*/evaluate.py + librosa.core.istft)
 # --------------------------------------------------------------------------

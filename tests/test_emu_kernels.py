@@ -228,3 +228,51 @@ def test_linear_split_bf16(lib, mode, group, K):
     assert not np.isnan(out).any()
     # |x|,|w| ~ N(0,1): ~1e-5 relative of sqrt(K)-sized sums; normalising a short 2-vector amplifies it
     np.testing.assert_allclose(out, ref, atol=2e-3 if group == 2 else 3e-4, rtol=1e-4)
+
+
+def test_label_features_match_oracle(lib):
+    B, n = 2, 1500
+    trips = [synth_mixture(60 + b, n, return_sources=True) for b in range(B)]
+    specs = [[O.stft(w, 256, 64) for w in t] for t in trips]
+    T, F = specs[0][0].shape
+    ri = lambda i: np.ascontiguousarray(np.stack([np.stack([s[i].real, s[i].imag], -1) for s in specs]).astype(np.float32))
+    mix, s1, s2 = ri(0), ri(1), ri(2)
+    feat = np.stack([O.log_magnitude(s[0]) for s in specs])
+    outs = {k: np.full((B, T, F) + ((2,) if k == "one_hot" else ()), np.nan, np.float32)
+            for k in ("one_hot", "mag_mix", "mag_s1", "mag_s2", "cos_s1", "cos_s2")}
+    umax = np.zeros(B, np.float32)
+    lib.labels(P(mix), P(s1), P(s2), P(feat), B, T, F, 40.0, P(umax), *[P(outs[k]) for k in
+               ("one_hot", "mag_mix", "mag_s1", "mag_s2", "cos_s1", "cos_s2")], None)
+    for b in range(B):
+        X, S1, S2 = specs[b]
+        np.testing.assert_array_equal(outs["one_hot"][b], O.one_hot_labels(feat[b], np.abs(S1), np.abs(S2), 40.0))
+        np.testing.assert_allclose(outs["mag_mix"][b], np.abs(X), rtol=1e-6)
+        np.testing.assert_allclose(outs["cos_s1"][b], O.cos_difference(X, S1), atol=2e-6)
+        np.testing.assert_allclose(outs["cos_s2"][b], O.cos_difference(X, S2), atol=2e-6)
+    assert 0.05 < outs["one_hot"].sum(-1).mean() < 0.98       # some bins active, some silent
+
+
+def _two_cluster_embeddings(rng, B, T, F, D, noise=0.15):
+    cents = rng.standard_normal((B, 2, D))
+    cents /= np.linalg.norm(cents, axis=-1, keepdims=True)
+    lab = rng.integers(0, 2, (B, T, F))
+    e = np.take_along_axis(cents[:, None, None], lab[..., None, None], axis=3)[..., 0, :]
+    e = e + noise * rng.standard_normal(e.shape)
+    e /= np.linalg.norm(e, axis=-1, keepdims=True)
+    feat = rng.uniform(-3.0, 1.0, (B, T, F)).astype(np.float32)
+    return e.astype(np.float32), feat, lab
+
+
+def test_dc_cluster_masks(lib):
+    rng = np.random.default_rng(11)
+    B, T, F, D = 2, 20, 33, 20
+    emb, feat, lab = _two_cluster_embeddings(rng, B, T, F, D)
+    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, D)
+    ws = np.zeros(nb // 4 + 4, np.float32)
+    masks = np.full((B, T, F, 2), np.nan, np.float32)
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 10, P(masks), P(ws), nb, None)
+    for b in range(B):
+        act = O.dc_active_bins(feat[b])
+        assert np.all(masks[b][~act] == 0) and np.all(masks[b][act].sum(-1) == 1)
+        agree = (masks[b][act][:, 0] == lab[b][act]).mean()
+        assert max(agree, 1 - agree) > 0.995        # cluster numbering is arbitrary

@@ -295,3 +295,61 @@ def test_end_to_end_separation_chimera(dev, prec):
         _, a, bb = O.chimera_forward(sd, O.log_magnitude(X)[None])
         ref = O.mask_istft(X, np.stack([a[0], bb[0]]), 64, 6400)
         np.testing.assert_allclose(sig[b], ref, atol=prec["atol"])
+
+
+def test_label_features_and_synthetic_loader(dev):
+    """Rows N3 / H1: label kernels vs the oracle restatement of get_one_hot / get_cos_difference, and the
+    synthetic wsj0-2mix loader's yield contract feeding loss_dc."""
+    from onssen_amd.data import wsj0_2mix_dataloader
+    from onssen_amd.features import stft_logmag, training_labels
+    from onssen_amd.loss import loss_dc
+    B, n = 3, 9000
+    trips = [synth_mixture(80 + b, n, return_sources=True) for b in range(B)]
+    wav = torch.from_numpy(np.stack([np.stack(t) for t in trips])).to(dev)
+    lm, ri = stft_logmag(wav.view(3 * B, -1))
+    T, F = lm.shape[1:]
+    lm, ri = lm.view(B, 3, T, F), ri.view(B, 3, T, F, 2)
+    oh, mm, m1, m2, c1, c2 = training_labels(ri[:, 0], ri[:, 1], ri[:, 2], lm[:, 0], 40.0, with_cos=True)
+    for b in range(B):
+        X, S1, S2 = (O.stft(w, 256, 64) for w in trips[b])
+        ref = O.one_hot_labels(lm[b, 0].cpu().numpy(), np.abs(S1), np.abs(S2), 40.0)
+        assert (oh[b].cpu().numpy() != ref).mean() < 1e-4            # ties / threshold edges at fp32 rounding only
+        np.testing.assert_allclose(m1[b].cpu().numpy(), np.abs(S1), rtol=2e-6, atol=1e-8)
+        big = (np.abs(X) > 1e-3) & (np.abs(S1) > 1e-3)
+        np.testing.assert_allclose(c1[b].cpu().numpy()[big], O.cos_difference(X, S1)[big], atol=1e-4)
+    fo = dict(data_path="", batch_size=4, frame_length=100, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
+    for name, n_in, n_lab in (("dc", 1, 2), ("chimera", 1, 4), ("chimera++", 1, 6), ("phase", 2, 6)):
+        loader = wsj0_2mix_dataloader(name, fo, "tr", "cuda:0")
+        inp, lab = next(iter(loader))
+        assert len(inp) == n_in and len(lab) == n_lab
+        assert inp[0].shape == (4, 100, 129) and lab[0].shape == (4, 100, 129, 2) and lab[1].shape == (4, 100, 129)
+    inp, lab = next(iter(wsj0_2mix_dataloader("dc", fo, "cv", "cuda:0")))
+    m, _ = build("deep_clustering", dict(F=129, H=16, L=1, D=20, C=2, seed=1, gain=1.0), dev)
+    with torch.no_grad():
+        loss = loss_dc(m(inp), lab)
+    assert loss.shape == (4, 4) and torch.isfinite(loss).all()
+
+
+def test_dc_cluster_agrees_with_sklearn_and_separates(dev):
+    """Row N2: device 2-means vs sklearn KMeans(n_clusters=2, random_state=0) on the same active bins
+    (permutation-invariant agreement), then the all-GPU separate_dc against the host-k-means variant."""
+    from sklearn.cluster import KMeans
+    from onssen_amd.separation import dc_masks, separate_dc
+    rng = np.random.default_rng(5)
+    B, T, F, D = 2, 400, 129, 20
+    cents = rng.standard_normal((B, 2, D)); cents /= np.linalg.norm(cents, axis=-1, keepdims=True)
+    lab = rng.integers(0, 2, (B, T, F))
+    e = np.take_along_axis(cents[:, None, None], lab[..., None, None], axis=3)[..., 0, :] + 0.2 * rng.standard_normal((B, T, F, D))
+    e = (e / np.linalg.norm(e, axis=-1, keepdims=True)).astype(np.float32)
+    feat = rng.uniform(-3.0, 1.0, (B, T, F)).astype(np.float32)
+    masks = dc_masks(torch.from_numpy(e).to(dev), torch.from_numpy(feat).to(dev)).cpu().numpy()
+    for b in range(B):
+        act = O.dc_active_bins(feat[b])
+        sk = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(e[b][act])
+        agree = (masks[b][act][:, 0] == sk).mean()
+        assert max(agree, 1 - agree) > 0.999 and np.all(masks[b][~act] == 0)
+    m, _ = build("deep_clustering", dict(F=129, H=32, L=1, D=20, C=2, seed=6, gain=1.0), dev)
+    wav = torch.from_numpy(np.stack([synth_mixture(90 + b, 8000) for b in range(2)])).to(dev)
+    a = separate_dc(m, wav)
+    assert a.shape == (2, 2, 8000) and torch.isfinite(a).all()
+    assert torch.equal(a, separate_dc(m, wav))                       # deterministic
