@@ -44,6 +44,12 @@ extern "C" {
                                      wih_p_host[l] to onssen_linear_pack_bf16x3 planes of the [2*NP][K_l] matrix
                                      (ld = K_l rounded up to 32): the input projections run split-bf16 too.
                                      H <= 640. */
+#define ONSSEN_BLSTM_XCD 4        /* (with BF16X3) one persistent launch per layer: every (direction, 16-row group)
+                                     recurrence runs inside one XCD, W_hh register-resident, h_t exchanged through
+                                     that XCD's L2.  Needs ceil(H/ug) <= 32, H <= 640, ug <= 20.  The kernel verifies
+                                     the placement itself and otherwise uses a placement-independent (slower)
+                                     protocol; bounded waits: ws word [281] = 1 reports that, word [280] != 0 an
+                                     aborted launch (outputs invalid). */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */

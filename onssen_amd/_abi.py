@@ -11,6 +11,7 @@ EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
 ABI_VERSION = 2
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
+BLSTM_XCD = 4
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)

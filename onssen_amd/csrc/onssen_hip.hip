@@ -1067,6 +1067,213 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
 }
 
 
+
+// -------------------------------------------------------------------------------------------------
+// K4, XCD-local persistent form (split-bf16 only): ONE launch runs all T steps of a layer.
+//
+// A (direction, 16-row batch group) recurrence is an exchange group of NU <= 32 workgroups, one hidden-unit
+// group each, and the launch places every member of a group on the SAME XCD (workgroup b is observed to run
+// on XCD b % 8, so group = b % 8, member = b / 8).  W_hh never leaves the register file, the cell state stays
+// in registers, and h_t moves between the members through that XCD's own L2: plain stores (write-through L1,
+// line kept in L2), s_waitcnt vmcnt(0), one flag word per member, consumers poll the 32 flags with ONE
+// L1-bypassing load and then fetch the fragment-ordered h image with L1-bypassing (sc1) loads.  No fabric
+// round trip, no kernel boundary: the step costs two L2 hops instead of ~1.6 us + a cold fetch.
+//
+// Correctness never rests on that placement.  At start-up every member publishes its HW_REG_XCC_ID with
+// agent-scope atomics; only if all ids of a group agree does the group use the L2-local protocol, otherwise
+// it runs the same loop with write-through (sc1) stores and system-scope (sc0 sc1) loads, which is valid for any
+// placement (and slower than one launch per step -- see DESIGN.md).  Every spin is bounded; a timeout raises
+// the abort word, all workgroups leave, and the status word tells the host.
+// -------------------------------------------------------------------------------------------------
+struct XcdArgs {
+  const float* G;               // [T][B][2][NP]
+  const unsigned short* whh;    // split-bf16 image [2][NU][KQ2][NT][2][64][8]
+  float* y;                     // [T][B][2][Hp]
+  unsigned short* hx;           // per group: [2 slots][KQ2][hi|lo][64][8]
+  unsigned* sync;               // [g*32 + m] flags, [256 + g] arrivals, [264 + g] max(xcc+1), [272 + g] max(16-xcc),
+                                // [280] abort, [281] status (1 = some group ran placement-independent protocol)
+  int B, T, Hp, NP, KQ2, NU, row0, nbg;
+  unsigned spin_limit;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
+  using namespace rec;
+  constexpr int UG = 4 * NT;
+  constexpr int NE = 16 * UG;
+  constexpr int EPT = (NE + 255) / 256;
+  constexpr int CPW = 5;                       // k-chunks (32 k) per wave: 4 x 5 x 32 = 640 >= H
+  constexpr unsigned kOOB = 0x7ffffff0u;
+  __shared__ float red[4 * NT * 4 * RLD];
+  __shared__ unsigned s_ctl[2];                // [0] abort, [1] fast
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = blockIdx.x & 7, ugi = blockIdx.x >> 3;
+  if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
+  const int dir = g / p.nbg, bg = g % p.nbg;
+  const int b0 = p.row0 + bg * 16;
+  unsigned* flags = p.sync + g * 32;
+  unsigned* abort_w = p.sync + 280;
+
+  // ---- placement check: do all members of this group sit on one XCD?
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    __hip_atomic_fetch_max(p.sync + 264 + g, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(p.sync + 272 + g, 16u - xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(p.sync + 256 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0, ab = 0;
+    while (__hip_atomic_fetch_add(p.sync + 256 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.NU) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+    }
+    const unsigned hi = __hip_atomic_fetch_add(p.sync + 264 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned lo = __hip_atomic_fetch_add(p.sync + 272 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[0] = ab;
+    s_ctl[1] = (hi + lo == 17u) ? 1u : 0u;     // max(xcc)+1 + 16-min(xcc) == 17  <=>  max == min
+    if (ab) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ab && s_ctl[1] == 0u) __hip_atomic_store(p.sync + 281, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_ctl[0]) return;
+  const bool fast = s_ctl[1] != 0;
+
+  // ---- resident recurrent weights (hi and lo fragments), chunks q = wave, wave+4, ...
+  const int fi = lane & 15;
+  s16x8 w[CPW][NT][2];
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.whh + (long)(dir * p.NU + ugi) * p.KQ2 * NT * 1024), 0, p.KQ2 * NT * 2048, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+          w[i][nt][hl] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              rw, (unsigned)(((wave + 4 * i) * NT + nt) * 2048 + hl * 1024 + lane * 16), 0, 0));
+  }
+  float cst[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
+  const long hx_group = (long)g * 2 * p.KQ2 * 1024;             // uint16 elements per group (two slots)
+
+  for (int step = 0; step < p.T; ++step) {
+    const int t = dir == 0 ? step : p.T - 1 - step;
+    float gpre[EPT][4];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / UG, ju = e % UG, b = b0 + row;
+      const bool ok = (e < NE) && (b < p.B);
+#pragma unroll
+      for (int gt = 0; gt < 4; ++gt)
+        gpre[i][gt] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + gt * UG + ju] : 0.0f;
+    }
+
+    if (step > 0) {
+      // ---- wait until every member's flag says "h of step-1 published": one 32-lane load per poll
+      if (wave == 0) {
+        unsigned spins = 0, ab = 0;
+        for (;;) {
+          const unsigned v = lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0xffffffffu;
+          if (__all(v >= (unsigned)step)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 63u) == 0 &&
+              (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            ab = 1;
+            break;
+          }
+        }
+        if (lane == 0) {
+          s_ctl[0] = ab;
+          if (ab) __hip_atomic_store(abort_w, 2u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      __syncthreads();
+      if (s_ctl[0]) break;
+
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
+      u32x4 a[CPW][2];
+#pragma unroll
+      for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const unsigned off = (wave + 4 * i) * 2048 + hl * 1024 + lane * 16;   // past KQ2 -> out of range -> zeros
+          a[i][hl] = fast ? __builtin_amdgcn_raw_buffer_load_b128(rh, off, 0, 16)    // sc1: bypass L1, this XCD's L2
+                          : __builtin_amdgcn_raw_buffer_load_b128(rh, off, 0, 17);   // sc0 sc1: coherent anywhere
+        }
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        if (wave + 4 * i < p.KQ2) {
+          const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
+            acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
+            acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
+      __syncthreads();
+    }
+
+    // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e / UG, ju = e % UG, b = b0 + row;
+      if (e < NE) {
+        float pre[4];
+#pragma unroll
+        for (int gt = 0; gt < 4; ++gt) {
+          float sacc = 0.0f;
+          if (step > 0) {
+            const int pl = gt * UG + ju;
+            const int src = ((row >> 2) << 4) + (pl & 15), r = row & 3;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) sacc += red[((wv * NT + (pl >> 4)) * 4 + r) * RLD + src];
+          }
+          pre[gt] = sacc + gpre[i][gt];
+        }
+        const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
+        const float cn = fg2 * cst[i] + ig * gg;
+        cst[i] = cn;
+        const float h = (b < p.B) ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
+        unsigned short hi, lo;
+        split_bf16(h, hi, lo);
+        const int k = ugi * UG + ju;
+        const unsigned off = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
+        if (fast) {
+          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, 16);      // write-through
+          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, 16);
+        }
+        if (b < p.B) p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + k] = h;
+      }
+    }
+    // every storing wave drains its stores (acknowledged by L2 / by memory), then one lane raises the flag
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
+    __syncthreads();
+    if (tid == 0) {
+      if (fast) __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // =================================================================================================
 // K1+K2 / K10: fp64 radix-2 FFT helpers (one wavefront per frame, data in LDS)
 // =================================================================================================
@@ -1232,6 +1439,22 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
   }
 }
 
+
+
+template <int NT>
+static int launch_xcd(XcdArgs xa, hipStream_t st) {
+  // <= 4 batch groups of 16 rows per launch (2 directions x 4 = the chip's 8 XCDs)
+  for (int r0 = 0; r0 < xa.B; r0 += 64) {
+    const int rows = xa.B - r0 < 64 ? xa.B - r0 : 64;
+    xa.row0 = r0;
+    xa.nbg = ceil_div(rows, 16);
+    hipError_t e = hipMemsetAsync(xa.sync, 0, 2048, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((lstm_xcd_kernel<NT>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ONSSEN_OK : (int)e;
+}
 
 template <int MT, int NT>
 static int launch_steps(StepArgs sp, char* ws, int T, bool x3, hipStream_t st) {
@@ -1473,7 +1696,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
   const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
-  return 512 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 512 B reserved; trailing 64 KiB profiling area
+  return 2048 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 2 KiB: exchange flags / status of the XCD-local form
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -1489,7 +1712,8 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(y)) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
-  wsp += 512;   // reserved header
+  unsigned* syncw = (unsigned*)wsp;
+  wsp += 2048;
   float* G = (float*)wsp;
   wsp += align256((size_t)T * B * 2 * NP * sizeof(float));
   float* ybuf = nullptr;
@@ -1532,6 +1756,22 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              2 * NP, stream);
     }
     if (rc != ONSSEN_OK) return rc;
+    if (flags & ONSSEN_BLSTM_XCD) {
+      if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
+      XcdArgs xa;
+      xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u;
+      ONSSEN_CLEAR_ERROR();
+      switch (ug) {
+        case 4: rc = launch_xcd<1>(xa, st); break;
+        case 8: rc = launch_xcd<2>(xa, st); break;
+        case 12: rc = launch_xcd<3>(xa, st); break;
+        case 16: rc = launch_xcd<4>(xa, st); break;
+        default: rc = launch_xcd<5>(xa, st); break;
+      }
+      if (rc != ONSSEN_OK) return rc;
+      continue;
+    }
     StepArgs sp;
     sp.G = G; sp.whh = x3 ? nullptr : whh_p_host[l]; sp.whh_x3 = x3 ? (const unsigned short*)whh_p_host[l] : nullptr;
     sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.dbg = dbg; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;

@@ -37,6 +37,10 @@ def recurrence_plan(B, H):
     flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
     if precision() == "bf16x3" and H <= 640:
         flags |= _abi.BLSTM_BF16X3
+        if os.environ.get("ONSSEN_XCD", "0") == "1":
+            # XCD-local persistent recurrence: at most 32 unit groups per direction
+            ug = 4 * -(-H // 128)
+            flags |= _abi.BLSTM_XCD
     if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
         flags |= _abi.BLSTM_SPLIT_ROWS
     return ug, flags
@@ -213,6 +217,12 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
                       [t.data_ptr() for t in (pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih)],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
+    if (flags & _abi.BLSTM_XCD) and os.environ.get("ONSSEN_CHECK") == "1":   # debug: synchronise, read the status words
+        torch.cuda.synchronize()
+        st = wsb[:2048].cpu().numpy().view("uint32")
+        if st[280] != 0:
+            raise _abi.OnssenError(f"XCD-local recurrence aborted (code {st[280]}): outputs are invalid")
+        run_blstm.last_status = int(st[281])
     return y
 
 

@@ -239,3 +239,33 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu
 }
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
+
+// ---- XCD-local persistent kernel support
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <class T> static inline T emu_fetch_max(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+  return old;
+}
+#define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
+static inline void __builtin_amdgcn_fence(int, const char*) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// XCC id: 0 for every workgroup, or scrambled per workgroup when ONSSEN_EMU_SCRAMBLE_XCC=1 (exercises the
+// placement-independent protocol)
+static inline unsigned __builtin_amdgcn_s_getreg(int) {
+  const char* e = getenv("ONSSEN_EMU_SCRAMBLE_XCC");
+  return (e && e[0] == '1') ? (blockIdx.x / 8u + blockIdx.x) & 7u : 0u;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b16(short v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  if ((unsigned long)(unsigned)voff + 2 <= (unsigned long)r.bytes) {
+    __atomic_store_n(reinterpret_cast<short*>(r.base + voff + soff), v, __ATOMIC_SEQ_CST);
+  }
+}
+static inline bool __all(bool p) {
+  auto& w = emu::ctx->wbuf[emu::wave];
+  w.a[emu::lane] = p ? 1.0f : 0.0f;
+  emu::wave_sync();
+  bool r = true;
+  for (int i = 0; i < 64; ++i) r = r && (w.a[i] != 0.0f);
+  emu::wave_sync();
+  return r;
+}

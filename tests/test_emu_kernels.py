@@ -276,3 +276,58 @@ def test_dc_cluster_masks(lib):
         assert np.all(masks[b][~act] == 0) and np.all(masks[b][act].sum(-1) == 1)
         agree = (masks[b][act][:, 0] == lab[b][act]).mean()
         assert max(agree, 1 - agree) > 0.995        # cluster numbering is arbitrary
+
+
+def _shm(shape, fill=0.0, dtype=np.float32):
+    """'Device' buffer in MAP_SHARED memory, 256-byte aligned: visible to forked workgroup processes."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    a = np.frombuffer(mmap.mmap(-1, max(n, 4096)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    a[...] = fill
+    return a
+
+
+@pytest.mark.parametrize("scramble", ["0", "1"])
+@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3)])
+def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble):
+    """ONSSEN_BLSTM_XCD: one persistent launch per layer, h exchanged inside the launch.  The mock runtime runs
+    every workgroup concurrently (forked) over shared memory; scramble=1 makes the members of a group report
+    different XCC ids, which must select the placement-independent protocol (status word 281)."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
+    F, L = 9, 2
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(3)
+    x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    wih3, whh3, bias = [], [], []
+    for l in range(L):
+        K = F if l == 0 else 2 * Hp
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
+        scratch = _shm((we,))
+        for d, sfx in enumerate(("", "_reverse")):
+            srcs = []
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                v = sd[f"rnn.{n}_l{l}{sfx}"]
+                sv = _shm(v.shape); sv[...] = v
+                srcs.append(sv)
+            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
+                          P(a[d]), P(scratch), P(c[d]), None)
+            lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
+        ld = (K + 31) // 32 * 32
+        pl = _shm((2, 2 * NP, ld), dtype=np.uint16)
+        lib.linear_pack_bf16x3(P(a), 2 * NP, K, Kp, ld, P(pl), None)
+        wih3.append(pl), whh3.append(b3), bias.append(c)
+    ws = _shm((lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64,))
+    y = _shm((T, B, 2, Hp), fill=np.nan)
+    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
+                      [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD, None)
+    status = ws.view(np.uint32)
+    assert status[280] == 0, f"launch aborted (code {status[280]})"
+    assert status[281] == (1 if scramble == "1" else 0)
+    ref = O.blstm_stack(np.array(x), sd, "rnn.", L)
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    assert np.abs(got - ref).max() < 2e-5
+    assert np.all(np.array(y)[:, :, :, H:] == 0)

@@ -353,3 +353,25 @@ def test_dc_cluster_agrees_with_sklearn_and_separates(dev):
     a = separate_dc(m, wav)
     assert a.shape == (2, 2, 8000) and torch.isfinite(a).all()
     assert torch.equal(a, separate_dc(m, wav))                       # deterministic
+
+
+@pytest.mark.parametrize("B,T,H,L", [(32, 400, 600, 2), (5, 37, 600, 2), (33, 21, 300, 3), (70, 9, 128, 2), (16, 50, 64, 1)])
+def test_xcd_local_persistent_recurrence(dev, monkeypatch, B, T, H, L):
+    """ONSSEN_BLSTM_XCD: one persistent launch per layer with the h exchange inside one XCD's L2 (or the
+    placement-independent protocol if the kernel finds a group spread over XCDs)."""
+    from onssen_amd.nn import _core
+    monkeypatch.setenv("ONSSEN_XCD", "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    cfg = dict(F=129, H=H, L=L, D=20, C=2, seed=3, gain=1.0)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = logmag_input(11, B, max(T, 3))[:, :T]
+    ref = TC.deep_clustering_forward(sd, x).numpy()
+    with torch.no_grad():
+        emb = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
+        emb2 = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
+    print(f"xcd-local B={B} T={T} H={H}: max abs err {np.abs(emb - ref).max():.3e}, placement-independent protocol used: "
+          f"{getattr(_core.run_blstm, 'last_status', None)}")
+    np.testing.assert_allclose(emb, ref, atol=5e-5, rtol=1e-4)
+    assert rel_l2(emb, ref).max() < 1e-4
+    np.testing.assert_array_equal(emb, emb2)
