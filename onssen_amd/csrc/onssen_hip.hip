@@ -16,6 +16,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/onssen_hip.h"
 
 typedef float f32x4 __attribute__((vector_size(16)));
@@ -1094,6 +1096,7 @@ struct XcdArgs {
                                 // [280] abort, [281] status (1 = some group ran placement-independent protocol)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
   unsigned spin_limit;
+  long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
 };
 
 template <int NT>
@@ -1157,121 +1160,149 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
   const long hx_group = (long)g * 2 * p.KQ2 * 1024;             // uint16 elements per group (two slots)
 
-  for (int step = 0; step < p.T; ++step) {
+  const bool stamp = p.dbg && tid == 0 && blockIdx.x == 0;
+  // input projection of a step: loaded one step AHEAD into a second register set.  Waiting for the h fragments
+  // (vmcnt retires in order) would otherwise also wait for these older, HBM-cold loads on the critical path.
+  auto load_g = [&](float (&gp)[EPT][4], int step) {
     const int t = dir == 0 ? step : p.T - 1 - step;
-    float gpre[EPT][4];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int e = tid + 256 * i;
       const int row = e / UG, ju = e % UG, b = b0 + row;
-      const bool ok = (e < NE) && (b < p.B);
+      const bool ok = (e < NE) && (b < p.B) && (step < p.T);
 #pragma unroll
       for (int gt = 0; gt < 4; ++gt)
-        gpre[i][gt] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + gt * UG + ju] : 0.0f;
+        gp[i][gt] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + gt * UG + ju] : 0.0f;
     }
+  };
+  float gcur[EPT][4], gnext[EPT][4];
+  load_g(gcur, 0);
 
-    if (step > 0) {
-      // ---- wait until every member's flag says "h of step-1 published": one 32-lane load per poll
-      if (wave == 0) {
-        unsigned spins = 0, ab = 0;
-        for (;;) {
-          const unsigned v = lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                         : 0xffffffffu;
-          if (__all(v >= (unsigned)step)) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 63u) == 0 &&
-              (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            ab = 1;
-            break;
+  // the loop body exists twice: L2-local protocol (FAST) and placement-independent protocol
+  auto run = [&](auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    constexpr int LD_AUX = FAST ? 16 : 17;       // sc1: bypass L1, served by this XCD's L2 | sc0 sc1: coherent anywhere
+    constexpr int ST_AUX = FAST ? 0 : 16;        // plain (line stays in L2) | sc1 write-through
+    // one time step; `guse` holds this step's input projection, `gpre` receives the next step's (the two
+    // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
+    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4]) -> bool {
+      const int t = dir == 0 ? step : p.T - 1 - step;
+      if (stamp) p.dbg[step * 8 + 0] = clock64();
+      if (step > 0) {
+        // ---- wait until every member's flag says "h of step-1 published": one 32-lane load per poll
+        if (wave == 0) {
+          unsigned spins = 0, ab = 0;
+          for (;;) {
+            const unsigned v = lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0xffffffffu;
+            if (__all(v >= (unsigned)step)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63u) == 0 &&
+                (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              ab = 1;
+              break;
+            }
+          }
+          if (lane == 0) {
+            s_ctl[0] = ab;
+            if (ab) __hip_atomic_store(abort_w, 2u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        if (lane == 0) {
-          s_ctl[0] = ab;
-          if (ab) __hip_atomic_store(abort_w, 2u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      __syncthreads();
-      if (s_ctl[0]) break;
+        __syncthreads();
+        if (s_ctl[0]) return false;
+        if (stamp) p.dbg[step * 8 + 1] = clock64();
 
-      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
-      u32x4 a[CPW][2];
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
+        u32x4 a[CPW][2];
 #pragma unroll
-      for (int i = 0; i < CPW; ++i)
+        for (int i = 0; i < CPW; ++i)
 #pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-          const unsigned off = (wave + 4 * i) * 2048 + hl * 1024 + lane * 16;   // past KQ2 -> out of range -> zeros
-          a[i][hl] = fast ? __builtin_amdgcn_raw_buffer_load_b128(rh, off, 0, 16)    // sc1: bypass L1, this XCD's L2
-                          : __builtin_amdgcn_raw_buffer_load_b128(rh, off, 0, 17);   // sc0 sc1: coherent anywhere
-        }
-      f32x4 acc[NT];
+          for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
+            a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, (wave + 4 * i) * 2048 + hl * 1024 + lane * 16, 0, LD_AUX);
+        load_g(gpre, step + 1);
+        f32x4 acc[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < CPW; ++i) {
-        if (wave + 4 * i < p.KQ2) {
-          const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
+        for (int i = 0; i < CPW; ++i) {
+          if (wave + 4 * i < p.KQ2) {
+            const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
-            acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
-            acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
+              acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
+              acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
+            }
           }
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
+        if (stamp) p.dbg[step * 8 + 2] = clock64();
+        __syncthreads();
+        if (stamp) p.dbg[step * 8 + 3] = clock64();
+      } else {
+        load_g(gpre, 1);
+        // step 0 has no recurrent term: publish zero partial sums so that the epilogue below is branch-free
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = 0.0f;
+        __syncthreads();
       }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
-      __syncthreads();
-    }
 
-    // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
+      // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / UG, ju = e % UG, b = b0 + row;
-      if (e < NE) {
-        float pre[4];
+      for (int i = 0; i < EPT; ++i) {
+        const int e = tid + 256 * i;
+        const int row = e / UG, ju = e % UG, b = b0 + row;
+        if (e < NE) {
+          // 16 independent LDS reads (4 gates x 4 wave partials) issued together, then summed
+          float part[4][4], pre[4];
 #pragma unroll
-        for (int gt = 0; gt < 4; ++gt) {
-          float sacc = 0.0f;
-          if (step > 0) {
+          for (int gt = 0; gt < 4; ++gt) {
             const int pl = gt * UG + ju;
-            const int src = ((row >> 2) << 4) + (pl & 15), r = row & 3;
+            const float* src = red + ((pl >> 4) * 4 + (row & 3)) * RLD + ((row >> 2) << 4) + (pl & 15);
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) sacc += red[((wv * NT + (pl >> 4)) * 4 + r) * RLD + src];
+            for (int wv = 0; wv < 4; ++wv) part[gt][wv] = src[wv * NT * 4 * RLD];
           }
-          pre[gt] = sacc + gpre[i][gt];
+#pragma unroll
+          for (int gt = 0; gt < 4; ++gt)
+            pre[gt] = ((part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3])) + guse[i][gt];
+          const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
+          const float cn = fg2 * cst[i] + ig * gg;
+          cst[i] = cn;
+          const float h = (b < p.B) ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
+          unsigned short hi, lo;
+          split_bf16(h, hi, lo);
+          const int k = ugi * UG + ju;
+          const unsigned off = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
+          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, ST_AUX);
+          if (b < p.B) p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + k] = h;
         }
-        const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
-        const float cn = fg2 * cst[i] + ig * gg;
-        cst[i] = cn;
-        const float h = (b < p.B) ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
-        unsigned short hi, lo;
-        split_bf16(h, hi, lo);
-        const int k = ugi * UG + ju;
-        const unsigned off = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
-        if (fast) {
-          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, 16);      // write-through
-          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, 16);
-        }
-        if (b < p.B) p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + k] = h;
       }
+      // every storing wave drains its stores (acknowledged by L2 / by memory), then one lane raises the flag
+      if (stamp) p.dbg[step * 8 + 4] = clock64();
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
+      __syncthreads();
+      if (stamp) p.dbg[step * 8 + 5] = clock64();
+      if (tid == 0) {
+        if (FAST) __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return true;
+    };
+    for (int step = 0; step < p.T; step += 2) {
+      if (!body(step, gcur, gnext)) break;
+      if (step + 1 < p.T && !body(step + 1, gnext, gcur)) break;
     }
-    // every storing wave drains its stores (acknowledged by L2 / by memory), then one lane raises the flag
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
-    __syncthreads();
-    if (tid == 0) {
-      if (fast) __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  };
+  if (fast) run(std::true_type{}); else run(std::false_type{});
 }
 
 // =================================================================================================
@@ -1760,7 +1791,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
       XcdArgs xa;
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg;
       ONSSEN_CLEAR_ERROR();
       switch (ug) {
         case 4: rc = launch_xcd<1>(xa, st); break;
