@@ -57,8 +57,9 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // Weight packing
 // =================================================================================================
 
-// packed gate column p of a direction  <->  (unit-group, gate, unit-in-group)
-//   p = ugi*(4*UG) + gate*UG + ju ;  original nn.LSTM row = gate*H + ugi*UG + ju  (gate order i,f,g,o)
+// packed gate column p of a direction  <->  (unit-group, unit-in-group, gate), gate fastest: the four gate
+// pre-activations of one hidden unit are one aligned float4 of G for the recurrence epilogue
+//   p = ugi*(4*UG) + ju*4 + gate ;  original nn.LSTM row = gate*H + ugi*UG + ju  (gate order i,f,g,o)
 __global__ void pack_wih_kernel(const float* __restrict__ w_ih, const float* __restrict__ b_ih,
                                 const float* __restrict__ b_hh, int in_dim, int bidir_in, int H, int Hp, int UG,
                                 int Kp, float* __restrict__ wih_p, float* __restrict__ bias_p) {
@@ -66,7 +67,7 @@ __global__ void pack_wih_kernel(const float* __restrict__ w_ih, const float* __r
   const long total = (long)NP * Kp;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int p = (int)(e / Kp), kk = (int)(e % Kp);
-    const int ugi = p / (4 * UG), rem = p % (4 * UG), gate = rem / UG, ju = rem % UG;
+    const int ugi = p / (4 * UG), rem = p % (4 * UG), ju = rem / 4, gate = rem % 4;
     const int u = ugi * UG + ju;
     int k;
     bool ok = u < H;
@@ -892,9 +893,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws,
       const int e = tid + 256 * i;
       const int row = e / UG, ju = e % UG, b = b0 + row;
       const bool ok = (e < NE) && (b < p.B) && !(p.ablate & 8);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        gpre[i][g] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + g * UG + ju] : 0.0f;
+      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + ((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      gpre[i][0] = g4.x; gpre[i][1] = g4.y; gpre[i][2] = g4.z; gpre[i][3] = g4.w;
       cold[i] = (ok && !first) ? p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] : 0.0f;
     }
   };
@@ -1097,6 +1098,7 @@ struct XcdArgs {
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
   unsigned spin_limit;
   long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
+  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA
 };
 
 template <int NT>
@@ -1169,10 +1171,10 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
     for (int i = 0; i < EPT; ++i) {
       const int e = tid + 256 * i;
       const int row = e / UG, ju = e % UG, b = b0 + row;
-      const bool ok = (e < NE) && (b < p.B) && (step < p.T);
-#pragma unroll
-      for (int gt = 0; gt < 4; ++gt)
-        gp[i][gt] = ok ? p.G[((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + gt * UG + ju] : 0.0f;
+      const bool ok = (e < NE) && (b < p.B) && (step < p.T) && !(p.ablate & 2);
+      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + ((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      gp[i][0] = g4.x; gp[i][1] = g4.y; gp[i][2] = g4.z; gp[i][3] = g4.w;
     }
   };
   float gcur[EPT][4], gnext[EPT][4];
@@ -1196,7 +1198,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
             const unsigned v = lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                            : 0xffffffffu;
             if (__all(v >= (unsigned)step)) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (!FAST) __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0 &&
                 (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
               ab = 1;
@@ -1219,8 +1221,11 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
         for (int i = 0; i < CPW; ++i)
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
-            a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, (wave + 4 * i) * 2048 + hl * 1024 + lane * 16, 0, LD_AUX);
+            a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(
+                rh, (p.ablate & 1) ? 0x7ffffff0u : (unsigned)((wave + 4 * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
+        if (stamp) p.dbg[step * 8 + 6] = clock64();
         load_g(gpre, step + 1);
+        if (stamp) p.dbg[step * 8 + 7] = clock64();
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1791,7 +1796,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
       XcdArgs xa;
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 7;
       ONSSEN_CLEAR_ERROR();
       switch (ug) {
         case 4: rc = launch_xcd<1>(xa, st); break;
