@@ -181,6 +181,18 @@ def main():
                    "chunks_per_gpu": B, "frames_per_chunk": T_FRAMES, "launch": "hipGraph replay" if graph else "eager",
                    "parallelism": f"utterance-sharded x{world}, no data-path collective"},
     }
+    from onssen_amd.nn._core import _XcdStatus, recurrence_plan
+    torch.cuda.synchronize()
+    _XcdStatus.poll(wait=True)     # raises if a persistent launch aborted
+    for mod in (model, getattr(model, "chimera", None)):      # the graph replays' own status words
+        for buf in (mod._ws.cache.values() if mod is not None else ()):
+            st = buf[1120:1128].cpu().view(torch.int32)
+            if int(st[0]) != 0:
+                raise SystemExit(f"persistent recurrence aborted during the timed region (code {int(st[0])})")
+            _XcdStatus.safe_protocol_seen |= int(st[1]) == 1
+    result["config"]["recurrence"] = ("XCD-local persistent kernel (one launch per layer)" if recurrence_plan(B, H)[1] & 4
+                                      else "one launch per time step")
+    result["config"]["xcd_placement_independent_protocol_used"] = _XcdStatus.safe_protocol_seen
     if rank == 0:
         result["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and kind != "phase_net":
@@ -218,7 +230,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         else:
             lib.linear(A, a_s0, a_s1, B, T * B, K, Wf, ldf, bias, N, mode, group, 1e-12, None, out_ptr, c_s0, c_s1, st())
     y = torch.empty(T, B, 2, Hp, device=dev)
-    ws = torch.empty(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
     xin = torch.randn(B, T, F, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     st = _stream   # evaluated at call time: under graph capture the current stream is the capture stream
@@ -234,7 +246,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
                               [whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
                               ws.numel(), flags, st())
 
-    gbuf = ws[512:]
+    gbuf = ws[4096:]
     F4, F32 = (F + 3) // 4 * 4, (F + 31) // 32 * 32
     K1, K132 = 2 * Hp, (2 * Hp + 31) // 32 * 32
 

@@ -1093,12 +1093,15 @@ struct XcdArgs {
   const unsigned short* whh;    // split-bf16 image [2][NU][KQ2][NT][2][64][8]
   float* y;                     // [T][B][2][Hp]
   unsigned short* hx;           // per group: [2 slots][KQ2][hi|lo][64][8]
-  unsigned* sync;               // [g*32 + m] flags, [256 + g] arrivals, [264 + g] max(xcc+1), [272 + g] max(16-xcc),
-                                // [280] abort, [281] status (1 = some group ran placement-independent protocol)
+  unsigned* sync;               // u32 words: [256 + g] arrivals, [280] abort, u64 pairs at [320 + 4g]: max(xcc+1), max(16-xcc),
+                                // [281] status (1 = some group ran the placement-independent protocol), [288 + g]
+                                // launch generation; u64 flags at byte 2048 + (g*32 + m)*8 (to the end of the 4 KiB header).  The block is zeroed ONCE
+                                // by the workspace owner: everything in it is monotonic, so no launch depends on a
+                                // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
   unsigned spin_limit;
   long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
-  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA
+  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA; test only: 8 = rotate groups over XCDs
 };
 
 template <int NT>
@@ -1110,29 +1113,42 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   constexpr int CPW = 5;                       // k-chunks (32 k) per wave: 4 x 5 x 32 = 640 >= H
   constexpr unsigned kOOB = 0x7ffffff0u;
   __shared__ float red[4 * NT * 4 * RLD];
-  __shared__ unsigned s_ctl[2];                // [0] abort, [1] fast
+  __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.x & 7, ugi = blockIdx.x >> 3;
+  // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
+  // the XCDs instead, so that the placement-independent protocol runs with real cross-XCD traffic
+  const int ugi = blockIdx.x >> 3, g = (p.ablate & 8) ? ((blockIdx.x + ugi) & 7) : (blockIdx.x & 7);
+  if (p.dbg && tid == 0)                       // profiling only: where did the dispatcher put this workgroup?
+    p.dbg[4096 + blockIdx.x] = (long long)(__builtin_amdgcn_s_getreg(6164) & 15u) |
+                               ((long long)__builtin_amdgcn_s_getreg(63492) << 8);   // hwreg(HW_REG_HW_ID)
   if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
   const int dir = g / p.nbg, bg = g % p.nbg;
   const int b0 = p.row0 + bg * 16;
-  unsigned* flags = p.sync + g * 32;
+  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * 32;
   unsigned* abort_w = p.sync + 280;
 
   // ---- placement check: do all members of this group sit on one XCD?
   if (tid == 0) {
     const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    __hip_atomic_fetch_max(p.sync + 264 + g, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_max(p.sync + 272 + g, 16u - xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // launch generation: bumped by member 0 at the very end of every launch, read here by everyone
+    const unsigned gen0 = __hip_atomic_fetch_add(p.sync + 288 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ctl[2] = gen0;
+    // max(xcc+1) and max(16-xcc) of THIS launch: tagged with the generation, so older launches (the dispatcher
+    // may start a launch on another XCD) never win the max
+    unsigned long long* xw = reinterpret_cast<unsigned long long*>(p.sync + 320) + 2 * g;
+    __hip_atomic_fetch_max(xw, ((unsigned long long)gen0 << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(xw + 1, ((unsigned long long)gen0 << 8) | (16u - xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(p.sync + 256 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0, ab = 0;
-    while (__hip_atomic_fetch_add(p.sync + 256 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.NU) {
+    // the arrival counter is never reset: NU arrivals per launch, so launch `gen0` ends at (gen0+1)*NU
+    while (__hip_atomic_fetch_add(p.sync + 256 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen0 * (unsigned)p.NU <
+           (unsigned)p.NU) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
     }
-    const unsigned hi = __hip_atomic_fetch_add(p.sync + 264 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned lo = __hip_atomic_fetch_add(p.sync + 272 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned hi = (unsigned)__hip_atomic_fetch_add(xw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 255u;
+    const unsigned lo = (unsigned)__hip_atomic_fetch_add(xw + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 255u;
     s_ctl[0] = ab;
     s_ctl[1] = (hi + lo == 17u) ? 1u : 0u;     // max(xcc)+1 + 16-min(xcc) == 17  <=>  max == min
     if (ab) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1141,6 +1157,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   __syncthreads();
   if (s_ctl[0]) return;
   const bool fast = s_ctl[1] != 0;
+  const unsigned long long gen = (unsigned long long)s_ctl[2] << 32;   // high half of every flag of this launch
 
   // ---- resident recurrent weights (hi and lo fragments), chunks q = wave, wave+4, ...
   const int fi = lane & 15;
@@ -1195,9 +1212,9 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
         if (wave == 0) {
           unsigned spins = 0, ab = 0;
           for (;;) {
-            const unsigned v = lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : 0xffffffffu;
-            if (__all(v >= (unsigned)step)) break;
+            const unsigned long long v =
+                lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            if (__all(v >= (gen | (unsigned)step))) break;   // stale words of earlier launches carry a smaller generation
             if (!FAST) __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0 &&
                 (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
@@ -1209,6 +1226,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
             s_ctl[0] = ab;
             if (ab) __hip_atomic_store(abort_w, 2u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          if (!FAST) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the producers' release below
         }
         __syncthreads();
         if (s_ctl[0]) return false;
@@ -1297,15 +1315,34 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
       __syncthreads();
       if (stamp) p.dbg[step * 8 + 5] = clock64();
       if (tid == 0) {
-        if (FAST) __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store(flags + ugi, (unsigned)step + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (FAST) {
+          __hip_atomic_store(flags + ugi, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {   // all waves' stores are acknowledged (barrier above): write this XCD's L2 back, then raise the flag
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __hip_atomic_store(flags + ugi, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       return true;
     };
-    for (int step = 0; step < p.T; step += 2) {
-      if (!body(step, gcur, gnext)) break;
-      if (step + 1 < p.T && !body(step + 1, gnext, gcur)) break;
+    bool ok = true;
+    for (int step = 0; ok && step < p.T; step += 2) {
+      ok = body(step, gcur, gnext);
+      if (ok && step + 1 < p.T) ok = body(step + 1, gnext, gcur);
     }
+    // member 0 closes the launch: once every member has published its last step (so nobody can still be
+    // reading the generation), bump it
+    if (ok && ugi == 0 && wave == 0) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long v =
+            lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+        if (__all(v >= (gen | (unsigned)p.T))) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > p.spin_limit) break;
+      }
+    }
+    if (ugi == 0 && tid == 0)
+      __hip_atomic_fetch_add(p.sync + 288 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (fast) run(std::true_type{}); else run(std::false_type{});
 }
@@ -1484,8 +1521,6 @@ static int launch_xcd(XcdArgs xa, hipStream_t st) {
     const int rows = xa.B - r0 < 64 ? xa.B - r0 : 64;
     xa.row0 = r0;
     xa.nbg = ceil_div(rows, 16);
-    hipError_t e = hipMemsetAsync(xa.sync, 0, 2048, st);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((lstm_xcd_kernel<NT>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
   }
   hipError_t e = hipGetLastError();
@@ -1732,7 +1767,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
   const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
-  return 2048 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 2 KiB: exchange flags / status of the XCD-local form
+  return 4096 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 4 KiB: exchange flags / status of the XCD-local form
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -1749,7 +1784,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
   unsigned* syncw = (unsigned*)wsp;
-  wsp += 2048;
+  wsp += 4096;
   float* G = (float*)wsp;
   wsp += align256((size_t)T * B * 2 * NP * sizeof(float));
   float* ybuf = nullptr;
@@ -1796,7 +1831,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
       XcdArgs xa;
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 7;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 15;
       ONSSEN_CLEAR_ERROR();
       switch (ug) {
         case 4: rc = launch_xcd<1>(xa, st); break;

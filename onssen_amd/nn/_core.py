@@ -30,20 +30,64 @@ def precision():
     return p
 
 
+_XCD_DISABLED = [False]      # set when a persistent launch reported an aborted exchange
+
+
 def recurrence_plan(B, H):
-    """(ug, flags) for onssen_blstm_forward_f32: hidden units per recurrence workgroup.  ONSSEN_UG
-    overrides (A/B benches, tests); ONSSEN_ABLATE sets the profiling-only ablation bits."""
-    ug = int(os.environ.get("ONSSEN_UG", "8"))
+    """(ug, flags) for onssen_blstm_forward_f32.
+
+    Split-bf16 precision and H <= 640: the XCD-local persistent recurrence (one launch per layer, every
+    (direction, 16-row group) inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)).  Otherwise one
+    launch per time step with 8 hidden units per workgroup.  ONSSEN_XCD=0 forces the per-step form,
+    ONSSEN_UG overrides its unit-group size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
     flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
-    if precision() == "bf16x3" and H <= 640:
+    x3 = precision() == "bf16x3" and H <= 640
+    if x3:
         flags |= _abi.BLSTM_BF16X3
-        if os.environ.get("ONSSEN_XCD", "0") == "1":
-            # XCD-local persistent recurrence: at most 32 unit groups per direction
-            ug = 4 * -(-H // 128)
-            flags |= _abi.BLSTM_XCD
+    if x3 and os.environ.get("ONSSEN_XCD", "1") == "1" and not _XCD_DISABLED[0]:
+        return 4 * -(-H // 128), flags | _abi.BLSTM_XCD
     if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
         flags |= _abi.BLSTM_SPLIT_ROWS
-    return ug, flags
+    return int(os.environ.get("ONSSEN_UG", "8")), flags
+
+
+class _XcdStatus:
+    """The persistent kernel bounds every wait and reports through two workspace words instead of hanging:
+    [280] != 0 -> a wait gave up, the launch aborted, outputs are invalid; [281] == 1 -> some exchange group was
+    spread over several XCDs and used the slower placement-independent protocol.  They are fetched with an
+    asynchronous copy after each eager forward and examined at the next call (never inside a graph capture),
+    so a failure is reported one call late instead of costing a synchronisation per forward."""
+    pending = []
+    safe_protocol_seen = False
+
+    @classmethod
+    def post(cls, wsb):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(wsb[1120:1128].view(torch.int32), non_blocking=True)     # u32 words 280, 281
+        ev = torch.cuda.Event()
+        ev.record()
+        cls.pending.append((ev, host))
+
+    @classmethod
+    def poll(cls, wait=False):
+        keep = []
+        for ev, host in cls.pending:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host))
+                continue
+            if int(host[1]) == 1:
+                cls.safe_protocol_seen = True
+            if int(host[0]) != 0:
+                cls.pending = []
+                _XCD_DISABLED[0] = True
+                raise _abi.OnssenError(
+                    f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
+                    "of that forward are invalid.  The per-step recurrence is used from now on.")
+        cls.pending = keep
 
 
 class BLSTMParams(nn.Module):
@@ -188,7 +232,7 @@ class _Workspaces:
     def get(self, key, nbytes, device):
         buf = self.cache.get(key)
         if buf is None or buf.numel() < nbytes or buf.device != device:
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # the header must start out zero (ABI)
             self.cache[key] = buf
         return buf
 
@@ -204,6 +248,8 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     lib = get_lib()
     p = packed.p
     B, T, In = x.shape
+    if not torch.cuda.is_current_stream_capturing():
+        _XcdStatus.poll()
     ug, flags = recurrence_plan(B, p.hidden_size)
     pk = packed.get(ug)
     if In != p.input_size:
@@ -217,12 +263,10 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
                       [t.data_ptr() for t in (pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih)],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
-    if (flags & _abi.BLSTM_XCD) and os.environ.get("ONSSEN_CHECK") == "1":   # debug: synchronise, read the status words
-        torch.cuda.synchronize()
-        st = wsb[:2048].cpu().numpy().view("uint32")
-        if st[280] != 0:
-            raise _abi.OnssenError(f"XCD-local recurrence aborted (code {st[280]}): outputs are invalid")
-        run_blstm.last_status = int(st[281])
+    if flags & _abi.BLSTM_XCD:
+        _XcdStatus.post(wsb)
+        if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
+            _XcdStatus.poll(wait=True)
     return y
 
 

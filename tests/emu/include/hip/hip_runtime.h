@@ -183,11 +183,17 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
-template <class T>
-static inline void emu_atomic_store(T* p, T v) {
-  static_assert(sizeof(T) == 4, "4-byte stores only");
-  uint32_t u; memcpy(&u, &v, 4);
-  __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_SEQ_CST);
+template <class T, class V>
+static inline void emu_atomic_store(T* p, V val) {
+  const T v = static_cast<T>(val);
+  if constexpr (sizeof(T) == 8) {
+    uint64_t u; memcpy(&u, &v, 8);
+    __atomic_store_n(reinterpret_cast<uint64_t*>(p), u, __ATOMIC_SEQ_CST);
+  } else {
+    static_assert(sizeof(T) == 4, "4- or 8-byte stores only");
+    uint32_t u; memcpy(&u, &v, 4);
+    __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_SEQ_CST);
+  }
 }
 #define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }

@@ -25,12 +25,15 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["bf16x3", "bf16x3-steps", "f32"])
 def prec(request, monkeypatch):
-    """Both arithmetic modes of the contractions.  Tolerances: exact-fp32 MFMA -> |a-b| <= 1e-5 + 1e-4|b|;
-    split-bf16 (the default; ~1e-5 relative per dot product) -> |a-b| <= 5e-5 + 1e-4|b|; per-vector
-    rel-L2 <= 1e-4 (the north-star figure) in both."""
-    monkeypatch.setenv("ONSSEN_PRECISION", request.param)
+    """The product's three forward paths: split-bf16 with the XCD-local persistent recurrence (default),
+    split-bf16 with one launch per time step, exact-fp32 MFMA (one launch per time step).
+    Tolerances: exact fp32 -> |a-b| <= 1e-5 + 1e-4|b|; split-bf16 (~1e-5 relative per dot product) ->
+    |a-b| <= 5e-5 + 1e-4|b|; per-vector rel-L2 <= 1e-4 (the north-star figure) in all."""
+    monkeypatch.setenv("ONSSEN_PRECISION", request.param.split("-")[0])
+    monkeypatch.setenv("ONSSEN_XCD", "0" if request.param.endswith("steps") else "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
     return {"name": request.param, "atol": 1e-5 if request.param == "f32" else 5e-5}
 
 
@@ -194,7 +197,9 @@ def test_unit_group_variants_agree(dev, monkeypatch, prec, ug):
         np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=prec["atol"], rtol=1e-4)
 
 
-def test_deterministic_and_graph_replay(dev):
+@pytest.mark.parametrize("xcd", ["1", "0"])
+def test_deterministic_and_graph_replay(dev, monkeypatch, xcd):
+    monkeypatch.setenv("ONSSEN_XCD", xcd)
     cfg = dict(F=129, H=64, L=2, D=20, C=2, seed=2, gain=1.0)
     m, _ = build("deep_clustering", cfg, dev)
     x = torch.from_numpy(logmag_input(13, 4, 40)).to(dev)
@@ -371,7 +376,29 @@ def test_xcd_local_persistent_recurrence(dev, monkeypatch, B, T, H, L):
         emb = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
         emb2 = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
     print(f"xcd-local B={B} T={T} H={H}: max abs err {np.abs(emb - ref).max():.3e}, placement-independent protocol used: "
-          f"{getattr(_core.run_blstm, 'last_status', None)}")
+          f"{_core._XcdStatus.safe_protocol_seen}")
     np.testing.assert_allclose(emb, ref, atol=5e-5, rtol=1e-4)
     assert rel_l2(emb, ref).max() < 1e-4
+    np.testing.assert_array_equal(emb, emb2)
+
+
+@pytest.mark.parametrize("B,T,H,L", [(64, 60, 600, 2), (33, 21, 300, 3)])
+def test_xcd_placement_independent_protocol(dev, monkeypatch, B, T, H, L):
+    """Test bit 8 of the debug flags rotates the exchange groups across the XCDs: the kernel must notice (XCC ids
+    disagree), switch to the write-through / agent-fence protocol, and still match the oracle."""
+    from onssen_amd.nn import _core
+    monkeypatch.setenv("ONSSEN_XCD", "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    monkeypatch.setenv("ONSSEN_ABLATE", "8")
+    _core._XcdStatus.safe_protocol_seen = False
+    cfg = dict(F=129, H=H, L=L, D=20, C=2, seed=3, gain=1.0)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = logmag_input(12, B, T)
+    ref = TC.deep_clustering_forward(sd, x).numpy()
+    with torch.no_grad():
+        emb = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
+        emb2 = m([torch.from_numpy(x).to(dev)])[0].cpu().numpy()
+    assert _core._XcdStatus.safe_protocol_seen
+    np.testing.assert_allclose(emb, ref, atol=5e-5, rtol=1e-4)
     np.testing.assert_array_equal(emb, emb2)

@@ -40,9 +40,9 @@ for ug in (8, 12, 16):
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
     y = torch.empty(T, B, 2, Hp, device=dev)
-    ws = torch.empty(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
-    gbuf = ws[512:]
+    gbuf = ws[4096:]
 
     def gemm():
         lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,
