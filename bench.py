@@ -212,6 +212,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     of a single-layer call minus its input-projection GEMM.  Launch-per-step form: the span of the T
     dependent launches / T (includes the dependent-launch gap the serial chain really pays)."""
     from onssen_amd.features import stft_logmag
+    from onssen_amd import _abi
     from onssen_amd.hip import get_lib
     from onssen_amd.nn._core import _stream, recurrence_plan
     lib = get_lib()
@@ -246,7 +247,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
                               [whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
                               ws.numel(), flags, st())
 
-    gbuf = ws[4096:]
+    gbuf = ws[_abi.BLSTM_WS_HEADER:]
     F4, F32 = (F + 3) // 4 * 4, (F + 31) // 32 * 32
     K1, K132 = 2 * Hp, (2 * Hp + 31) // 32 * 32
 

@@ -139,11 +139,17 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
  *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of L device pointers; entry l holds both
  *             directions back to back: wih [2*NP][Kp_l], whh [2][whh_elems], bias [2*NP]
  *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0
- *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned
- * One input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph to
- * amortise launch cost.  (A one-launch-per-layer persistent form with in-launch h exchange was built
- * and measured slower than kernel boundaries on this chip -- DESIGN.md, "Recurrence: what was tried".)
+ *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned.  Its first
+ *             ONSSEN_BLSTM_WS_HEADER_BYTES hold the exchange state of the ONSSEN_BLSTM_XCD form (flags,
+ *             generations, status words): the OWNER zeroes them once when the workspace is allocated and never
+ *             again -- everything in there is monotonic, and no call memsets it (so a hipGraph replay does not
+ *             depend on a memset node reaching the kernel's L2).  u32 word [280] != 0: a launch gave up waiting
+ *             (outputs invalid); word [281] = 1: some launch used the placement-independent protocol.
+ * Default form: one input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph
+ * to amortise launch cost.  ONSSEN_BLSTM_XCD: one GEMM + ONE persistent launch per layer (DESIGN.md,
+ * "XCD-local persistent recurrence").
  */
+#define ONSSEN_BLSTM_WS_HEADER_BYTES 16384
 size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug);
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,

@@ -1095,7 +1095,7 @@ struct XcdArgs {
   unsigned short* hx;           // per group: [2 slots][KQ2][hi|lo][64][8]
   unsigned* sync;               // u32 words: [256 + g] arrivals, [280] abort, u64 pairs at [320 + 4g]: max(xcc+1), max(16-xcc),
                                 // [281] status (1 = some group ran the placement-independent protocol), [288 + g]
-                                // launch generation; u64 flags at byte 2048 + (g*32 + m)*8 (to the end of the 4 KiB header).  The block is zeroed ONCE
+                                // launch generation; u64 flags at byte 2048 + ((g*32 + m)*4 + wave)*8 (8 KiB).  The block is zeroed ONCE
                                 // by the workspace owner: everything in it is monotonic, so no launch depends on a
                                 // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   constexpr int EPT = (NE + 255) / 256;
   constexpr int CPW = 5;                       // k-chunks (32 k) per wave: 4 x 5 x 32 = 640 >= H
   constexpr unsigned kOOB = 0x7ffffff0u;
-  __shared__ float red[4 * NT * 4 * RLD];
+  __shared__ float red[2 * 4 * NT * 4 * RLD];   // two step parities
   __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
   const int dir = g / p.nbg, bg = g % p.nbg;
   const int b0 = p.row0 + bg * 16;
-  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * 32;
+  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * 128;   // [member][wave]
   unsigned* abort_w = p.sync + 280;
 
   // ---- placement check: do all members of this group sit on one XCD?
@@ -1178,60 +1178,83 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
   for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
   const long hx_group = (long)g * 2 * p.KQ2 * 1024;             // uint16 elements per group (two slots)
-
   const bool stamp = p.dbg && tid == 0 && blockIdx.x == 0;
+
+  // ---- per-thread constants of the cell update: element e = (row, ju) of this member's 16 x UG tile
+  bool e_ok[EPT], e_inb[EPT];
+  long g_off[EPT], y_off[EPT];          // float offsets at t = 0
+  unsigned hx_off[EPT];                 // byte offset inside a hand-off slot
+  int red_off[EPT][4];                  // LDS float offset of the wave-0 partial of each gate
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) {
+    const int e = tid + 256 * i;
+    const int row = (e / UG) & 15, ju = e % UG, b = b0 + row, k = ugi * UG + ju;
+    e_ok[i] = e < NE;
+    e_inb[i] = e_ok[i] && b < p.B;
+    g_off[i] = ((long)b * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4;
+    y_off[i] = ((long)b * 2 + dir) * p.Hp + k;
+    hx_off[i] = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt) {
+      const int pl = gt * UG + ju;
+      red_off[i][gt] = ((pl >> 4) * 4 + (row & 3)) * RLD + ((row >> 2) << 4) + (pl & 15);
+    }
+  }
+  const long g_step = (long)p.B * 2 * p.NP, y_step = (long)p.B * 2 * p.Hp;
   // input projection of a step: loaded one step AHEAD into a second register set.  Waiting for the h fragments
   // (vmcnt retires in order) would otherwise also wait for these older, HBM-cold loads on the critical path.
   auto load_g = [&](float (&gp)[EPT][4], int step) {
     const int t = dir == 0 ? step : p.T - 1 - step;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / UG, ju = e % UG, b = b0 + row;
-      const bool ok = (e < NE) && (b < p.B) && (step < p.T) && !(p.ablate & 2);
-      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + ((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = e_inb[i] && (step < p.T) && !(p.ablate & 2);
+      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + g_off[i] + t * g_step) : make_float4(0.f, 0.f, 0.f, 0.f);
       gp[i][0] = g4.x; gp[i][1] = g4.y; gp[i][2] = g4.z; gp[i][3] = g4.w;
     }
   };
   float gcur[EPT][4], gnext[EPT][4];
   load_g(gcur, 0);
 
+  // One flag per WAVE of every member (128 per group, 1 KiB): a wave raises its own flag as soon as its own
+  // stores are acknowledged, and every wave polls for itself with one 16-byte load per lane -- no workgroup
+  // barrier on either side of the exchange.  The only barrier of a step is the one between the per-wave
+  // partial sums and the cell update; `red` is double-buffered so that this one barrier suffices.
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)flags, 0, 1024, 0x00020000);
+  bool gave_up = false;                          // after a timeout nobody waits any more: the launch drains
+                                                 // with garbage and the abort word tells the host
   // the loop body exists twice: L2-local protocol (FAST) and placement-independent protocol
   auto run = [&](auto fast_c) {
     constexpr bool FAST = decltype(fast_c)::value;
     constexpr int LD_AUX = FAST ? 16 : 17;       // sc1: bypass L1, served by this XCD's L2 | sc0 sc1: coherent anywhere
     constexpr int ST_AUX = FAST ? 0 : 16;        // plain (line stays in L2) | sc1 write-through
+    auto wait_flags = [&](unsigned want_lo) {    // until every wave of every member has published `want_lo`
+      if (gave_up) return;
+      const unsigned long long want = gen | want_lo;
+      unsigned spins = 0;
+      for (;;) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)lane * 16u, 0, LD_AUX);
+        const unsigned long long f0 = ((unsigned long long)v[1] << 32) | v[0], f1 = ((unsigned long long)v[3] << 32) | v[2];
+        const bool ready = (2 * lane >= 4 * p.NU) || (f0 >= want && f1 >= want);   // stale words carry an older generation
+        if (__all(ready)) break;
+        if (!FAST) __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0 &&
+            (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          if (lane == 0) __hip_atomic_store(abort_w, 2u + want_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gave_up = true;
+          break;
+        }
+      }
+      if (!FAST) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the producers' release below
+    };
     // one time step; `guse` holds this step's input projection, `gpre` receives the next step's (the two
     // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
-    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4]) -> bool {
+    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4]) {
       const int t = dir == 0 ? step : p.T - 1 - step;
+      float* redb = red + (step & 1) * (4 * NT * 4 * RLD);
       if (stamp) p.dbg[step * 8 + 0] = clock64();
       if (step > 0) {
-        // ---- wait until every member's flag says "h of step-1 published": one 32-lane load per poll
-        if (wave == 0) {
-          unsigned spins = 0, ab = 0;
-          for (;;) {
-            const unsigned long long v =
-                lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-            if (__all(v >= (gen | (unsigned)step))) break;   // stale words of earlier launches carry a smaller generation
-            if (!FAST) __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63u) == 0 &&
-                (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-              ab = 1;
-              break;
-            }
-          }
-          if (lane == 0) {
-            s_ctl[0] = ab;
-            if (ab) __hip_atomic_store(abort_w, 2u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (!FAST) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the producers' release below
-        }
-        __syncthreads();
-        if (s_ctl[0]) return false;
+        wait_flags((unsigned)step);
         if (stamp) p.dbg[step * 8 + 1] = clock64();
-
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
         u32x4 a[CPW][2];
@@ -1247,22 +1270,25 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(p.ablate & 4)) {
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) {
-          if (wave + 4 * i < p.KQ2) {
-            const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
+          for (int i = 0; i < CPW; ++i) {
+            if (wave + 4 * i < p.KQ2) {
+              const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
+              // term-major: NT independent accumulators between two MFMAs on the same one
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
-              acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
-              acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
             }
           }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
+          for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
         if (stamp) p.dbg[step * 8 + 2] = clock64();
         __syncthreads();
         if (stamp) p.dbg[step * 8 + 3] = clock64();
@@ -1272,7 +1298,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wave * NT + nt) * 4 + r) * RLD + lane] = 0.0f;
+          for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = 0.0f;
         __syncthreads();
       }
 
@@ -1281,15 +1307,12 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
           (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
-        const int e = tid + 256 * i;
-        const int row = e / UG, ju = e % UG, b = b0 + row;
-        if (e < NE) {
+        if (e_ok[i]) {
           // 16 independent LDS reads (4 gates x 4 wave partials) issued together, then summed
           float part[4][4], pre[4];
 #pragma unroll
           for (int gt = 0; gt < 4; ++gt) {
-            const int pl = gt * UG + ju;
-            const float* src = red + ((pl >> 4) * 4 + (row & 3)) * RLD + ((row >> 2) << 4) + (pl & 15);
+            const float* src = redb + red_off[i][gt];
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) part[gt][wv] = src[wv * NT * 4 * RLD];
           }
@@ -1299,50 +1322,37 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
           const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
           const float cn = fg2 * cst[i] + ig * gg;
           cst[i] = cn;
-          const float h = (b < p.B) ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
+          const float h = e_inb[i] ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
           unsigned short hi, lo;
           split_bf16(h, hi, lo);
-          const int k = ugi * UG + ju;
-          const unsigned off = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
-          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, off, 0, ST_AUX);
-          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, off + 1024, 0, ST_AUX);
-          if (b < p.B) p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + k] = h;
+          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, hx_off[i], 0, ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, hx_off[i] + 1024, 0, ST_AUX);
+          if (e_inb[i]) p.y[y_off[i] + t * y_step] = h;
         }
       }
-      // every storing wave drains its stores (acknowledged by L2 / by memory), then one lane raises the flag
+      // this wave's stores are acknowledged (by L2 / by memory) -> raise this wave's flag
       if (stamp) p.dbg[step * 8 + 4] = clock64();
       __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
-      __syncthreads();
       if (stamp) p.dbg[step * 8 + 5] = clock64();
-      if (tid == 0) {
+      if (lane == 0) {
         if (FAST) {
-          __hip_atomic_store(flags + ugi, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {   // all waves' stores are acknowledged (barrier above): write this XCD's L2 back, then raise the flag
+          __hip_atomic_store(flags + ugi * 4 + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {   // write this XCD's L2 back, then raise the flag
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __hip_atomic_store(flags + ugi, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(flags + ugi * 4 + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      return true;
     };
-    bool ok = true;
-    for (int step = 0; ok && step < p.T; step += 2) {
-      ok = body(step, gcur, gnext);
-      if (ok && step + 1 < p.T) ok = body(step + 1, gnext, gcur);
+    for (int step = 0; step < p.T; step += 2) {
+      body(step, gcur, gnext);
+      if (step + 1 < p.T) body(step + 1, gnext, gcur);
     }
-    // member 0 closes the launch: once every member has published its last step (so nobody can still be
-    // reading the generation), bump it
-    if (ok && ugi == 0 && wave == 0) {
-      unsigned spins = 0;
-      for (;;) {
-        const unsigned long long v =
-            lane < p.NU ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
-        if (__all(v >= (gen | (unsigned)p.T))) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > p.spin_limit) break;
-      }
+    // member 0 closes the launch: once every wave of the group has published its last step (so nobody can
+    // still be comparing against this generation), bump it
+    if (ugi == 0 && wave == 0) {
+      wait_flags((unsigned)p.T);
+      if (lane == 0) __hip_atomic_fetch_add(p.sync + 288 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (ugi == 0 && tid == 0)
-      __hip_atomic_fetch_add(p.sync + 288 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   if (fast) run(std::true_type{}); else run(std::false_type{});
 }
@@ -1767,7 +1777,7 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
   const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
   const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
   const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
-  return 4096 + g + (L > 1 ? y : 0) + c + hs + 65536;   // leading 4 KiB: exchange flags / status of the XCD-local form
+  return ONSSEN_BLSTM_WS_HEADER_BYTES + g + (L > 1 ? y : 0) + c + hs + 65536;   // header: exchange state of the XCD-local form
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -1784,7 +1794,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
   unsigned* syncw = (unsigned*)wsp;
-  wsp += 4096;
+  wsp += ONSSEN_BLSTM_WS_HEADER_BYTES;
   float* G = (float*)wsp;
   wsp += align256((size_t)T * B * 2 * NP * sizeof(float));
   float* ybuf = nullptr;

@@ -197,7 +197,13 @@ static inline void emu_atomic_store(T* p, V val) {
 }
 #define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
-static inline void __builtin_amdgcn_s_waitcnt(int) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// a wave executes s_waitcnt once for all of its lanes: here the lanes are threads, so "every earlier store of
+// this WAVE is visible" needs a wave rendezvous (call it from wave-uniform control flow only)
+static inline void __builtin_amdgcn_s_waitcnt(int) {
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  emu::wave_sync();
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
 struct __amdgpu_buffer_rsrc_t { char* base; int bytes; };
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int bytes, int) {
   return {static_cast<char*>(p), bytes};

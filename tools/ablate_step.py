@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from onssen_amd import nn as onn  # noqa: E402
+from onssen_amd import _abi, nn as onn  # noqa: E402
 from onssen_amd.hip import get_lib  # noqa: E402
 from onssen_amd.nn._core import _stream  # noqa: E402
 
@@ -42,7 +42,7 @@ for ug in (8, 12, 16):
     y = torch.empty(T, B, 2, Hp, device=dev)
     ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
-    gbuf = ws[4096:]
+    gbuf = ws[_abi.BLSTM_WS_HEADER:]
 
     def gemm():
         lib.linear(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, pk.wih[1].data_ptr(), 2 * Hp,

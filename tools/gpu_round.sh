@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 300 python tools/xcd_case_probe.py 2>&1 | grep -v amdgpu.ids | tail -16
+for ab in 0 4; do AB=$ab timeout 120 python tools/xcd_timeline.py 2>&1 | grep -v amdgpu.ids | tail -3; done
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 timeout 200 python tools/xcd_graph_probe.py 2>&1 | tail -6
 for c in dc_l2 chimera_l4; do
