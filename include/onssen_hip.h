@@ -131,6 +131,19 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
                          int ldw, const float* bias, int N, int mode, int group, float eps, const float* resid,
                          float* C, int64_t c_s0, int64_t c_s1, void* stream);
 
+/* Split-bf16 GEMM over PRE-SPLIT operands.  An "x3 image" of a row-major [rows][K] fp32 matrix is
+ * [rows][KB][2][32] bf16, KB = ceil(K/32): per row and 32-wide k block, 32 x hi = bf16(x) then 32 x lo =
+ * bf16(x - hi), zeros beyond K (16-byte aligned).  onssen_x3_image_f32 builds one from fp32 rows (row m at
+ * src + (m / R)*s0 + (m % R)*s1); the BLSTM's split-bf16 recurrence writes its output in this form as well.
+ *   C row m at C + (m / R)*c_s0 + (m % R)*c_s1 = epilogue(a_img[m] . w_img[n] + bias[n]), n < N
+ *   mode BIAS | SIGMOID | L2NORM (group in {20, 40, 80}: multiple of 4 dividing 80, N % group == 0; no residual).
+ * Same arithmetic as onssen_linear_bf16x3 (three bf16 MFMAs per product, fp32 accumulate); ~2x its speed because
+ * staging is a plain copy and the epilogue stays in registers.
+ */
+int onssen_x3_image_f32(const float* src, int64_t s0, int64_t s1, int R, int rows, int K, uint16_t* img, void* stream);
+int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
+                      int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3+K4  stacked bidirectional LSTM, eval semantics (zero initial state, no dropout).
  * Replaces `rnn_output, hidden = self.rnn(x)` (onssen/nn/deep_clustering.py:35, chimera.py:35,

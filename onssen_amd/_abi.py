@@ -30,6 +30,8 @@ SIGNATURES = {
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_linear_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_linear_bf16x3": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
+    "onssen_x3_image_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _vp]),
+    "onssen_linear_x3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -104,6 +106,13 @@ class Lib:
                       stream):
         self.check(self.dll.onssen_linear_bf16x3(A, a_s0, a_s1, R, M, K, planes, ldw, bias, N, mode, group, eps, resid,
                                                  Cp, c_s0, c_s1, stream), "onssen_linear_bf16x3")
+
+    def x3_image(self, src, s0, s1, R, rows, K, img, stream):
+        self.check(self.dll.onssen_x3_image_f32(src, s0, s1, R, rows, K, img, stream), "onssen_x3_image_f32")
+
+    def linear_x3p(self, a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream):
+        self.check(self.dll.onssen_linear_x3p(a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream),
+                   "onssen_linear_x3p")
 
     def blstm_forward(self, x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_ptrs, whh_ptrs, bias_ptrs, y, ws, ws_bytes,
                       flags, stream):

@@ -653,6 +653,273 @@ __global__ void pack_w_bf16x3_kernel(const float* __restrict__ w, int N, int K, 
 
 
 // =================================================================================================
+// K3/K7/K8, split-bf16 form over PRE-SPLIT operands ("x3 images").
+//
+// x3 image of a row-major [rows][K] fp32 matrix:  [rows][KB][2][32] bf16, KB = ceil(K/32): for every row and
+// 32-wide k block, 64 bytes of hi = bf16(x) followed by 64 bytes of lo = bf16(x - hi) (zeros beyond K).  One
+// 128-byte cache line per (row, k-step), for the activations (written in this form by the recurrence epilogue
+// or by x3_image_kernel) and for the weights (packed once).
+//
+// 256x160 tile, 256 threads = 4 waves (2 along M x 2 along N), 128x80 per wave = 8x5 MFMA tiles, 120 MFMAs per
+// wave and 32-wide k-step.  Staging is a plain copy (16-byte buffer loads with out-of-range -> 0, no VALU), LDS
+// is double-buffered so a k-step costs ONE barrier, and the next tile's LDS writes / the one after's global
+// loads are spread between the MFMAs of the current one.  The MFMA operands are swapped (A operand = W rows,
+// B operand = activation rows) so that a lane ends up with 4 CONSECUTIVE output features of one row: the
+// epilogue (bias, sigmoid, grouped L2 normalisation) runs in registers and stores 16 bytes per lane.
+// =================================================================================================
+namespace lxp {
+constexpr int BM = 256, BN = 160;
+constexpr int RS = 144;                      // LDS row stride in bytes: 128 + 16 pad (conflict-free 16-byte fragment reads)
+constexpr int STAGE = (BM + BN) * RS;        // 59,904 B per stage, two stages
+constexpr int A_IT = BM / 32, W_IT = BN / 32;   // 16-byte chunks per thread per k-step: 8 + 5
+}  // namespace lxp
+
+struct LinearXpArgs {
+  const unsigned short* A;      // x3 image [M][KB][2][32]
+  const unsigned short* W;      // x3 image [N][KB][2][32]
+  const float* bias;
+  float* C;
+  long c_s0, c_s1;
+  int R, M, N, KB, group;
+  float eps;
+  int tile_group;
+  int c_vec;                    // C rows 16-byte aligned and N % 4 == 0
+};
+
+// profiling builds only (-DONSSEN_XP_ABLATE=bits; compile time, a run-time test per load would wreck the
+// schedule being measured): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no fragment reads, 16 no C stores
+#ifndef ONSSEN_XP_ABLATE
+#define ONSSEN_XP_ABLATE 0
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
+  using namespace lxp;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 15, fg = lane >> 4;
+  // XCD-aware tile order (as linear_x3_kernel): each XCD walks a contiguous run of tiles, in column groups of GN
+  int n0, m0;
+  {
+    const int nbx = gridDim.x, nwg = nbx * gridDim.y, bid = blockIdx.y * nbx + blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GN = p.tile_group, nby = gridDim.y;
+    const int gfull = nbx / GN, nfull = gfull * GN * nby;
+    int tn, tm;
+    if (wg < nfull) {
+      const int rem = wg % (nby * GN);
+      tn = (wg / (nby * GN)) * GN + rem % GN;
+      tm = rem / GN;
+    } else {
+      const int gl = nbx - gfull * GN, rem = wg - nfull;
+      tn = gfull * GN + rem % gl;
+      tm = rem / gl;
+    }
+    n0 = tn * BN;
+    m0 = tm * BM;
+  }
+  const int pitch = p.KB * 128;                // bytes per image row
+  const int a_rows = p.M - m0 < BM ? p.M - m0 : BM, w_rows = p.N - n0 < BN ? p.N - n0 : BN;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + (long)m0 * p.KB * 64), 0, a_rows * pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.W + (long)n0 * p.KB * 64), 0, w_rows * pitch, 0x00020000);
+  // staging: thread -> (row = tid/8 + 32*it, 16-byte chunk tid%8); rows past the matrix are out of range -> 0
+  const int srow = tid >> 3, sch = tid & 7;
+  const unsigned g_voff = (unsigned)(srow * pitch + sch * 16);
+  const unsigned l_off = (unsigned)(srow * RS + sch * 16);
+  // two staging register sets: set (t & 1) carries tile t from its global load, issued THREE k-steps before the
+  // tile is multiplied (L2 -> CU round trips under this load are longer than one k-step), to its LDS write one
+  // k-step before
+  constexpr int NJ = A_IT + W_IT;
+  u32x4 rg[2][NJ];
+  auto g_load1 = [&](auto set_c, int j, int kb) {
+    constexpr int S = decltype(set_c)::value;
+    if constexpr ((ONSSEN_XP_ABLATE & 1) != 0) return;
+    // the k offset rides in the (range-checked) vector offset and k blocks past the matrix are sent out of range:
+    // they read zeros, never memory -- so the loop needs no "is there a next tile" predicate, its body exists
+    // exactly once per parity, and an odd number of k-steps is rounded up with a tile of zeros
+    const unsigned koff = kb < p.KB ? (unsigned)(kb * 128) : 0x40000000u;
+    if (j < A_IT) rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, g_voff + (unsigned)(j * 32 * pitch) + koff, 0, 0);
+    else rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, g_voff + (unsigned)((j - A_IT) * 32 * pitch) + koff, 0, 0);
+  };
+  auto s_store1 = [&](auto set_c, int j, int stage) {
+    constexpr int S = decltype(set_c)::value;
+    if constexpr ((ONSSEN_XP_ABLATE & 2) != 0) return;
+    unsigned char* base = smem + stage * STAGE + (j < A_IT ? j * 32 * RS : BM * RS + (j - A_IT) * 32 * RS);
+    *reinterpret_cast<u32x4*>(base + l_off) = rg[S][j];
+  };
+
+  f32x4 acc[8][5];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#ifdef ONSSEN_XP_CLOCK
+  const long long clk0 = clock64(), wclk0 = wall_clock64();
+#endif
+  const int nkb = p.KB;
+  const unsigned fa_off = (unsigned)((wm * 128 + fi) * RS + fg * 16);             // + mt*16*RS (+64 for lo)
+  const unsigned fw_off = (unsigned)(BM * RS + (wn * 80 + fi) * RS + fg * 16);    // + nt*16*RS (+64 for lo)
+  constexpr bool FR = (ONSSEN_XP_ABLATE & 8) == 0;
+  auto frag = [&](const unsigned char* sb, unsigned off) {
+    if constexpr (FR) return *reinterpret_cast<const s16x8*>(sb + off);
+    else return s16x8{(short)off, 1, 2, 3, 4, 5, 6, 7};
+  };
+  using c0 = std::integral_constant<int, 0>;
+  using c1 = std::integral_constant<int, 1>;
+
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) g_load1(c0{}, j, 0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) s_store1(c0{}, j, 0);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) g_load1(c1{}, j, 1);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) g_load1(c0{}, j, 2);
+  __syncthreads();
+
+  // k-step kb of parity E (tile kb sits in LDS stage E): tile kb+1 goes from staging set E^1 into stage E^1 and
+  // tile kb+3 is requested into the same set, spread between the five column tiles' MFMAs.  One barrier.
+  auto kstep = [&](int kb, auto e_c) {
+    constexpr int E = decltype(e_c)::value;
+    using eo = std::integral_constant<int, E ^ 1>;
+    const unsigned char* sb = smem + E * STAGE;
+    s16x8 xh[8], xl[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      xh[mt] = frag(sb, fa_off + mt * 16 * RS);
+      xl[mt] = frag(sb, fa_off + mt * 16 * RS + 64);
+    }
+    s16x8 wh = frag(sb, fw_off), wl = frag(sb, fw_off + 64);
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      s16x8 wh2 = wh, wl2 = wl;
+      if (nt + 1 < 5) {   // next column tile's fragments land behind this one's 24 MFMAs
+        wh2 = frag(sb, fw_off + (nt + 1) * 16 * RS);
+        wl2 = frag(sb, fw_off + (nt + 1) * 16 * RS + 64);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (j >= nt * NJ / 5 && j < (nt + 1) * NJ / 5) {
+          s_store1(eo{}, j, E ^ 1);
+          g_load1(eo{}, j, kb + 3);
+        }
+      }
+      if constexpr ((ONSSEN_XP_ABLATE & 4) != 0) {
+        acc[0][nt][0] += (float)(wh[0] + wl[0] + xh[nt][0] + xl[nt][0] + xh[nt + 3][0] + xl[nt + 3][0]);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          acc[mt][nt] = mfma_bf16(wh, xl[mt], acc[mt][nt]);   // small terms first
+          acc[mt][nt] = mfma_bf16(wl, xh[mt], acc[mt][nt]);
+          acc[mt][nt] = mfma_bf16(wh, xh[mt], acc[mt][nt]);
+        }
+      }
+      wh = wh2;
+      wl = wl2;
+    }
+    __syncthreads();
+  };
+  for (int kb = 0; kb < nkb; kb += 2) {
+    kstep(kb, c0{});
+    kstep(kb + 1, c1{});
+  }
+
+#ifdef ONSSEN_XP_CLOCK   // profiling builds: shader clocks and 100 MHz ticks of the main loop of workgroup 0 -> C[0], C[1]
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    p.C[0] = (float)(clock64() - clk0);
+    p.C[1] = (float)(wall_clock64() - wclk0);
+    return;
+  }
+#endif
+  // ---- epilogue in registers: lane holds, per (mt, nt), features n = n0 + wn*80 + nt*16 + 4*fg + {0..3} of row
+  //      m = m0 + wm*128 + mt*16 + fi
+  float4 bv[5];
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+    const int n = n0 + wn * 80 + nt * 16 + 4 * fg;
+    bv[nt].x = n + 0 < p.N ? p.bias[n + 0] : 0.f;
+    bv[nt].y = n + 1 < p.N ? p.bias[n + 1] : 0.f;
+    bv[nt].z = n + 2 < p.N ? p.bias[n + 2] : 0.f;
+    bv[nt].w = n + 3 < p.N ? p.bias[n + 3] : 0.f;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + wm * 128 + mt * 16 + fi;
+    float4 v[5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt)
+      v[nt] = make_float4(acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
+                          acc[mt][nt][3] + bv[nt].w);
+    if (MODE == ONSSEN_EPI_L2NORM) {
+      // groups of p.group consecutive features (group % 4 == 0, 80 % group == 0, at most 4 groups per wave):
+      // a lane's float4 never straddles a group; partial sums per group, then across the 4 lane groups
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const int q = (nt * 16 + 4 * fg) / p.group;
+        const float s4 = v[nt].x * v[nt].x + v[nt].y * v[nt].y + v[nt].z * v[nt].z + v[nt].w * v[nt].w;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) part[qq] += (q == qq) ? s4 : 0.f;
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        part[qq] += __shfl_xor(part[qq], 16);
+        part[qq] += __shfl_xor(part[qq], 32);
+        part[qq] = 1.0f / fmaxf(sqrtf(part[qq]), p.eps);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const int q = (nt * 16 + 4 * fg) / p.group;
+        const float sc = q == 0 ? part[0] : q == 1 ? part[1] : q == 2 ? part[2] : part[3];
+        // x / max(||x||, eps) like F.normalize: multiply by the reciprocal of the clamped norm
+        v[nt].x *= sc; v[nt].y *= sc; v[nt].z *= sc; v[nt].w *= sc;
+      }
+    } else if (MODE == ONSSEN_EPI_SIGMOID) {
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        v[nt].x = 1.0f / (1.0f + expf(-v[nt].x)); v[nt].y = 1.0f / (1.0f + expf(-v[nt].y));
+        v[nt].z = 1.0f / (1.0f + expf(-v[nt].z)); v[nt].w = 1.0f / (1.0f + expf(-v[nt].w));
+      }
+    }
+    if (m < p.M && ((ONSSEN_XP_ABLATE & 16) == 0 || v[0].x == 123.456f)) {
+      float* crow = p.C + (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1;
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) {
+        const int n = n0 + wn * 80 + nt * 16 + 4 * fg;
+        if (p.c_vec) {
+          if (n < p.N) *reinterpret_cast<float4*>(crow + n) = v[nt];
+        } else {
+          if (n + 0 < p.N) crow[n + 0] = v[nt].x;
+          if (n + 1 < p.N) crow[n + 1] = v[nt].y;
+          if (n + 2 < p.N) crow[n + 2] = v[nt].z;
+          if (n + 3 < p.N) crow[n + 3] = v[nt].w;
+        }
+      }
+    }
+  }
+}
+
+// fp32 rows (row m at src + (m / R)*s0 + (m % R)*s1, K contiguous) -> x3 image [rows][KB][2][32]
+__global__ void x3_image_kernel(const float* __restrict__ src, long s0, long s1, int R, int rows, int K, int KB,
+                                unsigned short* __restrict__ img) {
+  const long total = (long)rows * KB * 32;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(e & 31);
+    const long rb = e >> 5;                       // row * KB + kblock
+    const int m = (int)(rb / KB), k = (int)(rb % KB) * 32 + kk;
+    unsigned short h, l;
+    split_bf16(k < K ? src[(long)(m / R) * s0 + (long)(m % R) * s1 + k] : 0.0f, h, l);
+    img[rb * 64 + kk] = h;
+    img[rb * 64 + 32 + kk] = l;
+  }
+}
+
+// =================================================================================================
 // N3: training-label features from the three complex STFTs (mix, s1, s2) of a chunk
 // (onssen/data/feature_utils.py:77-95 get_cos_difference / get_one_hot, wsj0_2mix.py:130-152)
 // =================================================================================================
@@ -1764,6 +2031,46 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
     return ONSSEN_E_ARG;
   }
 #undef ONSSEN_LINX3
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+
+int onssen_x3_image_f32(const float* src, int64_t s0, int64_t s1, int R, int rows, int K, uint16_t* img, void* stream) {
+  if (!src || !img || R <= 0 || rows <= 0 || K <= 0) return ONSSEN_E_ARG;
+  if (!aligned16(img)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  const int KB = ceil_div(K, 32);
+  const long n = (long)rows * KB * 32;
+  hipLaunchKernelGGL(x3_image_kernel, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (long)s0, (long)s1, R, rows, K, KB, img);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
+                      int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream) {
+  if (!a_img || !w_img || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0) return ONSSEN_E_ARG;
+  if (!aligned16(a_img) || !aligned16(w_img)) return ONSSEN_E_ALIGN;
+  const int KB = ceil_div(K, 32);
+  if ((long)lxp::BM * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
+  if (mode == ONSSEN_EPI_L2NORM) {
+    if (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4 || (N % group) != 0) return ONSSEN_E_ARG;
+  } else if (mode != ONSSEN_EPI_BIAS && mode != ONSSEN_EPI_SIGMOID) {
+    return ONSSEN_E_ARG;
+  }
+  ONSSEN_CLEAR_ERROR();
+  LinearXpArgs p;
+  p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
+  p.KB = KB; p.group = group; p.eps = eps;
+  static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
+  p.tile_group = x3_gn < 1 ? 1 : x3_gn;
+  p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
+  const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == ONSSEN_EPI_BIAS) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS>), grid, block, 0, st, p);
+  else if (mode == ONSSEN_EPI_L2NORM) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_L2NORM>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_SIGMOID>), grid, block, 0, st, p);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

@@ -230,6 +230,41 @@ def test_linear_split_bf16(lib, mode, group, K):
     np.testing.assert_allclose(out, ref, atol=2e-3 if group == 2 else 3e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("mode,group,K", [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40),
+                                          (_abi.EPI_L2NORM, 40, 33)])
+def test_linear_x3_images(lib, mode, group, K):
+    """onssen_x3_image_f32 + onssen_linear_x3p (pre-split operands, 256x160 tile, register epilogue): ragged M/N/K,
+    strided A rows and C rows, all epilogues."""
+    rng = np.random.default_rng(8)
+    Bb, Tt, N = 3, 91, 200           # M = 273 (2 row blocks), N = 200 (2 column blocks)
+    x = rand(rng, Bb, Tt, K)
+    W = rand(rng, N, K)
+    bias = rand(rng, N)
+    KB = (K + 31) // 32
+    M = Bb * Tt
+    a_img = np.full((M, KB, 2, 32), 0x7fc0, np.uint16)     # NaN patterns: the kernel must overwrite all of it
+    w_img = np.full((N, KB, 2, 32), 0x7fc0, np.uint16)
+    # activations time-major like the recurrent stack's rows (m = t*B + b) read from a (B, T, K) tensor
+    lib.x3_image(P(x), K, Tt * K, Bb, M, K, P(a_img), None)
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
+    got_w = (f(w_img[:, :, 0]) + f(w_img[:, :, 1])).reshape(N, KB * 32)
+    assert np.abs(got_w[:, :K] - W).max() <= 2 ** -16 * np.abs(W).max() and not got_w[:, K:].any()
+    xt = x.transpose(1, 0, 2).reshape(M, K)
+    got_a = (f(a_img[:, :, 0]) + f(a_img[:, :, 1])).reshape(M, KB * 32)
+    assert np.abs(got_a[:, :K] - xt).max() <= 2 ** -16 * np.abs(xt).max()
+    out = np.full((Bb, Tt, N), np.nan, np.float32)
+    lib.linear_x3p(P(a_img), M, K, P(w_img), P(bias), N, mode, group, 1e-12, P(out), Bb, N, Tt * N, None)
+    ref = x.astype(np.float64) @ W.T.astype(np.float64) + bias
+    if mode == _abi.EPI_L2NORM:
+        r = ref.reshape(Bb, Tt, N // group, group)
+        ref = (r / np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), 1e-12)).reshape(Bb, Tt, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = 1 / (1 + np.exp(-ref))
+    assert not np.isnan(out).any()
+    np.testing.assert_allclose(out, ref, atol=3e-4, rtol=1e-4)
+
+
 def test_label_features_match_oracle(lib):
     B, n = 2, 1500
     trips = [synth_mixture(60 + b, n, return_sources=True) for b in range(B)]

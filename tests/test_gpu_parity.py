@@ -111,6 +111,37 @@ def test_linear_split_bf16_kernel(dev, M, K, N, mode, group):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,K,N,mode,group", [(1000, 1200, 2580, _abi.EPI_L2NORM, 20), (333, 129, 4800, _abi.EPI_BIAS, 0),
+                                              (257, 1200, 258, _abi.EPI_SIGMOID, 0), (12800, 1200, 4800, _abi.EPI_BIAS, 0),
+                                              (700, 600, 320, _abi.EPI_L2NORM, 40)])
+def test_linear_x3_image_kernel(dev, M, K, N, mode, group):
+    """onssen_x3_image_f32 + onssen_linear_x3p: pre-split operands, register epilogue."""
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    KB = (K + 31) // 32
+    a_img = torch.empty(M, KB, 2, 32, device=dev, dtype=torch.int16)
+    w_img = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.x3_image(Ad.data_ptr(), K, 0, 1, M, K, a_img.data_ptr(), st)
+    lib.x3_image(Wd.data_ptr(), K, 0, 1, N, K, w_img.data_ptr(), st)
+    out = torch.full((M, N), float("nan"), device=dev)
+    lib.linear_x3p(a_img.data_ptr(), M, K, w_img.data_ptr(), bd.data_ptr(), N, mode, group, 1e-12, out.data_ptr(), 1, N, 0, st)
+    ref = A.double() @ W.double().T + bias.double()
+    if mode == _abi.EPI_L2NORM:
+        r = ref.view(M, N // group, group)
+        ref = (r / r.norm(dim=-1, keepdim=True).clamp_min(1e-12)).view(M, N)
+    elif mode == _abi.EPI_SIGMOID:
+        ref = torch.sigmoid(ref)
+    err = (out.cpu().double() - ref).abs().max().item()
+    print(f"x3-image GEMM M={M} K={K} N={N} mode={mode}: max abs err {err:.3e}")
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-5, rtol=1e-4)
+
+
 # ---------------------------------------------------------------- golden vectors of the reference
 @pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
 def test_dc_tiny_golden(dev, golden_dir, prec, name):
