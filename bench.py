@@ -221,7 +221,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
     x3 = bool(flags & 2)
-    wih = pk.wih_x3 if x3 else pk.wih
+    wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if x3 else pk.wih
     whh = pk.whh_x3 if x3 else pk.whh
 
     def lin(A, a_s0, a_s1, K, Wf, ldf, W3, ld3, bias, N, mode, group, out_ptr, c_s0, c_s1):
@@ -231,7 +231,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         else:
             lib.linear(A, a_s0, a_s1, B, T * B, K, Wf, ldf, bias, N, mode, group, 1e-12, None, out_ptr, c_s0, c_s1, st())
     y = torch.empty(T, B, 2, Hp, device=dev)
-    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, max(F, 2 * Hp), H, 1, ug), dtype=torch.uint8, device=dev)
     xin = torch.randn(B, T, F, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     st = _stream   # evaluated at call time: under graph capture the current stream is the capture stream
@@ -250,25 +250,54 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     gbuf = ws[_abi.BLSTM_WS_HEADER:]
     F4, F32 = (F + 3) // 4 * 4, (F + 31) // 32 * 32
     K1, K132 = 2 * Hp, (2 * Hp + 31) // 32 * 32
-
-    def gemm0():
-        lin(xin.data_ptr(), xin.stride(1), xin.stride(0), F, pk.wih[0].data_ptr(), F4, pk.wih_x3[0].data_ptr(), F32,
-            pk.bias[0].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
-
-    def gemm_in():
-        if lyr == 0:
-            gemm0()
-        else:
-            lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, pk.wih[1].data_ptr(), K1, pk.wih_x3[1].data_ptr(), K132,
-                pk.bias[1].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
-
+    images = bool(flags & _abi.BLSTM_XCD)   # activations travel as x3 images, GEMMs run on pre-split operands
     hd = model._head_dc if kind == "chimera" else model._head
     hp = hd.get(Hp)
     out = torch.empty(B, T, hp.N, device=dev)
+    if images:
+        img_x = torch.empty(T * B, F32 // 32, 2, 32, device=dev, dtype=torch.int16)
+        img_y = torch.empty(T * B, K132 // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, K1, img_y.data_ptr(), st())
 
-    def head():
-        lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, hp.w.data_ptr(), K1, hp.planes.data_ptr(), hp.ld3, hp.b.data_ptr(),
-            hp.N, 1, D, out.data_ptr(), hp.N, T * hp.N)
+        def image_in():    # the single-layer call below splits its fp32 input first; in the stack only layer 0 does
+            if lyr == 0:
+                lib.x3_image(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, img_x.data_ptr(), st())
+            else:
+                lib.x3_image(yin.data_ptr(), B * 2 * Hp, 2 * Hp, B, T * B, K1, img_y.data_ptr(), st())
+
+        def gemm0():       # layer 0 as the stack runs it: split the features, then the GEMM
+            lib.x3_image(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, img_x.data_ptr(), st())
+            lib.linear_x3p(img_x.data_ptr(), T * B, F, pk.wih_img[0].data_ptr(), pk.bias[0].data_ptr(), 2 * NP, 0, 0, 1e-12,
+                           gbuf.data_ptr(), B, B * 2 * NP, 2 * NP, st())
+
+        def gemm_in():
+            if lyr == 0:
+                gemm0()
+            else:
+                lib.linear_x3p(img_y.data_ptr(), T * B, K1, pk.wih_img[1].data_ptr(), pk.bias[1].data_ptr(), 2 * NP, 0, 0,
+                               1e-12, gbuf.data_ptr(), B, B * 2 * NP, 2 * NP, st())
+
+        def head():
+            lib.linear_x3p(img_y.data_ptr(), T * B, K1, hp.img.data_ptr(), hp.b.data_ptr(), hp.N, 1, D, 1e-12,
+                           out.data_ptr(), B, hp.N, T * hp.N, st())
+    else:
+        def image_in():
+            pass
+
+        def gemm0():
+            lin(xin.data_ptr(), xin.stride(1), xin.stride(0), F, pk.wih[0].data_ptr(), F4, pk.wih_x3[0].data_ptr(), F32,
+                pk.bias[0].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
+
+        def gemm_in():
+            if lyr == 0:
+                gemm0()
+            else:
+                lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, pk.wih[1].data_ptr(), K1, pk.wih_x3[1].data_ptr(), K132,
+                    pk.bias[1].data_ptr(), 2 * NP, 0, 0, gbuf.data_ptr(), B * 2 * NP, 2 * NP)
+
+        def head():
+            lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, hp.w.data_ptr(), K1, hp.planes.data_ptr(), hp.ld3, hp.b.data_ptr(),
+                hp.N, 1, D, out.data_ptr(), hp.N, T * hp.N)
 
     def timed(fn, reps=5):
         fn()
@@ -292,26 +321,31 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     t_layer, t_gin, t_g0, t_head = timed(layer), timed(gemm_in), timed(gemm0), timed(head)
-    t_rec = t_layer - t_gin                                    # recurrence of one layer (both directions)
+    t_img = timed(image_in) if images and lyr else 0.0         # (for lyr == 0 the split is part of gemm0 = gemm_in)
+    t_rec = t_layer - t_gin - t_img                            # recurrence of one layer (both directions)
     flop_rec = 2.0 * 2 * B * 4 * H * H * T                     # h W_hh^T, both directions, 2 FLOP/MAC
     flop_gin = 2.0 * B * T * 8 * H * (2 * H if lyr else F)
     flop_head = 2.0 * B * T * hp.N * 2 * H
+    xcd = bool(flags & _abi.BLSTM_XCD)
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf)).get("recurrence_hbm_bytes_per_launch")
-    launches = T
+        traffic = json.load(open(tf)).get("xcd_recurrence_hbm_bytes_per_launch" if xcd else "recurrence_hbm_bytes_per_launch")
+    # persistent form: one launch per layer and 64 batch rows; launch-per-step form: T launches per layer
+    launches = -(-B // 64) if xcd else T
     # ceiling for ALGORITHMIC (fp32-equivalent) FLOPs: the exact-fp32 MFMA rate, or a third of the dense bf16
     # MFMA rate when every product is three bf16 MFMAs
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    rec = {"kernel": "lstm_step_kernel", "bound": "mfma",
+    rec = {"kernel": "lstm_xcd_kernel" if xcd else "lstm_step_kernel", "bound": "mfma",
            "achieved": flop_rec / t_rec / 1e12, "peak": peak, "unit": "TFLOP/s",
            "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
            "peak_note": "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
+           "bound_note": "a serial chain of T dependent time steps: the kernel is bound by the per-step exchange latency "
+                         "(two L2 round trips + barrier), not by MFMA issue or HBM -- see DESIGN.md",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
            "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
-    gem = {"kernel": "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+    gem = {"kernel": "linear_x3p_kernel" if images else "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
            "achieved_by_call": {"input_proj_l0": 2.0 * B * T * 8 * H * F / t_g0 / 1e12,
                                 "input_proj_l1": (flop_gin / t_gin / 1e12) if lyr else None,
                                 "fc_dc_l2norm": flop_head / t_head / 1e12},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 2
+#define ONSSEN_ABI_VERSION 3
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -49,7 +49,12 @@ extern "C" {
                                      that XCD's L2.  Needs ceil(H/ug) <= 32, H <= 640, ug <= 20.  The kernel verifies
                                      the placement itself and otherwise uses a placement-independent (slower)
                                      protocol; bounded waits: ws word [281] = 1 reports that, word [280] != 0 an
-                                     aborted launch (outputs invalid). */
+                                     aborted launch (outputs invalid).
+                                     In this form the activations travel between the layers as x3 images (see
+                                     onssen_linear_x3p) written by the recurrence epilogue: wih_p_host[l] must be the
+                                     x3 image (onssen_x3_image_f32) of the packed [2*NP][K_l] input-projection
+                                     matrix, and the last layer's output image stays in the workspace for the
+                                     heads (onssen_blstm_y_image). */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
@@ -152,18 +157,22 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
  *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of L device pointers; entry l holds both
  *             directions back to back: wih [2*NP][Kp_l], whh [2][whh_elems], bias [2*NP]
  *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0
- *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned.  Its first
- *             ONSSEN_BLSTM_WS_HEADER_BYTES hold the exchange state of the ONSSEN_BLSTM_XCD form (flags,
- *             generations, status words): the OWNER zeroes them once when the workspace is allocated and never
- *             again -- everything in there is monotonic, and no call memsets it (so a hipGraph replay does not
- *             depend on a memset node reaching the kernel's L2).  u32 word [280] != 0: a launch gave up waiting
- *             (outputs invalid); word [281] = 1: some launch used the placement-independent protocol.
+ *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned, ZEROED ONCE by its owner when
+ *             it is allocated and never again.  Its first ONSSEN_BLSTM_WS_HEADER_BYTES hold the exchange state
+ *             of the ONSSEN_BLSTM_XCD form (flags, generations, status words): everything in there is monotonic,
+ *             and no call memsets it (so a hipGraph replay does not depend on a memset node reaching the kernel's
+ *             L2); the k padding of the x3 images further back is never written and must read as zero.  u32 word
+ *             [280] != 0: a launch gave up waiting (outputs invalid); word [281] = 1: some launch used the
+ *             placement-independent protocol.
  * Default form: one input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph
  * to amortise launch cost.  ONSSEN_BLSTM_XCD: one GEMM + ONE persistent launch per layer (DESIGN.md,
  * "XCD-local persistent recurrence").
  */
 #define ONSSEN_BLSTM_WS_HEADER_BYTES 16384
-size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug);
+size_t onssen_blstm_workspace_bytes(int B, int T, int in_dim, int H, int L, int ug);
+/* Where the ONSSEN_BLSTM_XCD form leaves the x3 image [T*B][KB][2][32] (row m = t*B + b, KB = ceil(2*Hp/32),
+ * k = d*Hp + j) of the LAST layer's output: byte offset inside the workspace.  Feed it to onssen_linear_x3p. */
+int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t* offset_bytes, int* KB);
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,

@@ -8,7 +8,7 @@ imports torch, so the same binding drives the product library
 import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -32,7 +32,8 @@ SIGNATURES = {
     "onssen_linear_bf16x3": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_x3_image_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_linear_x3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp]),
-    "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
@@ -78,8 +79,14 @@ class Lib:
     def lstm_pack_whh_bf16x3(self, w_hh, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_whh_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whh_bf16x3")
 
-    def blstm_workspace_bytes(self, B, T, H, L, ug):
-        return int(self.dll.onssen_blstm_workspace_bytes(B, T, H, L, ug))
+    def blstm_workspace_bytes(self, B, T, in_dim, H, L, ug):
+        return int(self.dll.onssen_blstm_workspace_bytes(B, T, in_dim, H, L, ug))
+
+    def blstm_y_image(self, B, T, in_dim, H, L, ug):
+        """(byte offset inside the workspace, KB) of the last layer's x3 output image (ONSSEN_BLSTM_XCD form)."""
+        off, kb = C.c_size_t(0), C.c_int(0)
+        self.check(self.dll.onssen_blstm_y_image(B, T, in_dim, H, L, ug, C.byref(off), C.byref(kb)), "onssen_blstm_y_image")
+        return int(off.value), int(kb.value)
 
     # ---- kernels (pointers are ints) --------------------------------------
     def stft_logmag(self, wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream):

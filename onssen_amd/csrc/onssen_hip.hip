@@ -1369,6 +1369,8 @@ struct XcdArgs {
   unsigned spin_limit;
   long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
   int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA; test only: 8 = rotate groups over XCDs
+  unsigned short* yimg;         // x3 image [T*B][KBI][2][32] of the layer output (the next GEMM's A operand), or null
+  int KBI;                      // ceil(2*Hp / 32)
 };
 
 template <int NT>
@@ -1449,7 +1451,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 
   // ---- per-thread constants of the cell update: element e = (row, ju) of this member's 16 x UG tile
   bool e_ok[EPT], e_inb[EPT];
-  long g_off[EPT], y_off[EPT];          // float offsets at t = 0
+  long g_off[EPT], y_off[EPT], i_off[EPT];   // float / float / uint16 offsets at t = 0
   unsigned hx_off[EPT];                 // byte offset inside a hand-off slot
   int red_off[EPT][4];                  // LDS float offset of the wave-0 partial of each gate
 #pragma unroll
@@ -1460,6 +1462,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
     e_inb[i] = e_ok[i] && b < p.B;
     g_off[i] = ((long)b * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4;
     y_off[i] = ((long)b * 2 + dir) * p.Hp + k;
+    i_off[i] = ((long)b * p.KBI + ((dir * p.Hp + k) >> 5)) * 64 + ((dir * p.Hp + k) & 31);
     hx_off[i] = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
 #pragma unroll
     for (int gt = 0; gt < 4; ++gt) {
@@ -1467,7 +1470,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
       red_off[i][gt] = ((pl >> 4) * 4 + (row & 3)) * RLD + ((row >> 2) << 4) + (pl & 15);
     }
   }
-  const long g_step = (long)p.B * 2 * p.NP, y_step = (long)p.B * 2 * p.Hp;
+  const long g_step = (long)p.B * 2 * p.NP, y_step = (long)p.B * 2 * p.Hp, i_step = (long)p.B * p.KBI * 64;
   // input projection of a step: loaded one step AHEAD into a second register set.  Waiting for the h fragments
   // (vmcnt retires in order) would otherwise also wait for these older, HBM-cold loads on the critical path.
   auto load_g = [&](float (&gp)[EPT][4], int step) {
@@ -1594,7 +1597,14 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
           split_bf16(h, hi, lo);
           __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, hx_off[i], 0, ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, hx_off[i] + 1024, 0, ST_AUX);
-          if (e_inb[i]) p.y[y_off[i] + t * y_step] = h;
+          if (e_inb[i]) {
+            if (p.y) p.y[y_off[i] + t * y_step] = h;
+            if (p.yimg) {   // the same split pair, in the layout the next layer's / the head's GEMM reads
+              unsigned short* d = p.yimg + i_off[i] + t * i_step;
+              d[0] = hi;
+              d[32] = lo;
+            }
+          }
         }
       }
       // this wave's stores are acknowledged (by L2 / by memory) -> raise this wave's flag
@@ -2077,14 +2087,40 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t onssen_blstm_workspace_bytes(int B, int T, int H, int L, int ug) {
+// workspace layout: header | G | ybuf (L > 1) | c | h hand-off image | x3 images: layer-0 input, output A (the
+// LAST layer's), output B (L > 1) | 64 KiB debug
+struct BlstmWs {
+  size_t g, y, c, hs, img_x, img_y, off_imgx, off_imga, off_imgb, total;
+};
+static bool blstm_ws_layout(int B, int T, int in_dim, int H, int L, int ug, BlstmWs* w) {
   int Hp, NP, KQ;
-  if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, nullptr) != ONSSEN_OK || B <= 0 || T <= 0 || L <= 0) return 0;
-  const size_t g = align256((size_t)T * B * 2 * NP * sizeof(float));
-  const size_t y = align256((size_t)T * B * 2 * Hp * sizeof(float));
-  const size_t c = align256((size_t)2 * B * Hp * sizeof(float));
-  const size_t hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
-  return ONSSEN_BLSTM_WS_HEADER_BYTES + g + (L > 1 ? y : 0) + c + hs + 65536;   // header: exchange state of the XCD-local form
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, nullptr) != ONSSEN_OK || B <= 0 || T <= 0 || L <= 0 || in_dim <= 0) return false;
+  w->g = align256((size_t)T * B * 2 * NP * sizeof(float));
+  w->y = L > 1 ? align256((size_t)T * B * 2 * Hp * sizeof(float)) : 0;
+  w->c = align256((size_t)2 * B * Hp * sizeof(float));
+  w->hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
+  w->img_x = align256((size_t)T * B * ceil_div(in_dim, 32) * 128);
+  w->img_y = align256((size_t)T * B * ceil_div(2 * Hp, 32) * 128);
+  w->off_imgx = ONSSEN_BLSTM_WS_HEADER_BYTES + w->g + w->y + w->c + w->hs;
+  w->off_imga = w->off_imgx + w->img_x;
+  w->off_imgb = w->off_imga + w->img_y;
+  w->total = w->off_imgb + (L > 1 ? w->img_y : 0) + 65536;   // the last 64 KiB: debug timestamps
+  return true;
+}
+
+size_t onssen_blstm_workspace_bytes(int B, int T, int in_dim, int H, int L, int ug) {
+  BlstmWs w;
+  return blstm_ws_layout(B, T, in_dim, H, L, ug, &w) ? w.total : 0;
+}
+
+int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t* offset_bytes, int* KB) {
+  BlstmWs w;
+  int Hp;
+  if (!blstm_ws_layout(B, T, in_dim, H, L, ug, &w) || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK)
+    return ONSSEN_E_ARG;
+  if (offset_bytes) *offset_bytes = w.off_imga;
+  if (KB) *KB = ceil_div(2 * Hp, 32);
+  return ONSSEN_OK;
 }
 
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
@@ -2096,7 +2132,9 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
   if (!x || !y || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || T <= 0 || in_dim <= 0 || L <= 0)
     return ONSSEN_E_ARG;
-  if (ws_bytes < onssen_blstm_workspace_bytes(B, T, H, L, ug)) return ONSSEN_E_WORKSPACE;
+  BlstmWs wl;
+  if (!blstm_ws_layout(B, T, in_dim, H, L, ug, &wl)) return ONSSEN_E_ARG;
+  if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(y)) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
@@ -2118,18 +2156,31 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   uint16_t* hsb = (uint16_t*)wsp;
   const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 16) * KQ2 * 2048;   // split-bf16 image; >= the fp32 image (2*KQ2 >= KQ)
   wsp += align256(hs_bytes);
-  long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)wsp : nullptr;
+  long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)((char*)ws + wl.total - 65536) : nullptr;
   {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
     hipError_t e = hipMemsetAsync(hsb, 0, hs_bytes, st);
     if (e != hipSuccess) return (int)e;
   }
   const int mt = (B > 16 && !(flags & ONSSEN_BLSTM_SPLIT_ROWS)) ? 2 : 1;
+  // XCD form: activations travel between the layers (and on to the heads) as x3 images written by the recurrence
+  // epilogue; wih_p_host[l] is then the x3 image of the [2*NP][K_l] input-projection matrix
+  const bool images = x3 && (flags & ONSSEN_BLSTM_XCD);
+  uint16_t* img_x = (uint16_t*)((char*)ws + wl.off_imgx);
+  uint16_t* img_ab[2] = {(uint16_t*)((char*)ws + wl.off_imga), (uint16_t*)((char*)ws + wl.off_imgb)};
   for (int l = 0; l < L; ++l) {
     // the last layer writes `y`; the layers before it alternate so that each reads what the previous wrote
     float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;
     const float* yin = ((L - 1 - l) % 2 == 0) ? ybuf : y;
     int rc;
-    if (x3) {   // wih_p_host[l]: split-bf16 planes [2][2*NP][ld], ld = K rounded up to 32
+    if (images) {
+      const uint16_t* a_img = l == 0 ? img_x : img_ab[(L - l) % 2];   // layer l-1 wrote buffer (L-1-(l-1)) % 2
+      if (l == 0) {
+        rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
+        if (rc != ONSSEN_OK) return rc;
+      }
+      rc = onssen_linear_x3p(a_img, T * B, l == 0 ? in_dim : 2 * Hp, (const uint16_t*)wih_p_host[l], bias_p_host[l],
+                             2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G, B, (int64_t)B * 2 * NP, 2 * NP, stream);
+    } else if (x3) {   // wih_p_host[l]: split-bf16 planes [2][2*NP][ld], ld = K rounded up to 32
       const int K = l == 0 ? in_dim : 2 * Hp, ld = ceil_div(K, 32) * 32;
       rc = onssen_linear_bf16x3(l == 0 ? x : yin, l == 0 ? xs_t : (int64_t)B * 2 * Hp, l == 0 ? xs_b : 2 * Hp, B, T * B,
                                 K, (const uint16_t*)wih_p_host[l], ld, bias_p_host[l], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f,
@@ -2147,7 +2198,9 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     if (flags & ONSSEN_BLSTM_XCD) {
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
       XcdArgs xa;
-      xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
+      // fp32 rows only where somebody reads them (the caller's y); every layer leaves its x3 image
+      xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = l == L - 1 ? y : nullptr; xa.hx = hsb; xa.sync = syncw; xa.B = B;
+      xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 15;
       ONSSEN_CLEAR_ERROR();
       switch (ug) {

@@ -164,7 +164,7 @@ class _PackedImages:
         dev = flat[0].device
         H, L = p.hidden_size, p.num_layers
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
-        self.wih, self.whh, self.bias, self.whh_x3, self.wih_x3 = [], [], [], [], []
+        self.wih, self.whh, self.bias, self.whh_x3, self.wih_x3, self.wih_img = [], [], [], [], [], []
         _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
         for l in range(L):
@@ -185,7 +185,12 @@ class _PackedImages:
             ld = (ld + 31) // 32 * 32
             a3 = torch.empty(2, 2 * self.NP, ld, device=dev, dtype=torch.int16)     # hi plane, lo plane
             lib.linear_pack_bf16x3(a.data_ptr(), 2 * self.NP, in_l if l == 0 else 2 * self.Hp, Kp, ld, a3.data_ptr(), st)
+            # x3 image of the same matrix (ONSSEN_BLSTM_XCD form: pre-split operands, onssen_linear_x3p)
+            K_l = in_l if l == 0 else 2 * self.Hp
+            ai = torch.empty(2 * self.NP, (K_l + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+            lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
             self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
+            self.wih_img.append(ai)
         self.key = key
         return self
 
@@ -218,6 +223,8 @@ class PackedHead:
         self.ld3 = (2 * Hp + 31) // 32 * 32
         self.planes = torch.empty(2, N, self.ld3, device=dev, dtype=torch.int16)
         lib.linear_pack_bf16x3(self.w.data_ptr(), N, 2 * Hp, 2 * Hp, self.ld3, self.planes.data_ptr(), _stream())
+        self.img = torch.empty(N, self.ld3 // 32, 2, 32, device=dev, dtype=torch.int16)     # x3 image (onssen_linear_x3p)
+        lib.x3_image(self.w.data_ptr(), 2 * Hp, 0, 1, N, 2 * Hp, self.img.data_ptr(), _stream())
         self.N, self.key = N, key
         return self
 
@@ -256,14 +263,19 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
         raise RuntimeError(f"input feature size {In} != {p.input_size}")
     if x.stride(2) != 1:
         x = x.contiguous()
-    nbytes = lib.blstm_workspace_bytes(B, T, p.hidden_size, p.num_layers, pk.ug)
+    nbytes = lib.blstm_workspace_bytes(B, T, In, p.hidden_size, p.num_layers, pk.ug)
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
+    wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
-                      [t.data_ptr() for t in (pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih)],
+                      [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
+    y.x3_image = None
     if flags & _abi.BLSTM_XCD:
+        # the last layer's output also sits in the workspace as an x3 image: the heads' GEMM operand
+        off, _ = lib.blstm_y_image(B, T, In, p.hidden_size, p.num_layers, pk.ug)
+        y.x3_image = (wsb, off)                        # keeps the workspace alive with y
         _XcdStatus.post(wsb)
         if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
             _XcdStatus.poll(wait=True)
@@ -280,7 +292,13 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
     out = torch.empty(B, T, hd.N, device=y.device, dtype=torch.float32)
     a_ptr = y.data_ptr() + b_off * 2 * Hp * 4
     rp = resid.data_ptr() if resid is not None else None
-    if precision() == "bf16x3" and (mode != EPI_L2NORM or 160 % group == 0):
+    img = getattr(y, "x3_image", None)
+    if (img is not None and resid is None and b_off == 0 and Btot == B
+            and (mode != EPI_L2NORM or (group % 4 == 0 and 80 % group == 0 and 80 // group <= 4))):
+        wsb, off = img                               # pre-split activations straight from the recurrence epilogue
+        lib.linear_x3p(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, mode, group, eps,
+                       out.data_ptr(), B, hd.N, T * hd.N, _stream())
+    elif precision() == "bf16x3" and (mode != EPI_L2NORM or 160 % group == 0):
         lib.linear_bf16x3(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.planes.data_ptr(), hd.ld3, hd.b.data_ptr(),
                           hd.N, mode, group, eps, rp, out.data_ptr(), hd.N, T * hd.N, _stream())
     else:

@@ -94,7 +94,7 @@ def test_blstm_stack_matches_oracle(lib, H, ug, B):
     rng = np.random.default_rng(3)
     x = rand(rng, B, T, F)
     Hp, NP, wih, whh, bias = _pack_lstm(lib, sd, "rnn.", F, H, L, ug)
-    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64)
+    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64)
     y = np.full((T, B, 2, Hp), np.nan, np.float32)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, 0, None)
@@ -187,7 +187,7 @@ def test_blstm_split_bf16_recurrence(lib, H, ug, B):
         pl = np.zeros((2, 2 * NP, ld), np.uint16)           # hi plane, lo plane of the [2*NP][K] projection matrix
         lib.linear_pack_bf16x3(P(wih[l]), 2 * NP, K, wih[l].shape[-1], ld, P(pl), None)
         wih3.append(pl)
-    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64)
+    ws = aligned_f32(lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64)
     y = np.full((T, B, 2, Hp), np.nan, np.float32)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3, None)
@@ -351,11 +351,10 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble):
             lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
                           P(a[d]), P(scratch), P(c[d]), None)
             lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
-        ld = (K + 31) // 32 * 32
-        pl = _shm((2, 2 * NP, ld), dtype=np.uint16)
-        lib.linear_pack_bf16x3(P(a), 2 * NP, K, Kp, ld, P(pl), None)
+        pl = _shm((2 * NP, (K + 31) // 32, 2, 32), dtype=np.uint16)      # x3 image of the [2*NP][K] projection matrix
+        lib.x3_image(P(a), Kp, 0, 1, 2 * NP, K, P(pl), None)
         wih3.append(pl), whh3.append(b3), bias.append(c)
-    ws = _shm((lib.blstm_workspace_bytes(B, T, H, L, ug) // 4 + 64,))
+    ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
     y = _shm((T, B, 2, Hp), fill=np.nan)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD, None)

@@ -40,7 +40,7 @@ for ug in (8, 12, 16):
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
     y = torch.empty(T, B, 2, Hp, device=dev)
-    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, 2 * Hp, H, 1, ug), dtype=torch.uint8, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     gbuf = ws[_abi.BLSTM_WS_HEADER:]
 

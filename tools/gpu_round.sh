@@ -1,3 +1,13 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for ab in clk0 clk11 clk3 clk1 clk4; do ONSSEN_PROBE_LIB=build_variants/lib_$ab.so timeout 120 python tools/gemm_probe3.py 2>&1 | grep -v amdgpu.ids | tail -2; done
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+timeout 200 python tools/xcd_graph_probe.py 2>&1 | tail -6
+for c in dc_l2 chimera_l4; do
+timeout 300 python bench.py --config $c --steps 20 --warmup 3 > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err
+python - <<PY
+import json
+r = json.loads(open("gpurun_out/bench_$c.json").read().strip().splitlines()[-1])
+print("$c", "ms/step", r["ms_per_step"], "xRT", r["value"], "rec us/step", r["roofline"].get("us_per_time_step"), "|", r["config"].get("recurrence"), "| safe protocol:", r["config"].get("xcd_placement_independent_protocol_used"))
+print("   ", r["roofline"]["other_kernels"]["ms_by_call"], r["roofline"]["kernel"], r["roofline"]["other_kernels"]["kernel"])
+PY
+done

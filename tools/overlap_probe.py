@@ -20,7 +20,7 @@ Hp, NP = pk.Hp, pk.NP
 
 def make_chain(B, ablate=0):
     y = torch.empty(T, B, 2, Hp, device=dev)
-    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, H, 1, ug), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.blstm_workspace_bytes(B, T, 2 * Hp, H, 1, ug), dtype=torch.uint8, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
 
     def run():

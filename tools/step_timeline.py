@@ -11,7 +11,7 @@ dev = torch.device("cuda:0"); lib = get_lib()
 model = onn.deep_clustering(F, H, 2, 20).to(dev).eval()
 pk = model._packed.get(ug); Hp = pk.Hp
 y = torch.empty(T, B, 2, Hp, device=dev)
-nb = lib.blstm_workspace_bytes(B, T, H, 1, ug)
+nb = lib.blstm_workspace_bytes(B, T, 2 * Hp, H, 1, ug)
 ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
 for x3, ab in ((2, 0), (2, 1), (2, 2), (2, 3), (2, 11), (0, 0)):

@@ -13,11 +13,11 @@ for (H, B) in ((600, 32), (600, 48), (600, 64), (300, 64)):
     model = onn.deep_clustering(F, H, 2, 20).to(dev).eval()
     pk = model._packed.get(ug); Hp = pk.Hp; NU = Hp // ug
     y = torch.empty(T, B, 2, Hp, device=dev)
-    nb = lib.blstm_workspace_bytes(B, T, H, 1, ug)
+    nb = lib.blstm_workspace_bytes(B, T, 2 * Hp, H, 1, ug)
     ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     for it in range(3):
-        lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih_x3[1].data_ptr()],
+        lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih_img[1].data_ptr()],
                           [pk.whh_x3[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(),
                           (32 << 8) | 2 | 4, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

@@ -12,11 +12,11 @@ dev = torch.device("cuda:0"); lib = get_lib()
 model = onn.deep_clustering(F, H, 2, 20).to(dev).eval()
 pk = model._packed.get(ug); Hp = pk.Hp
 y = torch.empty(T, B, 2, Hp, device=dev)
-nb = lib.blstm_workspace_bytes(B, T, H, 1, ug)
+nb = lib.blstm_workspace_bytes(B, T, 2 * Hp, H, 1, ug)
 ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
 yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
 def layer(dbgflag):
-    lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih_x3[1].data_ptr()],
+    lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [pk.wih_img[1].data_ptr()],
                       [pk.whh_x3[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(), ws.numel(),
                       (dbgflag << 8) | 2 | 4, torch.cuda.current_stream().cuda_stream)
 AB = int(os.environ.get('AB', 0))
