@@ -175,9 +175,12 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "f32" else "f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, 8 kHz STFT "
+        "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, {SR // 1000} kHz STFT "
                                f"{NFFT}/{HOP}, {B} x {T_FRAMES}-frame chunks per GPU; step = STFT+log-mag -> BLSTM "
-                               "-> fc_dc + L2-normalise -> mask-apply + iSTFT (2 speakers)",
+                               + {"deep_clustering": "-> fc_dc + L2-normalise -> mask-apply + iSTFT (2 speakers)",
+                                  "chimera": "-> fc_dc + L2-normalise, fc_mi + sigmoid -> mask-apply + iSTFT (2 speakers)",
+                                  "phase_net": "-> embedding + mask heads -> phase BLSTM over (masked magnitude, phase) "
+                                               "-> unit-norm phase head -> mask-apply + iSTFT (2 speakers)"}[kind],
                    "chunks_per_gpu": B, "frames_per_chunk": T_FRAMES, "launch": "hipGraph replay" if graph else "eager",
                    "parallelism": f"utterance-sharded x{world}, no data-path collective"},
     }
