@@ -168,7 +168,7 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
  * to amortise launch cost.  ONSSEN_BLSTM_XCD: one GEMM + ONE persistent launch per layer (DESIGN.md,
  * "XCD-local persistent recurrence").
  */
-#define ONSSEN_BLSTM_WS_HEADER_BYTES 16384
+#define ONSSEN_BLSTM_WS_HEADER_BYTES 32768
 size_t onssen_blstm_workspace_bytes(int B, int T, int in_dim, int H, int L, int ug);
 /* Where the ONSSEN_BLSTM_XCD form leaves the x3 image [T*B][KB][2][32] (row m = t*B + b, KB = ceil(2*Hp/32),
  * k = d*Hp + j) of the LAST layer's output: byte offset inside the workspace.  Feed it to onssen_linear_x3p. */

@@ -12,7 +12,7 @@ ABI_VERSION = 3
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
-BLSTM_WS_HEADER = 16384   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
+BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)

@@ -1362,7 +1362,7 @@ struct XcdArgs {
   unsigned short* hx;           // per group: [2 slots][KQ2][hi|lo][64][8]
   unsigned* sync;               // u32 words: [256 + g] arrivals, [280] abort, u64 pairs at [320 + 4g]: max(xcc+1), max(16-xcc),
                                 // [281] status (1 = some group ran the placement-independent protocol), [288 + g]
-                                // launch generation; u64 flags at byte 2048 + ((g*32 + m)*4 + wave)*8 (8 KiB).  The block is zeroed ONCE
+                                // launch generation; u64 flags at byte 2048 + ((g*32 + m)*NW + wave)*8 (up to 16 KiB).  The block is zeroed ONCE
                                 // by the workspace owner: everything in it is monotonic, so no launch depends on a
                                 // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
@@ -1373,15 +1373,16 @@ struct XcdArgs {
   int KBI;                      // ceil(2*Hp / 32)
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   using namespace rec;
   constexpr int UG = 4 * NT;
   constexpr int NE = 16 * UG;
-  constexpr int EPT = (NE + 255) / 256;
-  constexpr int CPW = 5;                       // k-chunks (32 k) per wave: 4 x 5 x 32 = 640 >= H
+  constexpr int NTHR = 64 * NW;                // NW = 4 or 8 waves: two waves per SIMD issue MFMAs ~1.4x denser than one
+  constexpr int EPT = (NE + NTHR - 1) / NTHR;
+  constexpr int CPW = 20 / NW + (20 % NW != 0);   // k-chunks (32 k) per wave: NW x CPW x 32 >= 640 >= H
   constexpr unsigned kOOB = 0x7ffffff0u;
-  __shared__ float red[2 * 4 * NT * 4 * RLD];   // two step parities
+  __shared__ float red[2 * NW * NT * 4 * RLD];   // two step parities
   __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
@@ -1393,7 +1394,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
   const int dir = g / p.nbg, bg = g % p.nbg;
   const int b0 = p.row0 + bg * 16;
-  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * 128;   // [member][wave]
+  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * (32 * NW);   // [member][wave]
   unsigned* abort_w = p.sync + 280;
 
   // ---- placement check: do all members of this group sit on one XCD?
@@ -1441,7 +1442,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
         for (int hl = 0; hl < 2; ++hl)
           w[i][nt][hl] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              rw, (unsigned)(((wave + 4 * i) * NT + nt) * 2048 + hl * 1024 + lane * 16), 0, 0));
+              rw, (unsigned)(((wave + NW * i) * NT + nt) * 2048 + hl * 1024 + lane * 16), 0, 0));
   }
   float cst[EPT];
 #pragma unroll
@@ -1456,7 +1457,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   int red_off[EPT][4];                  // LDS float offset of the wave-0 partial of each gate
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + NTHR * i;
     const int row = (e / UG) & 15, ju = e % UG, b = b0 + row, k = ugi * UG + ju;
     e_ok[i] = e < NE;
     e_inb[i] = e_ok[i] && b < p.B;
@@ -1489,7 +1490,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
   // stores are acknowledged, and every wave polls for itself with one 16-byte load per lane -- no workgroup
   // barrier on either side of the exchange.  The only barrier of a step is the one between the per-wave
   // partial sums and the cell update; `red` is double-buffered so that this one barrier suffices.
-  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)flags, 0, 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)flags, 0, 32 * NW * 8, 0x00020000);
   bool gave_up = false;                          // after a timeout nobody waits any more: the launch drains
                                                  // with garbage and the abort word tells the host
   // the loop body exists twice: L2-local protocol (FAST) and placement-independent protocol
@@ -1502,9 +1503,13 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
       const unsigned long long want = gen | want_lo;
       unsigned spins = 0;
       for (;;) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)lane * 16u, 0, LD_AUX);
-        const unsigned long long f0 = ((unsigned long long)v[1] << 32) | v[0], f1 = ((unsigned long long)v[3] << 32) | v[2];
-        const bool ready = (2 * lane >= 4 * p.NU) || (f0 >= want && f1 >= want);   // stale words carry an older generation
+        bool ready = true;
+#pragma unroll
+        for (int h = 0; h < NW / 4; ++h) {   // 32*NW flags: NW/4 16-byte loads per lane
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)(h * 1024 + lane * 16), 0, LD_AUX);
+          const unsigned long long f0 = ((unsigned long long)v[1] << 32) | v[0], f1 = ((unsigned long long)v[3] << 32) | v[2];
+          ready = ready && ((h * 128 + 2 * lane >= NW * p.NU) || (f0 >= want && f1 >= want));   // stale words carry an older generation
+        }
         if (__all(ready)) break;
         if (!FAST) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0 &&
@@ -1520,7 +1525,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
     // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
     auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4]) {
       const int t = dir == 0 ? step : p.T - 1 - step;
-      float* redb = red + (step & 1) * (4 * NT * 4 * RLD);
+      float* redb = red + (step & 1) * (NW * NT * 4 * RLD);
       if (stamp) p.dbg[step * 8 + 0] = clock64();
       if (step > 0) {
         wait_flags((unsigned)step);
@@ -1533,7 +1538,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
             a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(
-                rh, (p.ablate & 1) ? 0x7ffffff0u : (unsigned)((wave + 4 * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
+                rh, (p.ablate & 1) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
         if (stamp) p.dbg[step * 8 + 6] = clock64();
         load_g(gpre, step + 1);
         if (stamp) p.dbg[step * 8 + 7] = clock64();
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
         if (!(p.ablate & 4)) {
 #pragma unroll
           for (int i = 0; i < CPW; ++i) {
-            if (wave + 4 * i < p.KQ2) {
+            if (wave + NW * i < p.KQ2) {
               const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
               // term-major: NT independent accumulators between two MFMAs on the same one
 #pragma unroll
@@ -1578,17 +1583,20 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         if (e_ok[i]) {
-          // 16 independent LDS reads (4 gates x 4 wave partials) issued together, then summed
-          float part[4][4], pre[4];
+          // 4 gates x NW wave partials: independent LDS reads issued together, then summed pairwise
+          float part[4][NW], pre[4];
 #pragma unroll
           for (int gt = 0; gt < 4; ++gt) {
             const float* src = redb + red_off[i][gt];
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) part[gt][wv] = src[wv * NT * 4 * RLD];
+            for (int wv = 0; wv < NW; ++wv) part[gt][wv] = src[wv * NT * 4 * RLD];
           }
 #pragma unroll
-          for (int gt = 0; gt < 4; ++gt)
-            pre[gt] = ((part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3])) + guse[i][gt];
+          for (int gt = 0; gt < 4; ++gt) {
+            float sum = (part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3]);
+            if constexpr (NW == 8) sum += (part[gt][4] + part[gt][5]) + (part[gt][6] + part[gt][7]);
+            pre[gt] = sum + guse[i][gt];
+          }
           const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
           const float cn = fg2 * cst[i] + ig * gg;
           cst[i] = cn;
@@ -1613,10 +1621,10 @@ __global__ __launch_bounds__(256) void lstm_xcd_kernel(XcdArgs p) {
       if (stamp) p.dbg[step * 8 + 5] = clock64();
       if (lane == 0) {
         if (FAST) {
-          __hip_atomic_store(flags + ugi * 4 + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(flags + ugi * NW + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {   // write this XCD's L2 back, then raise the flag
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __hip_atomic_store(flags + ugi * 4 + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(flags + ugi * NW + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     };
@@ -1802,13 +1810,14 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 
 
 template <int NT>
-static int launch_xcd(XcdArgs xa, hipStream_t st) {
+static int launch_xcd(XcdArgs xa, int nw, hipStream_t st) {
   // <= 4 batch groups of 16 rows per launch (2 directions x 4 = the chip's 8 XCDs)
   for (int r0 = 0; r0 < xa.B; r0 += 64) {
     const int rows = xa.B - r0 < 64 ? xa.B - r0 : 64;
     xa.row0 = r0;
     xa.nbg = ceil_div(rows, 16);
-    hipLaunchKernelGGL((lstm_xcd_kernel<NT>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
+    if (nw == 8) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
+    else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ONSSEN_OK : (int)e;
@@ -2203,12 +2212,15 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 15;
       ONSSEN_CLEAR_ERROR();
+      // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
+      // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase
+      static const int xcd_nw = getenv("ONSSEN_XCD_WAVES") && atoi(getenv("ONSSEN_XCD_WAVES")) == 8 ? 8 : 4;
       switch (ug) {
-        case 4: rc = launch_xcd<1>(xa, st); break;
-        case 8: rc = launch_xcd<2>(xa, st); break;
-        case 12: rc = launch_xcd<3>(xa, st); break;
-        case 16: rc = launch_xcd<4>(xa, st); break;
-        default: rc = launch_xcd<5>(xa, st); break;
+        case 4: rc = launch_xcd<1>(xa, xcd_nw, st); break;
+        case 8: rc = launch_xcd<2>(xa, xcd_nw, st); break;
+        case 12: rc = launch_xcd<3>(xa, xcd_nw, st); break;
+        case 16: rc = launch_xcd<4>(xa, xcd_nw, st); break;
+        default: rc = launch_xcd<5>(xa, xcd_nw, st); break;
       }
       if (rc != ONSSEN_OK) return rc;
       continue;

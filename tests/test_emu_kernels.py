@@ -2,6 +2,8 @@
 HIP runtime (tests/emu) and driven through the same C ABI / ctypes binding as
 the GPU library, checked against the NumPy oracle.  Sizes are tiny (every
 work-item is an OS thread)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -365,3 +367,14 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble):
     got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
     assert np.abs(got - ref).max() < 2e-5
     assert np.all(np.array(y)[:, :, :, H:] == 0)
+
+
+def test_blstm_xcd_eight_wave_variant():
+    """ONSSEN_XCD_WAVES=8 (two waves per SIMD, 256 flags per group) is read once per process: run the persistent-
+    recurrence test in a child interpreter with it set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, ONSSEN_XCD_WAVES="8")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
