@@ -1643,86 +1643,109 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
 }
 
 // =================================================================================================
-// K1+K2 / K10: fp64 radix-2 FFT helpers (one wavefront per frame, data in LDS)
+// K1+K2 / K10: fp64 FFT helpers.  One wavefront transforms one frame in its own LDS buffer: radix-4
+// decimation-in-time stages (N = 4^k, or two half-size transforms + one radix-2 stage for N = 2*4^k), twiddles and
+// the Hann window from a constant table, and NO workgroup barrier: a wave's LDS operations execute in order, so
+// the stages of a frame only need the compiler to keep them in order.
 // =================================================================================================
+#include "fft_tables.inc"
+
 template <int N>
-struct FftTables {
-  double tw_re[N / 2], tw_im[N / 2];  // exp(-2 pi i k / N)
-  double win[N];                       // periodic Hann
+struct FftPlan {
+  static constexpr bool kOdd = (N == 512 || N == 128 || N == 2048);   // N = 2 * 4^k
+  static constexpr int M = kOdd ? N / 2 : N;                           // radix-4 transform length
+  static constexpr int DIG = M == 64 ? 3 : M == 256 ? 4 : M == 1024 ? 5 : 0;
+  static_assert(DIG != 0, "FFT length must be 4^k or 2*4^k with 64 <= 4^k <= 1024");
 };
 
+// LDS position of input sample n so that the in-place stages below end in natural order
 template <int N>
-__device__ __forceinline__ void fft_tables_init(FftTables<N>& tb, int tid, int nthreads) {
-  const double two_pi = 6.283185307179586476925286766559;
-  for (int k = tid; k < N / 2; k += nthreads) {
-    double s, c;
-    sincos(-two_pi * (double)k / (double)N, &s, &c);
-    tb.tw_re[k] = c;
-    tb.tw_im[k] = s;
-  }
-  for (int i = tid; i < N; i += nthreads) tb.win[i] = 0.5 - 0.5 * cos(two_pi * (double)i / (double)N);
-}
-
-template <int LOGN>
-__device__ __forceinline__ int bitrev(int i) {
+__device__ __forceinline__ int fft_perm(int n) {
+  using P = FftPlan<N>;
+  const int m = P::kOdd ? (n >> 1) : n;
   int r = 0;
 #pragma unroll
-  for (int b = 0; b < LOGN; ++b) r |= ((i >> b) & 1) << (LOGN - 1 - b);
-  return r;
+  for (int d = 0; d < P::DIG; ++d) r |= ((m >> (2 * d)) & 3) << (2 * (P::DIG - 1 - d));
+  return (P::kOdd ? (n & 1) * P::M : 0) + r;
 }
 
-// In-place decimation-in-time butterflies over bit-reversed input; every wave of the workgroup calls
-// this together (the stage barrier is workgroup-wide).  inverse = conjugated twiddles, unscaled.
-template <int N, int LOGN>
-__device__ __forceinline__ void fft_stages(double* re, double* im, const FftTables<N>& tb, int lane, bool inverse) {
-  for (int s = 0; s < LOGN; ++s) {
-    const int half = 1 << s;
-    __syncthreads();
-    for (int j = lane; j < N / 2; j += 64) {
-      const int pos = j & (half - 1);
-      const int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half;
-      const int tk = pos << (LOGN - 1 - s);
-      const double wr = tb.tw_re[tk], wi = inverse ? -tb.tw_im[tk] : tb.tw_im[tk];
-      const double xr = re[i1], xi = im[i1];
-      const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-      const double ur = re[i0], ui = im[i0];
-      re[i0] = ur + tr;
-      im[i0] = ui + ti;
-      re[i1] = ur - tr;
-      im[i1] = ui - ti;
+template <int N>
+__device__ __forceinline__ double fft_win(int i) { return 0.5 - 0.5 * kCos1024[i * (1024 / N)]; }   // periodic Hann
+
+// In-place FFT of the wave's frame (input at fft_perm positions, output in natural order).  inverse = conjugated
+// twiddles, unscaled.  Every lane of the wave calls this.
+template <int N>
+__device__ __forceinline__ void fft_wave(double* re, double* im, int lane, bool inverse) {
+  using P = FftPlan<N>;
+  constexpr int M = P::M;
+  const double sg = inverse ? 1.0 : -1.0;   // sign of the imaginary part of the twiddles / of the +-i rotations
+#pragma unroll
+  for (int d = 0; d < P::DIG; ++d) {
+    const int Ls = 1 << (2 * d);            // length of the four sub-transforms being combined
+    __builtin_amdgcn_wave_barrier();
+    for (int u = lane; u < N / 4; u += 64) {
+      const int sub = u / (M / 4), v = u % (M / 4);
+      const int j = v & (Ls - 1), base = sub * M + ((v >> (2 * d)) << (2 * d + 2)) + j;
+      const int tk = j * (1024 / (4 * Ls));            // W_{4Ls}^j = table[tk]
+      double xr[4], xi[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double ar = re[base + q * Ls], ai = im[base + q * Ls];
+        if (q == 0 || d == 0) {
+          xr[q] = ar;
+          xi[q] = ai;
+        } else {
+          const double wr = kCos1024[q * tk], wi = sg * kSin1024[q * tk];
+          xr[q] = ar * wr - ai * wi;
+          xi[q] = ar * wi + ai * wr;
+        }
+      }
+      // y0 = x0+x1+x2+x3, y1 = x0 + s*i*x1 - x2 - s*i*x3 (s = sg: -i forward), y2 = x0-x1+x2-x3, y3 = x0 - s*i*x1 - x2 + s*i*x3
+      const double ar = xr[0] + xr[2], ai = xi[0] + xi[2], br = xr[0] - xr[2], bi = xi[0] - xi[2];
+      const double cr = xr[1] + xr[3], ci = xi[1] + xi[3], dr = xr[1] - xr[3], di = xi[1] - xi[3];
+      re[base] = ar + cr;           im[base] = ai + ci;
+      re[base + 2 * Ls] = ar - cr;  im[base + 2 * Ls] = ai - ci;
+      // s*i*(dr + i di) = s*(-di + i dr)
+      re[base + Ls] = br - sg * di;      im[base + Ls] = bi + sg * dr;
+      re[base + 3 * Ls] = br + sg * di;  im[base + 3 * Ls] = bi - sg * dr;
     }
   }
-  __syncthreads();
+  if (P::kOdd) {   // X[k] = E[k] + W_N^k O[k], X[k + N/2] = E[k] - W_N^k O[k]
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < N / 2; k += 64) {
+      const double wr = kCos1024[k * (1024 / N)], wi = sg * kSin1024[k * (1024 / N)];
+      const double er = re[k], ei = im[k], orr = re[k + N / 2], oi = im[k + N / 2];
+      const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
+      re[k] = er + tr;          im[k] = ei + ti;
+      re[k + N / 2] = er - tr;  im[k + N / 2] = ei - ti;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
-template <int N, int LOGN>
+template <int N>
 __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ wav, int B, int n_samples,
                                                           long wav_stride, int hop, int T, float eps,
                                                           float* __restrict__ logmag, float* __restrict__ stft_ri) {
-  __shared__ FftTables<N> tb;
   __shared__ double buf_re[4][N], buf_im[4][N];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int F = N / 2 + 1;
-  fft_tables_init<N>(tb, tid, 256);
-  __syncthreads();
   const long total = (long)B * T;
-  const long frame = (long)blockIdx.x * 4 + wave;
-  const bool active = frame < total;
-  const int b = active ? (int)(frame / T) : 0, t = active ? (int)(frame % T) : 0;
   double* re = buf_re[wave];
   double* im = buf_im[wave];
-  const float* sig = wav + (long)b * wav_stride;
-  for (int i = lane; i < N; i += 64) {
-    int pidx = t * hop + i - N / 2;  // centred frame, reflect padding (edge sample not repeated)
-    if (pidx < 0) pidx = -pidx;
-    if (pidx >= n_samples) pidx = 2 * (n_samples - 1) - pidx;
-    const double v = active ? (double)sig[pidx] * tb.win[i] : 0.0;
-    const int j = bitrev<LOGN>(i);
-    re[j] = v;
-    im[j] = 0.0;
-  }
-  fft_stages<N, LOGN>(re, im, tb, lane, false);
-  if (active) {
+  // grid-stride over frames, one frame per wave at a time; no workgroup-wide synchronisation anywhere
+  for (long frame = (long)blockIdx.x * 4 + wave; frame < total; frame += (long)gridDim.x * 4) {
+    const int b = (int)(frame / T), t = (int)(frame % T);
+    const float* sig = wav + (long)b * wav_stride;
+    for (int i = lane; i < N; i += 64) {
+      int pidx = t * hop + i - N / 2;  // centred frame, reflect padding (edge sample not repeated)
+      if (pidx < 0) pidx = -pidx;
+      if (pidx >= n_samples) pidx = 2 * (n_samples - 1) - pidx;
+      const int j = fft_perm<N>(i);
+      re[j] = (double)sig[pidx] * fft_win<N>(i);
+      im[j] = 0.0;
+    }
+    fft_wave<N>(re, im, lane, false);
     for (int f = lane; f < F; f += 64) {
       const float xr = (float)re[f], xi = (float)im[f];  // complex128 -> complex64 like the reference
       const long o = (frame * F + f);
@@ -1732,23 +1755,22 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
         stft_ri[2 * o + 1] = xi;
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the next frame overwrites the buffer
   }
 }
 
 // FB = frames transformed per workgroup (FB/4 rounds of 4 waves); sized so that the LDS image
 // (tables + 4 FFT buffers + FB windowed frames, all fp64) stays under 160 KiB.
-template <int N, int LOGN, int FB>
+template <int N, int FB>
 __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ stft_ri,
                                                          const float* __restrict__ mask, long m_sb, long m_sc,
                                                          long m_st, long m_sf, int C, int T, int hop, int length,
                                                          int FR, float* __restrict__ out) {
-  __shared__ FftTables<N> tb;
   __shared__ double buf_re[4][N], buf_im[4][N];
   __shared__ double fr[FB][N];  // windowed time-domain frames of this chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int F = N / 2 + 1;
   const int chunk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
-  fft_tables_init<N>(tb, tid, 256);
   // output samples n in [chunk*FR*hop, +FR*hop); padded position p = n + N/2 is covered by frames
   // t with t*hop <= p < t*hop + N
   const int p0 = chunk * FR * hop + N / 2;
@@ -1760,7 +1782,6 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
     const bool active = t < T;
     double* re = buf_re[wave];
     double* im = buf_im[wave];
-    __syncthreads();  // tables ready / previous round's buffers consumed
     const float* xs = stft_ri + ((long)(b * T + (active ? t : 0)) * F) * 2;
     const float* ms = mask ? mask + (long)b * m_sb + (long)c * m_sc + (long)(active ? t : 0) * m_st : nullptr;
     for (int f = lane; f < F; f += 64) {
@@ -1771,17 +1792,18 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
         xi = (double)xs[2 * f + 1] * (double)mv;
       }
       if (f == 0 || f == N / 2) xi = 0.0;  // c2r transforms ignore the imaginary part of DC / Nyquist
-      const int j = bitrev<LOGN>(f);
+      const int j = fft_perm<N>(f);
       re[j] = xr;
       im[j] = xi;
       if (f > 0 && f < N / 2) {  // Hermitian mirror
-        const int jm = bitrev<LOGN>(N - f);
+        const int jm = fft_perm<N>(N - f);
         re[jm] = xr;
         im[jm] = -xi;
       }
     }
-    fft_stages<N, LOGN>(re, im, tb, lane, true);
-    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? tb.win[i] * (re[i] * inv_n) : 0.0;
+    fft_wave<N>(re, im, lane, true);
+    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? fft_win<N>(i) * (re[i] * inv_n) : 0.0;
+    __builtin_amdgcn_wave_barrier();   // the wave's next round overwrites its buffer
   }
   __syncthreads();
   const int exp_len = N + hop * (T - 1);
@@ -1799,7 +1821,8 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
       for (int t = tlo; t <= thi && t - tfirst < FB; ++t) {
         const int i = pp - t * hop;
         s += fr[t - tfirst][i];
-        wss += tb.win[i] * tb.win[i];
+        const double w = fft_win<N>(i);
+        wss += w * w;
       }
       y = (wss > 2.2250738585072014e-308) ? s / wss : s;
     }
@@ -1886,13 +1909,13 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
-    hipLaunchKernelGGL((stft_logmag_kernel<256, 8>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
+    hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
                        eps, logmag, stft_ri);
   else if (n_fft == 512)
-    hipLaunchKernelGGL((stft_logmag_kernel<512, 9>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
+    hipLaunchKernelGGL((stft_logmag_kernel<512>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
                        eps, logmag, stft_ri);
   else if (n_fft == 1024)
-    hipLaunchKernelGGL((stft_logmag_kernel<1024, 10>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop,
+    hipLaunchKernelGGL((stft_logmag_kernel<1024>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop,
                        T, eps, logmag, stft_ri);
   else
     return ONSSEN_E_ARG;
@@ -2324,13 +2347,13 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
   const dim3 grid((unsigned)ceil_div(length, FR * hop), (unsigned)C, (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
-    hipLaunchKernelGGL((mask_istft_kernel<256, 8, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+    hipLaunchKernelGGL((mask_istft_kernel<256, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
                        (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
   else if (n_fft == 512)
-    hipLaunchKernelGGL((mask_istft_kernel<512, 9, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+    hipLaunchKernelGGL((mask_istft_kernel<512, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
                        (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
   else if (n_fft == 1024)
-    hipLaunchKernelGGL((mask_istft_kernel<1024, 10, 8>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
+    hipLaunchKernelGGL((mask_istft_kernel<1024, 8>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
                        (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
   else
     return ONSSEN_E_ARG;
