@@ -213,6 +213,18 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
                           int iters, float* masks, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N1 (forward)  deep-clustering loss VALUE (validation / monitoring; the training backward stays on autograd):
+ *   per_utt[b] = ||V^T V||_F - 2 ||V^T Y||_F + ||Y^T Y||_F,  V = w * (sum_c Y) * emb, Y = w * one_hot,
+ *   w_r = sqrt(mag_r / total_mag[b]),  total_mag[b] = sum_r mag_r            (Frobenius NORMS, as upstream)
+ * Replaces onssen/loss/loss_dc.py:24-43 + loss_util.py:4-11; the caller forms upstream's (B,B) product
+ * per_utt[None,:] * total_mag[:,None] (loss_dc.py:44) and its mean (utils/train.py:78-79).
+ *   emb (B, TF, D), one_hot (B, TF, C) as float, mag (B, TF); D + C <= 34.
+ */
+size_t onssen_loss_dc_workspace_bytes(int B);
+int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
+                       float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10  mask-apply + inverse STFT overlap-add.
  * Replaces `stft_est = stft_mix * mask; librosa.core.istft(stft_est[i].T, hop_length, length)` at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:42-45 and egs/wsj0-2mix/chimera/evaluate.py:40-43.

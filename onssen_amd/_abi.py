@@ -39,6 +39,8 @@ SIGNATURES = {
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
+    "onssen_loss_dc_workspace_bytes": (_sz, [_i]),
+    "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
@@ -78,6 +80,13 @@ class Lib:
 
     def lstm_pack_whh_bf16x3(self, w_hh, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_whh_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whh_bf16x3")
+
+    def loss_dc_workspace_bytes(self, B):
+        return int(self.dll.onssen_loss_dc_workspace_bytes(B))
+
+    def loss_dc(self, emb, one_hot, mag, B, TF, D, Cc, per_utt, total_mag, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_loss_dc_f32(emb, one_hot, mag, B, TF, D, Cc, per_utt, total_mag, ws, ws_bytes, stream),
+                   "onssen_loss_dc_f32")
 
     def blstm_workspace_bytes(self, B, T, in_dim, H, L, ug):
         return int(self.dll.onssen_blstm_workspace_bytes(B, T, in_dim, H, L, ug))

@@ -1875,6 +1875,115 @@ __global__ void probe_kernel(float* p) {
 }
 
 // =================================================================================================
+// N1 (forward half): deep-clustering loss value, onssen/loss/loss_dc.py:6-44 with loss_util.py:4-11.
+// Per utterance b: z_r = [ s_r * V_r (D) | Y_r (C) ], s_r = sum_c Y_r[c] (0 on silent bins), weight w_r^2 =
+// mag_r / sum_r mag_r.  Everything the loss needs is the (D+C) x (D+C) Gram matrix G = sum_r mag_r z_r z_r^T:
+// V^T V, V^T Y and Y^T Y are its blocks, and the 1/sum(mag) scale is applied at the end (the weights are
+// linear in the Gram), so the embedding is streamed from HBM exactly once.
+// =================================================================================================
+namespace lossdc {
+constexpr int NBLK = 64;        // row blocks per utterance (partials reduced in a fixed order: deterministic)
+constexpr int RT = 64;          // rows per LDS tile
+constexpr int ZMAX = 34;        // D + C <= 34
+}  // namespace lossdc
+
+__global__ __launch_bounds__(256) void loss_dc_partial_kernel(const float* __restrict__ emb, const float* __restrict__ one_hot,
+                                                              const float* __restrict__ mag, int TF, int D, int C,
+                                                              float* __restrict__ partial) {
+  using namespace lossdc;
+  __shared__ float q[RT][ZMAX + 1];      // sqrt(mag_r) * z_r
+  __shared__ float msum[256];
+  const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+  const int Z = D + C, nout = Z * Z;
+  const int rows_per = (TF + NBLK - 1) / NBLK, r0 = blk * rows_per, r1 = r0 + rows_per < TF ? r0 + rows_per : TF;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // outputs tid, tid+256, ... (Z*Z <= 1156)
+  float mtot = 0.f;
+  const long base = (long)b * TF;
+  for (int t0 = r0; t0 < r1; t0 += RT) {
+    const int nr = r1 - t0 < RT ? r1 - t0 : RT;
+    __syncthreads();
+    for (int e = tid; e < nr * Z; e += 256) {
+      const int r = e / Z, a = e % Z;
+      const long row = base + t0 + r;
+      const float m = mag[row];
+      float v;
+      if (a < D) {
+        float sact = 0.f;
+        for (int c = 0; c < C; ++c) sact += one_hot[row * C + c];
+        v = sact * emb[row * D + a];
+      } else {
+        v = one_hot[row * C + (a - D)];
+      }
+      q[r][a] = sqrtf(m) * v;
+    }
+    for (int r = tid; r < nr; r += 256) mtot += mag[base + t0 + r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int o = tid + 256 * k;
+      if (o < nout) {
+        const int i = o / Z, j = o % Z;
+        float sum = acc[k];
+        for (int r = 0; r < nr; ++r) sum += q[r][i] * q[r][j];
+        acc[k] = sum;
+      }
+    }
+  }
+  float* dst = partial + ((long)b * NBLK + blk) * (ZMAX * ZMAX + 1);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int o = tid + 256 * k;
+    if (o < nout) dst[o] = acc[k];
+  }
+  msum[tid] = mtot;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if (tid < sft) msum[tid] += msum[tid + sft];
+    __syncthreads();
+  }
+  if (tid == 0) dst[ZMAX * ZMAX] = msum[0];
+}
+
+// one workgroup per utterance: reduce the partial Grams, then ||V^T V||_F - 2 ||V^T Y||_F + ||Y^T Y||_F
+__global__ __launch_bounds__(256) void loss_dc_final_kernel(const float* __restrict__ partial, int D, int C,
+                                                            float* __restrict__ per_utt, float* __restrict__ total_mag) {
+  using namespace lossdc;
+  __shared__ double red[3][256];
+  __shared__ float tot;
+  const int tid = threadIdx.x, b = blockIdx.x, Z = D + C, nout = Z * Z;
+  const float* src = partial + (long)b * NBLK * (ZMAX * ZMAX + 1);
+  if (tid == 0) {
+    float t = 0.f;
+    for (int k = 0; k < NBLK; ++k) t += src[(long)k * (ZMAX * ZMAX + 1) + ZMAX * ZMAX];
+    tot = t;
+  }
+  __syncthreads();
+  double s_vv = 0.0, s_vy = 0.0, s_yy = 0.0;
+  for (int o = tid; o < nout; o += 256) {
+    float g = 0.f;
+    for (int k = 0; k < NBLK; ++k) g += src[(long)k * (ZMAX * ZMAX + 1) + o];
+    g /= tot;                                  // w_r^2 = mag_r / sum(mag)
+    const int i = o / Z, j = o % Z;
+    const double g2 = (double)g * (double)g;
+    if (i < D && j < D) s_vv += g2;
+    else if (i < D && j >= D) s_vy += g2;
+    else if (i >= D && j >= D) s_yy += g2;
+  }
+  red[0][tid] = s_vv; red[1][tid] = s_vy; red[2][tid] = s_yy;
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if (tid < sft) {
+      red[0][tid] += red[0][tid + sft]; red[1][tid] += red[1][tid + sft]; red[2][tid] += red[2][tid + sft];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    per_utt[b] = (float)(sqrt(red[0][0]) - 2.0 * sqrt(red[1][0]) + sqrt(red[2][0]));
+    total_mag[b] = tot;
+  }
+}
+
+// =================================================================================================
 // C ABI
 // =================================================================================================
 extern "C" {
@@ -2113,6 +2222,26 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   if (mode == ONSSEN_EPI_BIAS) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS>), grid, block, 0, st, p);
   else if (mode == ONSSEN_EPI_L2NORM) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_L2NORM>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_SIGMOID>), grid, block, 0, st, p);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+
+size_t onssen_loss_dc_workspace_bytes(int B) {
+  return B > 0 ? (size_t)B * lossdc::NBLK * (lossdc::ZMAX * lossdc::ZMAX + 1) * sizeof(float) : 0;
+}
+
+int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
+                       float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream) {
+  if (!emb || !one_hot || !mag || !per_utt || !total_mag || !ws || B <= 0 || TF <= 0 || D <= 0 || C <= 0 ||
+      D + C > lossdc::ZMAX)
+    return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_loss_dc_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_dc_partial_kernel, dim3(lossdc::NBLK, (unsigned)B), dim3(256), 0, st, emb, one_hot, mag, TF, D, C,
+                     (float*)ws);
+  hipLaunchKernelGGL(loss_dc_final_kernel, dim3((unsigned)B), dim3(256), 0, st, (const float*)ws, D, C, per_utt, total_mag);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

@@ -1,6 +1,7 @@
 """Training losses needed by the data-parallel step.
 
-Stock PyTorch ops with autograd (the fused HIP version is a 'next' row).
+With autograd (training): stock PyTorch ops.  Without (``trainer.validate``, onssen/utils/train.py:91-99, runs the
+loss under ``no_grad``): the HIP kernel ``onssen_loss_dc_f32``, which streams the embedding once.
 Semantics follow onssen/loss/loss_dc.py:6-44 and loss_util.py:4-11 exactly,
 including their quirks: the affinity terms are Frobenius *norms* (not squared
 norms) and the final product ``(B,) * (B,1)`` broadcasts to a (B, B) tensor
@@ -21,6 +22,8 @@ def loss_dc(output, label):
     one_hot = one_hot.float()
     B, T, F, C = one_hot.shape
     D = embedding.shape[-1]
+    if embedding.is_cuda and not (torch.is_grad_enabled() and embedding.requires_grad) and D + C <= 34:
+        return _loss_dc_hip(embedding.float().contiguous(), one_hot.contiguous(), mag_mix.float().contiguous(), B, T * F, D, C)
     V = embedding.reshape(B, T * F, D)
     Y = one_hot.reshape(B, T * F, C)
     mag = mag_mix.detach().reshape(B, T * F)
@@ -33,3 +36,21 @@ def loss_dc(output, label):
     yty = torch.bmm(Y.transpose(1, 2), Y)
     per_utt = _fro(vtv) - 2 * _fro(vty) + _fro(yty)      # (B,)
     return per_utt * total                               # (B,) * (B,1) -> (B,B), as upstream
+
+
+_WS = {}
+
+
+def _loss_dc_hip(emb, one_hot, mag, B, TF, D, C):
+    from .hip import get_lib
+    lib = get_lib()
+    dev = emb.device
+    nbytes = lib.loss_dc_workspace_bytes(B)
+    ws = _WS.get((dev, B))
+    if ws is None:
+        ws = _WS[(dev, B)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    per_utt = torch.empty(B, device=dev, dtype=torch.float32)
+    total = torch.empty(B, device=dev, dtype=torch.float32)
+    lib.loss_dc(emb.data_ptr(), one_hot.data_ptr(), mag.data_ptr(), B, TF, D, C, per_utt.data_ptr(), total.data_ptr(),
+                ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    return per_utt * total.unsqueeze(1)                  # (B,) * (B,1) -> (B,B), as upstream

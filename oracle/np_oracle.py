@@ -256,3 +256,29 @@ def phase_net_forward(sd, x_mag, x_phase, dtype=np.float32):
         p = p.reshape(B, T, F, -1) + x_phase
         outs.append(l2_normalize(p))
     return [e, mA, mB, outs[0], outs[1]]
+
+
+# ----------------------------------------------------------------------------- N1: deep-clustering loss value
+def loss_dc_per_utt(embedding, one_hot, mag_mix):
+    """Per-utterance deep-clustering loss term of onssen/loss/loss_dc.py:24-42 (fp64 here):
+    silent bins drop out of V (:29-30), both factors are weighted by sqrt(|x_i| / sum_j |x_j|) (:34-36), and the
+    three affinity terms are Frobenius NORMS, not squared norms (loss_util.py:7-11, loss_dc.py:39-42).
+    embedding (B, TF, D), one_hot (B, TF, C), mag_mix (B, TF) -> (B,)"""
+    V = np.asarray(embedding, np.float64)
+    Y = np.asarray(one_hot, np.float64)
+    mag = np.asarray(mag_mix, np.float64)
+    V = Y.sum(2, keepdims=True) * V
+    w = np.sqrt(mag / mag.sum(1, keepdims=True))[..., None]
+    V, Y = V * w, Y * w
+    fro = lambda a: np.sqrt((a * a).reshape(a.shape[0], -1).sum(1))
+    Vt = V.transpose(0, 2, 1)
+    return fro(Vt @ V) - 2.0 * fro(Vt @ Y) + fro(Y.transpose(0, 2, 1) @ Y)
+
+
+def loss_dc(embedding, one_hot, mag_mix):
+    """The (B, B) tensor upstream returns (loss_dc.py:44: (B,) * (B,1) broadcasts) -- its mean is the training loss
+    (onssen/utils/train.py:78-79).  embedding (B,T,F,D), one_hot (B,T,F,C), mag_mix (B,T,F)."""
+    B = embedding.shape[0]
+    per = loss_dc_per_utt(embedding.reshape(B, -1, embedding.shape[-1]), one_hot.reshape(B, -1, one_hot.shape[-1]),
+                          mag_mix.reshape(B, -1))
+    return per[None, :] * np.asarray(mag_mix, np.float64).reshape(B, -1).sum(1)[:, None]

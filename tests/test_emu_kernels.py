@@ -378,3 +378,23 @@ def test_blstm_xcd_eight_wave_variant():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3)])
+def test_loss_dc_value(lib, B, TF, D, C):
+    """onssen_loss_dc_f32 against the NumPy restatement of loss_dc (Frobenius norms of the weighted affinity blocks)."""
+    rng = np.random.default_rng(5)
+    emb = rand(rng, B, TF, D)
+    emb /= np.linalg.norm(emb, axis=-1, keepdims=True)
+    lab = rng.integers(0, C + 1, size=(B, TF))                      # C = silent bin
+    one_hot = np.zeros((B, TF, C), np.float32)
+    for c in range(C):
+        one_hot[..., c] = lab == c
+    mag = np.abs(rand(rng, B, TF)) + 0.01
+    per_utt = np.full(B, np.nan, np.float32)
+    total = np.full(B, np.nan, np.float32)
+    ws = aligned_f32(lib.loss_dc_workspace_bytes(B) // 4 + 64)
+    lib.loss_dc(P(emb), P(one_hot), P(mag), B, TF, D, C, P(per_utt), P(total), P(ws), ws.nbytes, None)
+    ref = O.loss_dc_per_utt(emb, one_hot, mag)
+    np.testing.assert_allclose(total, mag.sum(1), rtol=1e-5)
+    np.testing.assert_allclose(per_utt, ref, rtol=1e-4, atol=1e-6)

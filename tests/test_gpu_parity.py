@@ -433,3 +433,29 @@ def test_xcd_placement_independent_protocol(dev, monkeypatch, B, T, H, L):
     assert _core._XcdStatus.safe_protocol_seen
     np.testing.assert_allclose(emb, ref, atol=5e-5, rtol=1e-4)
     np.testing.assert_array_equal(emb, emb2)
+
+
+def test_loss_dc_value_on_device_matches_reference_fixture(dev, golden_dir, monkeypatch):
+    """N1 (forward): validation-style loss -- HIP forward + onssen_loss_dc_f32 under no_grad -- against the value the
+    reference's loss_dc produced (G4 fixture), and against the oracle on a full-size batch."""
+    from onssen_amd.loss import loss_dc
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    z = np.load(f"{golden_dir}/g4_loss_dc.npz")
+    cfg = dict(F=129, H=int(z["H"]), L=int(z["L"]), D=20, C=2, seed=int(z["seed"]), gain=1.0)
+    m, _ = build("deep_clustering", cfg, dev)
+    with torch.no_grad():
+        out = m([torch.from_numpy(z["x"]).to(dev)])
+        loss = loss_dc(out, [torch.from_numpy(z["one_hot"]).to(dev), torch.from_numpy(z["mag"]).to(dev)])
+    assert tuple(loss.shape) == (3, 3)
+    np.testing.assert_allclose(loss.cpu().numpy(), z["loss"], rtol=1e-4)
+    # BASELINE-size rows: 4 x (400 x 129) bins, D = 20
+    rng = np.random.default_rng(9)
+    B, T, F, D = 4, 400, 129, 20
+    emb = rng.standard_normal((B, T, F, D)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=-1, keepdims=True)
+    lab = rng.integers(0, 3, size=(B, T, F))
+    one_hot = np.stack([lab == 0, lab == 1], -1).astype(np.float64)
+    mag = (np.abs(rng.standard_normal((B, T, F))) + 1e-3).astype(np.float32)
+    with torch.no_grad():
+        got = loss_dc([torch.from_numpy(emb).to(dev)], [torch.from_numpy(one_hot).to(dev), torch.from_numpy(mag).to(dev)])
+    np.testing.assert_allclose(got.cpu().numpy(), O.loss_dc(emb, one_hot, mag), rtol=1e-4)

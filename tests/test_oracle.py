@@ -120,3 +120,16 @@ def test_torch_cpu_restatement_matches_reference_golden(golden_dir):
     outs = TC.phase_net_forward(sd, z["x"], z["x_phase"])
     np.testing.assert_allclose(outs[3].numpy(), z["out_phase_A"], atol=1e-6)
     np.testing.assert_allclose(outs[4].numpy(), z["out_phase_B"], atol=1e-6)
+
+
+def test_loss_dc_restatement_matches_reference_fixture(golden_dir):
+    """N1: oracle/np_oracle.loss_dc against the reference's own loss_dc (tools/gen_golden.py G4): value and the
+    (B, B) broadcast quirk, on the reference network's embedding reproduced by the oracle forward."""
+    from onssen_amd.synthetic import make_state_dict
+    z = np.load(f"{golden_dir}/g4_loss_dc.npz")
+    sd = make_state_dict("deep_clustering", 129, int(z["H"]), int(z["L"]), 20, 2, seed=int(z["seed"]))
+    emb = O.deep_clustering_forward(sd, z["x"])
+    loss = O.loss_dc(emb, z["one_hot"], z["mag"])
+    assert loss.shape == z["loss"].shape == (3, 3)
+    np.testing.assert_allclose(loss, z["loss"], rtol=1e-4)
+    np.testing.assert_allclose(loss.mean(), float(z["loss_mean"]), rtol=1e-4)
