@@ -671,7 +671,6 @@ namespace lxp {
 constexpr int BM = 256, BN = 160;
 constexpr int RS = 144;                      // LDS row stride in bytes: 128 + 16 pad (conflict-free 16-byte fragment reads)
 constexpr int STAGE = (BM + BN) * RS;        // 59,904 B per stage, two stages
-constexpr int A_IT = BM / 32, W_IT = BN / 32;   // 16-byte chunks per thread per k-step: 8 + 5
 }  // namespace lxp
 
 struct LinearXpArgs {
@@ -692,9 +691,15 @@ struct LinearXpArgs {
 #define ONSSEN_XP_ABLATE 0
 #endif
 
-template <int MODE>
-__global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
+// WMS = waves along M (2 waves along N always): 2 -> 4 waves x (128x80), one per SIMD; 4 -> 8 waves x (64x80), two
+// per SIMD (denser MFMA issue and the hardware overlaps one wave's waits with the other's MFMAs, for 38 % more
+// fragment reads)
+template <int MODE, int WMS>
+__global__ __launch_bounds__(128 * WMS) void linear_x3p_kernel(LinearXpArgs p) {
   using namespace lxp;
+  constexpr int NTHR = 128 * WMS, MT = 16 / WMS, WROWS = BM / WMS;
+  constexpr int RSTEP = NTHR / 8;                                   // rows staged per pass of the workgroup
+  constexpr int A_IT = BM / RSTEP, W_IT = (BN + RSTEP - 1) / RSTEP;   // 16-byte chunks per thread per k-step
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
       (void*)(p.A + (long)m0 * p.KB * 64), 0, a_rows * pitch, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.W + (long)n0 * p.KB * 64), 0, w_rows * pitch, 0x00020000);
-  // staging: thread -> (row = tid/8 + 32*it, 16-byte chunk tid%8); rows past the matrix are out of range -> 0
+  // staging: thread -> (row = tid/8 + RSTEP*it, 16-byte chunk tid%8); rows past the matrix are out of range -> 0
   const int srow = tid >> 3, sch = tid & 7;
   const unsigned g_voff = (unsigned)(srow * pitch + sch * 16);
   const unsigned l_off = (unsigned)(srow * RS + sch * 16);
@@ -742,19 +747,20 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
     // they read zeros, never memory -- so the loop needs no "is there a next tile" predicate, its body exists
     // exactly once per parity, and an odd number of k-steps is rounded up with a tile of zeros
     const unsigned koff = kb < p.KB ? (unsigned)(kb * 128) : 0x40000000u;
-    if (j < A_IT) rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, g_voff + (unsigned)(j * 32 * pitch) + koff, 0, 0);
-    else rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, g_voff + (unsigned)((j - A_IT) * 32 * pitch) + koff, 0, 0);
+    if (j < A_IT) rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, g_voff + (unsigned)(j * RSTEP * pitch) + koff, 0, 0);
+    else rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, g_voff + (unsigned)((j - A_IT) * RSTEP * pitch) + koff, 0, 0);
   };
   auto s_store1 = [&](auto set_c, int j, int stage) {
     constexpr int S = decltype(set_c)::value;
     if constexpr ((ONSSEN_XP_ABLATE & 2) != 0) return;
-    unsigned char* base = smem + stage * STAGE + (j < A_IT ? j * 32 * RS : BM * RS + (j - A_IT) * 32 * RS);
-    *reinterpret_cast<u32x4*>(base + l_off) = rg[S][j];
+    unsigned char* base = smem + stage * STAGE + (j < A_IT ? j * RSTEP * RS : BM * RS + (j - A_IT) * RSTEP * RS);
+    if (j < A_IT || (j - A_IT) * RSTEP + RSTEP <= BN || srow + (j - A_IT) * RSTEP < BN)   // last W pass may be partial
+      *reinterpret_cast<u32x4*>(base + l_off) = rg[S][j];
   };
 
-  f32x4 acc[8][5];
+  f32x4 acc[MT][5];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -762,7 +768,7 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
   const long long clk0 = clock64(), wclk0 = wall_clock64();
 #endif
   const int nkb = p.KB;
-  const unsigned fa_off = (unsigned)((wm * 128 + fi) * RS + fg * 16);             // + mt*16*RS (+64 for lo)
+  const unsigned fa_off = (unsigned)((wm * WROWS + fi) * RS + fg * 16);             // + mt*16*RS (+64 for lo)
   const unsigned fw_off = (unsigned)(BM * RS + (wn * 80 + fi) * RS + fg * 16);    // + nt*16*RS (+64 for lo)
   constexpr bool FR = (ONSSEN_XP_ABLATE & 8) == 0;
   auto frag = [&](const unsigned char* sb, unsigned off) {
@@ -788,9 +794,9 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
     constexpr int E = decltype(e_c)::value;
     using eo = std::integral_constant<int, E ^ 1>;
     const unsigned char* sb = smem + E * STAGE;
-    s16x8 xh[8], xl[8];
+    s16x8 xh[MT], xl[MT];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       xh[mt] = frag(sb, fa_off + mt * 16 * RS);
       xl[mt] = frag(sb, fa_off + mt * 16 * RS + 64);
     }
@@ -810,10 +816,10 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
         }
       }
       if constexpr ((ONSSEN_XP_ABLATE & 4) != 0) {
-        acc[0][nt][0] += (float)(wh[0] + wl[0] + xh[nt][0] + xl[nt][0] + xh[nt + 3][0] + xl[nt + 3][0]);
+        acc[0][nt][0] += (float)(wh[0] + wl[0] + xh[nt % MT][0] + xl[nt % MT][0] + xh[(nt + 3) % MT][0] + xl[(nt + 3) % MT][0]);
       } else {
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           acc[mt][nt] = mfma_bf16(wh, xl[mt], acc[mt][nt]);   // small terms first
           acc[mt][nt] = mfma_bf16(wl, xh[mt], acc[mt][nt]);
           acc[mt][nt] = mfma_bf16(wh, xh[mt], acc[mt][nt]);
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
   }
 #endif
   // ---- epilogue in registers: lane holds, per (mt, nt), features n = n0 + wn*80 + nt*16 + 4*fg + {0..3} of row
-  //      m = m0 + wm*128 + mt*16 + fi
+  //      m = m0 + wm*WROWS + mt*16 + fi
   float4 bv[5];
 #pragma unroll
   for (int nt = 0; nt < 5; ++nt) {
@@ -848,8 +854,8 @@ __global__ __launch_bounds__(256) void linear_x3p_kernel(LinearXpArgs p) {
     bv[nt].w = n + 3 < p.N ? p.bias[n + 3] : 0.f;
   }
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int m = m0 + wm * 128 + mt * 16 + fi;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * WROWS + mt * 16 + fi;
     float4 v[5];
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt)
@@ -2217,11 +2223,18 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
-  const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(256);
+  static const int xp_wms = getenv("ONSSEN_X3P_WAVES") && atoi(getenv("ONSSEN_X3P_WAVES")) == 4 ? 2 : 4;   // 8 waves unless =4
+  const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(128 * xp_wms);
   hipStream_t st = (hipStream_t)stream;
-  if (mode == ONSSEN_EPI_BIAS) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS>), grid, block, 0, st, p);
-  else if (mode == ONSSEN_EPI_L2NORM) hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_L2NORM>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_SIGMOID>), grid, block, 0, st, p);
+#define ONSSEN_XP(MODE_)                                                                           \
+  do {                                                                                             \
+    if (xp_wms == 4) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 4>), grid, block, 0, st, p);     \
+    else hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 2>), grid, block, 0, st, p);                 \
+  } while (0)
+  if (mode == ONSSEN_EPI_BIAS) ONSSEN_XP(ONSSEN_EPI_BIAS);
+  else if (mode == ONSSEN_EPI_L2NORM) ONSSEN_XP(ONSSEN_EPI_L2NORM);
+  else ONSSEN_XP(ONSSEN_EPI_SIGMOID);
+#undef ONSSEN_XP
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

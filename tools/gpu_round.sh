@@ -1,25 +1,11 @@
 #!/bin/bash
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
-python - <<'PY' 2>&1 | grep -v amdgpu.ids | tail -4
-import torch, time, numpy as np
-from onssen_amd.loss import loss_dc
-dev = torch.device("cuda:0")
-B, T, F, D = 32, 400, 129, 20
-emb = torch.nn.functional.normalize(torch.randn(B, T, F, D, device=dev), dim=-1)
-lab = torch.randint(0, 3, (B, T, F), device=dev)
-one_hot = torch.stack([lab == 0, lab == 1], -1).double()
-mag = torch.rand(B, T, F, device=dev) + 1e-3
-def timeit(fn, n=10):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n): fn()
-    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
-oh32 = one_hot.float()
-with torch.no_grad():
-    t_hip = timeit(lambda: loss_dc([emb], [oh32, mag]))
-e2 = emb.clone().requires_grad_(True)
-t_aten = timeit(lambda: loss_dc([e2], [oh32, mag]))
-print(f"loss_dc value, B=32 x 51600 bins x D=20: HIP {t_hip:.3f} ms ({emb.numel()*4/t_hip/1e6:.0f} GB/s of embedding read) | ATen ops (autograd path, forward only) {t_aten:.3f} ms")
+for c in dc_l2 chimera_l4; do
+timeout 300 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err
+python - <<PY
+import json
+r = json.loads(open("gpurun_out/bench_$c.json").read().strip().splitlines()[-1])
+print("$c", "ms/step", r["ms_per_step"], "xRT", r["value"], "rec us/step", r["roofline"].get("us_per_time_step"), r["roofline"]["other_kernels"]["ms_by_call"])
 PY
+done
