@@ -239,15 +239,17 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     yin = torch.randn(T, B, 2 * Hp, device=dev).tanh_()
     st = _stream   # evaluated at call time: under graph capture the current stream is the capture stream
     lyr = 1 if L > 1 else 0          # time a layer with the steady-state shape (in = 2H) when there is one
+    # XCD form: like the stack, the layer leaves only its x3 image (no fp32 rows: the heads read the image)
+    y_ptr = None if flags & _abi.BLSTM_XCD else y.data_ptr()
 
     def layer():
         if lyr == 0:
             lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [wih[0].data_ptr()],
-                              [whh[0].data_ptr()], [pk.bias[0].data_ptr()], y.data_ptr(), ws.data_ptr(),
+                              [whh[0].data_ptr()], [pk.bias[0].data_ptr()], y_ptr, ws.data_ptr(),
                               ws.numel(), flags, st())
         else:   # feed y-shaped input through layer 1's weights: x (B,T,2Hp) strides of the time-major buffer
             lib.blstm_forward(yin.data_ptr(), 2 * Hp, B * 2 * Hp, B, T, 2 * Hp, H, 1, ug, [wih[1].data_ptr()],
-                              [whh[1].data_ptr()], [pk.bias[1].data_ptr()], y.data_ptr(), ws.data_ptr(),
+                              [whh[1].data_ptr()], [pk.bias[1].data_ptr()], y_ptr, ws.data_ptr(),
                               ws.numel(), flags, st())
 
     gbuf = ws[_abi.BLSTM_WS_HEADER:]

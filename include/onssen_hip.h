@@ -156,7 +156,9 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
  *   x         element (b, t, k) at x + b*xs_b + t*xs_t + k, k < in_dim
  *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of L device pointers; entry l holds both
  *             directions back to back: wih [2*NP][Kp_l], whh [2][whh_elems], bias [2*NP]
- *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0
+ *   y         (T, B, 2*Hp) time-major output of the last layer: [fwd(Hp) | rev(Hp)], padded units are 0.  May be
+ *             NULL in the ONSSEN_BLSTM_XCD form when the caller only consumes the x3 image (onssen_blstm_y_image):
+ *             the recurrence then skips its fp32 stores.
  *   ws        workspace of onssen_blstm_workspace_bytes() bytes, 256-byte aligned, ZEROED ONCE by its owner when
  *             it is allocated and never again.  Its first ONSSEN_BLSTM_WS_HEADER_BYTES hold the exchange state
  *             of the ONSSEN_BLSTM_XCD form (flags, generations, status words): everything in there is monotonic,

@@ -1374,7 +1374,7 @@ struct XcdArgs {
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
   unsigned spin_limit;
   long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
-  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA; test only: 8 = rotate groups over XCDs
+  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA, 16 = no y / image stores; test only: 8 = rotate groups over XCDs
   unsigned short* yimg;         // x3 image [T*B][KBI][2][32] of the layer output (the next GEMM's A operand), or null
   int KBI;                      // ceil(2*Hp / 32)
 };
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
           split_bf16(h, hi, lo);
           __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, hx_off[i], 0, ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, hx_off[i] + 1024, 0, ST_AUX);
-          if (e_inb[i]) {
+          if (e_inb[i] && !(p.ablate & 16)) {
             if (p.y) p.y[y_off[i] + t * y_step] = h;
             if (p.yimg) {   // the same split pair, in the layout the next layer's / the head's GEMM reads
               unsigned short* d = p.yimg + i_off[i] + t * i_step;
@@ -2304,12 +2304,14 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   int Hp, NP, KQ;
   int64_t we;
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
-  if (!x || !y || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || T <= 0 || in_dim <= 0 || L <= 0)
+  if (!x || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || T <= 0 || in_dim <= 0 || L <= 0)
     return ONSSEN_E_ARG;
+  // y may be NULL only in the XCD form, whose consumers can take the x3 image of the output instead
+  if (!y && !((flags & ONSSEN_BLSTM_XCD) && (flags & ONSSEN_BLSTM_BF16X3))) return ONSSEN_E_ARG;
   BlstmWs wl;
   if (!blstm_ws_layout(B, T, in_dim, H, L, ug, &wl)) return ONSSEN_E_ARG;
   if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
-  if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(y)) return ONSSEN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || (y && !aligned16(y))) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   char* wsp = (char*)ws;
   unsigned* syncw = (unsigned*)wsp;
@@ -2375,7 +2377,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       // fp32 rows only where somebody reads them (the caller's y); every layer leaves its x3 image
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = l == L - 1 ? y : nullptr; xa.hx = hsb; xa.sync = syncw; xa.B = B;
       xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 15;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
       // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase

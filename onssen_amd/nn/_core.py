@@ -250,8 +250,16 @@ def require_device(x, who):
                            "onssen_amd has no CPU fallback")
 
 
-def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
-    """x (B,T,In) float32 cuda -> y (T,B,2,Hp) time-major (padded units are 0)."""
+def heads_take_image(B, H, groups=()):
+    """True when this forward's heads can all read the recurrence's x3 output image (XCD form, no residual, L2-norm
+    groups of 20 / 40 / 80): the caller may then pass ``need_y=False`` and the fp32 rows are never written."""
+    _, flags = recurrence_plan(B, H)
+    return bool(flags & _abi.BLSTM_XCD) and all(g % 4 == 0 and 80 % g == 0 and 80 // g <= 4 for g in groups)
+
+
+def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
+    """x (B,T,In) float32 cuda -> y (T,B,2,Hp) time-major (padded units are 0).  With ``need_y=False`` (see
+    heads_take_image) only the x3 image attached to the result is valid."""
     lib = get_lib()
     p = packed.p
     B, T, In = x.shape
@@ -270,8 +278,10 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn"):
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
-                      [t.data_ptr() for t in pk.bias], y.data_ptr(), wsb.data_ptr(), wsb.numel(), flags, _stream())
+                      [t.data_ptr() for t in pk.bias], y.data_ptr() if need_y or not flags & _abi.BLSTM_XCD else None,
+                      wsb.data_ptr(), wsb.numel(), flags, _stream())
     y.x3_image = None
+    y.fp32_valid = bool(need_y or not flags & _abi.BLSTM_XCD)
     if flags & _abi.BLSTM_XCD:
         # the last layer's output also sits in the workspace as an x3 image: the heads' GEMM operand
         off, _ = lib.blstm_y_image(B, T, In, p.hidden_size, p.num_layers, pk.ug)
@@ -298,6 +308,8 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
         wsb, off = img                               # pre-split activations straight from the recurrence epilogue
         lib.linear_x3p(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, mode, group, eps,
                        out.data_ptr(), B, hd.N, T * hd.N, _stream())
+    elif not getattr(y, "fp32_valid", True):
+        raise RuntimeError("run_head: this head cannot read the x3 image but the recurrence was run with need_y=False")
     elif precision() == "bf16x3" and (mode != EPI_L2NORM or 160 % group == 0):
         lib.linear_bf16x3(a_ptr, Btot * 2 * Hp, 2 * Hp, B, T * B, 2 * Hp, hd.planes.data_ptr(), hd.ld3, hd.b.data_ptr(),
                           hd.N, mode, group, eps, rp, out.data_ptr(), hd.N, T * hd.N, _stream())

@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
-                    require_device, run_blstm, run_head, use_hip_path)
+                    heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
 
 class chimera(nn.Module):
@@ -40,7 +40,8 @@ class chimera(nn.Module):
         x = x.float()
         batch_size, frame, frequency = x.size()
         require_device(x, "chimera")
-        y = run_blstm(self._packed, self._ws, x)
+        y = run_blstm(self._packed, self._ws, x,
+                      need_y=not heads_take_image(batch_size, self.hidden_dim, (self.embedding_dim,)))
         emb = run_head(self._head_dc, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
         masks = run_head(self._head_mi, y, batch_size, frame, EPI_SIGMOID)
         return emb.view(batch_size, frame, frequency, -1), masks.view(batch_size, frame, frequency, -1)

@@ -3,7 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
-                    require_device, run_blstm, run_head, use_hip_path)
+                    heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
 
 class deep_clustering(nn.Module):
@@ -34,7 +34,8 @@ class deep_clustering(nn.Module):
         if not use_hip_path(self):
             return [self._autograd_forward(x)]
         require_device(x, "deep_clustering")
-        y = run_blstm(self._packed, self._ws, x)
+        y = run_blstm(self._packed, self._ws, x,
+                      need_y=not heads_take_image(batch_size, self.hidden_dim, (self.embedding_dim,)))
         emb = run_head(self._head, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
         return [emb.view(batch_size, frame, frequency, -1)]
 
