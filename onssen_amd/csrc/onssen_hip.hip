@@ -1586,8 +1586,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
       // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
+      float keep_h[EPT];
+      unsigned keep_hl[EPT];
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
+        keep_h[i] = 0.0f;
+        keep_hl[i] = 0u;
         if (e_ok[i]) {
           // 4 gates x NW wave partials: independent LDS reads issued together, then summed pairwise
           float part[4][NW], pre[4];
@@ -1611,14 +1615,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
           split_bf16(h, hi, lo);
           __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, hx_off[i], 0, ST_AUX);
           __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, hx_off[i] + 1024, 0, ST_AUX);
-          if (e_inb[i] && !(p.ablate & 16)) {
-            if (p.y) p.y[y_off[i] + t * y_step] = h;
-            if (p.yimg) {   // the same split pair, in the layout the next layer's / the head's GEMM reads
-              unsigned short* d = p.yimg + i_off[i] + t * i_step;
-              d[0] = hi;
-              d[32] = lo;
-            }
-          }
+          keep_h[i] = h;
+          keep_hl[i] = (unsigned)hi | ((unsigned)lo << 16);
         }
       }
       // this wave's stores are acknowledged (by L2 / by memory) -> raise this wave's flag
@@ -1631,6 +1629,19 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
         } else {   // write this XCD's L2 back, then raise the flag
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           __hip_atomic_store(flags + ugi * NW + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // the layer's OUTPUT (fp32 rows for the caller, x3 image for the next GEMM) is nobody's business inside this
+      // launch: it leaves after the flag, off the exchange's critical path
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        if (e_inb[i] && !(p.ablate & 16)) {
+          if (p.y) p.y[y_off[i] + t * y_step] = keep_h[i];
+          if (p.yimg) {   // the same split pair, in the layout the next layer's / the head's GEMM reads
+            unsigned short* d = p.yimg + i_off[i] + t * i_step;
+            d[0] = (unsigned short)(keep_hl[i] & 0xffffu);
+            d[32] = (unsigned short)(keep_hl[i] >> 16);
+          }
         }
       }
     };

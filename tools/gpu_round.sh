@@ -1,5 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
+timeout 120 python tools/xcd_timeline.py 2>&1 | grep -v amdgpu.ids | tail -2
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 for c in dc_l2 chimera_l4; do
 timeout 300 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err
