@@ -1,19 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-run() { name=$1; shift; timeout 400 env "$@" python bench.py ${BENCH_ARGS} > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; python - <<PY
-import json
-try:
-    r = json.loads(open("gpurun_out/bench_$name.json").read().strip().splitlines()[-1])
-    print("$name", "ms/step %.3f" % r["ms_per_step"], "xRT %.0f" % r["value"], "fps %.0f" % r["frames_per_s"], "rec us/step %.2f" % r["roofline"]["us_per_time_step"], "frac %.3f" % r["roofline"]["frac"], "|", r["config"].get("recurrence"), "| cpu", round(r["cpu_baseline"]["value"]) if r.get("cpu_baseline") else None, r["roofline"]["other_kernels"]["ms_by_call"], r["roofline"]["other_kernels"]["achieved_by_call"])
-except Exception as e:
-    print("$name FAILED", e, open("gpurun_out/bench_$name.err").read()[-400:])
-PY
-}
-BENCH_ARGS="--config dc_l2" run dc_l2_bf16x3 A=1
-BENCH_ARGS="--config dc_l2 --precision f32 --no-cpu-baseline" run dc_l2_f32 A=1
-BENCH_ARGS="--config dc_l2 --no-cpu-baseline" run dc_l2_bf16x3_steps ONSSEN_XCD=0
-BENCH_ARGS="--config dc_l3 --no-cpu-baseline" run dc_l3 A=1
-BENCH_ARGS="--config chimera_l4 --no-cpu-baseline" run chimera_l4 A=1
-BENCH_ARGS="--config phase_l4 --no-cpu-baseline" run phase_l4 A=1
-bash tools/profile_round.sh r01e > gpurun_out/profile_round.log 2>&1
-head -8 gpurun_out/prof_r01e/kernel_stats.csv | cut -c1-150
+timeout 300 python tools/cumask_xcd_probe.py 2>&1 | grep -v amdgpu.ids | tail -8
