@@ -1372,6 +1372,8 @@ struct XcdArgs {
                                 // by the workspace owner: everything in it is monotonic, so no launch depends on a
                                 // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
+  int RG;                       // batch rows per exchange group: 16, or 8 / 4 when the batch is small enough to give
+                                // every XCD a group anyway (the MFMA tile stays 16 rows; less h to move and to update)
   unsigned spin_limit;
   long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
   int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA, 16 = no y / image stores; test only: 8 = rotate groups over XCDs
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
                                ((long long)__builtin_amdgcn_s_getreg(63492) << 8);   // hwreg(HW_REG_HW_ID)
   if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
   const int dir = g / p.nbg, bg = g % p.nbg;
-  const int b0 = p.row0 + bg * 16;
+  const int b0 = p.row0 + bg * p.RG;
   unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * (32 * NW);   // [member][wave]
   unsigned* abort_w = p.sync + 280;
 
@@ -1465,7 +1467,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   for (int i = 0; i < EPT; ++i) {
     const int e = tid + NTHR * i;
     const int row = (e / UG) & 15, ju = e % UG, b = b0 + row, k = ugi * UG + ju;
-    e_ok[i] = e < NE;
+    e_ok[i] = e < p.RG * UG;
     e_inb[i] = e_ok[i] && b < p.B;
     g_off[i] = ((long)b * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4;
     y_off[i] = ((long)b * 2 + dir) * p.Hp + k;
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
             a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(
-                rh, (p.ablate & 1) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
+                rh, ((p.ablate & 1) || (lane & 15) >= p.RG) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
         if (stamp) p.dbg[step * 8 + 6] = clock64();
         load_g(gpre, step + 1);
         if (stamp) p.dbg[step * 8 + 7] = clock64();
@@ -1852,10 +1854,14 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
 template <int NT>
 static int launch_xcd(XcdArgs xa, int nw, hipStream_t st) {
   // <= 4 batch groups of 16 rows per launch (2 directions x 4 = the chip's 8 XCDs)
-  for (int r0 = 0; r0 < xa.B; r0 += 64) {
-    const int rows = xa.B - r0 < 64 ? xa.B - r0 : 64;
+  // rows per group: the smallest of 4 / 8 / 16 that still covers the batch with the chip's 8 groups per launch
+  xa.RG = xa.B <= 16 ? 4 : xa.B <= 32 ? 8 : 16;
+  static const int rg_env = getenv("ONSSEN_XCD_RG") ? atoi(getenv("ONSSEN_XCD_RG")) : 0;   // profiling: force 4 / 8 / 16
+  if (rg_env == 4 || rg_env == 8 || rg_env == 16) xa.RG = rg_env;
+  for (int r0 = 0; r0 < xa.B; r0 += 4 * xa.RG) {
+    const int rows = xa.B - r0 < 4 * xa.RG ? xa.B - r0 : 4 * xa.RG;
     xa.row0 = r0;
-    xa.nbg = ceil_div(rows, 16);
+    xa.nbg = ceil_div(rows, xa.RG);
     if (nw == 8) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
     else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
   }
@@ -2283,7 +2289,7 @@ static bool blstm_ws_layout(int B, int T, int in_dim, int H, int L, int ug, Blst
   w->g = align256((size_t)T * B * 2 * NP * sizeof(float));
   w->y = L > 1 ? align256((size_t)T * B * 2 * Hp * sizeof(float)) : 0;
   w->c = align256((size_t)2 * B * Hp * sizeof(float));
-  w->hs = align256((size_t)2 * 2 * ceil_div(B, 16) * ceil_div(Hp, 32) * 2048);   // h hand-off image (both forms fit)
+  w->hs = align256((size_t)2 * 2 * ceil_div(B, 4) * ceil_div(Hp, 32) * 2048);    // h hand-off image: one per (direction, group of >= 4 rows)
   w->img_x = align256((size_t)T * B * ceil_div(in_dim, 32) * 128);
   w->img_y = align256((size_t)T * B * ceil_div(2 * Hp, 32) * 128);
   w->off_imgx = ONSSEN_BLSTM_WS_HEADER_BYTES + w->g + w->y + w->c + w->hs;
@@ -2341,7 +2347,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
   if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
   uint16_t* hsb = (uint16_t*)wsp;
-  const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 16) * KQ2 * 2048;   // split-bf16 image; >= the fp32 image (2*KQ2 >= KQ)
+  const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 4) * KQ2 * 2048;   // split-bf16 images of all groups; >= the fp32 image (2*KQ2 >= KQ)
   wsp += align256(hs_bytes);
   long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)((char*)ws + wl.total - 65536) : nullptr;
   {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
