@@ -55,6 +55,10 @@ extern "C" {
                                      x3 image (onssen_x3_image_f32) of the packed [2*NP][K_l] input-projection
                                      matrix, and the last layer's output image stays in the workspace for the
                                      heads (onssen_blstm_y_image). */
+#define ONSSEN_BLSTM_FUSE_IN0 16   /* (with XCD, in_dim <= 160) the first layer's input projection is computed inside its
+                                     recurrence launch: wih_p_host[0] must be the B-fragment image made by
+                                     onssen_lstm_pack_wih_bf16x3 of the layer's two W_ih, back to back; no G is
+                                     written or read for that layer. */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
@@ -101,6 +105,9 @@ int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih
  * v_mfma_f32_16x16x32_bf16 B-fragment order [NU][KQ2][ug/4][hi|lo][64][8], KQ2 = ceil(Hp/32). */
 int onssen_lstm_geometry_x3(int H, int ug, int* KQ2, int* Hs, int64_t* whh_x3_elems);
 int onssen_lstm_pack_whh_bf16x3(const float* w_hh, int H, int ug, uint16_t* whh_x3, void* stream);
+/* The same B-fragment image for one direction's W_ih [4H][in_dim] (ONSSEN_BLSTM_FUSE_IN0):
+ * [NU][ceil(in_dim/32)][ug/4][hi|lo][64][8] uint16, zero beyond in_dim. */
+int onssen_lstm_pack_wih_bf16x3(const float* w_ih, int in_dim, int H, int ug, uint16_t* wih_x3, void* stream);
 
 /* Pack a head nn.Linear(2H -> N) for the [fwd(Hp) | rev(Hp)] activation layout, optionally folding an
  * eval-mode nn.BatchNorm1d(2H) that precedes it (onssen/nn/deep_clustering.py:36-39):

@@ -12,6 +12,7 @@ ABI_VERSION = 3
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
+BLSTM_FUSE_IN0 = 16
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -25,6 +26,7 @@ SIGNATURES = {
     "onssen_lstm_geometry": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "onssen_lstm_geometry_x3": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64)]),
     "onssen_lstm_pack_whh_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
+    "onssen_lstm_pack_wih_bf16x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
@@ -80,6 +82,9 @@ class Lib:
 
     def lstm_pack_whh_bf16x3(self, w_hh, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_whh_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whh_bf16x3")
+
+    def lstm_pack_wih_bf16x3(self, w_ih, in_dim, H, ug, out, stream):
+        self.check(self.dll.onssen_lstm_pack_wih_bf16x3(w_ih, in_dim, H, ug, out, stream), "onssen_lstm_pack_wih_bf16x3")
 
     def loss_dc_workspace_bytes(self, B):
         return int(self.dll.onssen_loss_dc_workspace_bytes(B))

@@ -108,7 +108,8 @@ __global__ void pack_whh_kernel(const float* __restrict__ w_hh, int H, int Hp, i
 
 // split-bf16 MFMA B-fragment image of W_hh for v_mfma_f32_16x16x32_bf16: [ugi][q][nt][hi|lo][lane][8] with
 //   column = nt*16 + (lane&15),  k = 32q + 8(lane>>4) + j
-__global__ void pack_whh_bf16x3_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ2,
+// w: [4H][K] (W_hh with K = H, or a layer's W_ih with K = its input width); KQ2 = ceil(K / 32) chunks
+__global__ void pack_whh_bf16x3_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ2, int K,
                                        unsigned short* __restrict__ out) {
   const int NTl = UG / 4, NU = Hp / UG;
   const long total = (long)NU * KQ2 * NTl * 512;   // (lane, j) pairs; each writes hi and lo
@@ -123,7 +124,7 @@ __global__ void pack_whh_bf16x3_kernel(const float* __restrict__ w_hh, int H, in
     const int gate = pl / UG, ju = pl % UG;
     const int u = ugi * UG + ju;
     const int k = 32 * q + 8 * (lane >> 4) + j;
-    const float v = (u < H && k < H) ? w_hh[(long)(gate * H + u) * H + k] : 0.0f;
+    const float v = (u < H && k < K) ? w_hh[(long)(gate * H + u) * K + k] : 0.0f;
     unsigned short hi, lo;
     split_bf16(v, hi, lo);
     const long base = (((long)(ugi * KQ2 + q) * NTl + nt) * 2) * 512 + lane * 8 + j;
@@ -1372,6 +1373,10 @@ struct XcdArgs {
                                 // by the workspace owner: everything in it is monotonic, so no launch depends on a
                                 // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
   int B, T, Hp, NP, KQ2, NU, row0, nbg;
+  const unsigned short* wih0;   // FUSE_IN0: B-fragment image of the layer's W_ih [2][NU][KC0][NT][hi|lo][64][8], else null
+  const unsigned short* ximg;   // FUSE_IN0: x3 image of the layer's input rows [T*B][KC0][2][32]
+  const float* bias0;           // FUSE_IN0: [2*NP] packed bias (G column order)
+  int KC0;                      // FUSE_IN0: ceil(in_dim / 32) <= 5, else 0
   int RG;                       // batch rows per exchange group: 16, or 8 / 4 when the batch is small enough to give
                                 // every XCD a group anyway (the MFMA tile stays 16 rows; less h to move and to update)
   unsigned spin_limit;
@@ -1391,6 +1396,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   constexpr int CPW = 20 / NW + (20 % NW != 0);   // k-chunks (32 k) per wave: NW x CPW x 32 >= 640 >= H
   constexpr unsigned kOOB = 0x7ffffff0u;
   __shared__ float red[2 * NW * NT * 4 * RLD];   // two step parities
+  constexpr int KCMAX = 5;                       // fused layer-0 input projection: in_dim <= 160
+  __shared__ __attribute__((aligned(16))) unsigned short wih_s[KCMAX * NT * 1024];   // [chunk][nt][hi|lo][64][8]
   __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
@@ -1452,6 +1459,15 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
           w[i][nt][hl] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(
               rw, (unsigned)(((wave + NW * i) * NT + nt) * 2048 + hl * 1024 + lane * 16), 0, 0));
   }
+  // ---- fused input projection of the first layer (in_dim <= 160): this member's W_ih slice lives in LDS, the
+  //      products x_t W_ih^T are accumulated into the same MFMA accumulators as h_{t-1} W_hh^T -- behind the latency
+  //      of the h exchange, which they do not depend on -- and G never exists in memory
+  const bool fuse = p.KC0 > 0;
+  if (fuse) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.wih0 + (long)(dir * p.NU + ugi) * p.KC0 * NT * 1024);
+    for (int i = tid; i < p.KC0 * NT * 128; i += NTHR) reinterpret_cast<u32x4*>(wih_s)[i] = src[i];
+    __syncthreads();
+  }
   float cst[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
@@ -1486,13 +1502,39 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
     const int t = dir == 0 ? step : p.T - 1 - step;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-      const bool ok = e_inb[i] && (step < p.T) && !(p.ablate & 2);
+      const bool ok = e_inb[i] && (step < p.T) && !(p.ablate & 2) && !fuse;
       const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + g_off[i] + t * g_step) : make_float4(0.f, 0.f, 0.f, 0.f);
       gp[i][0] = g4.x; gp[i][1] = g4.y; gp[i][2] = g4.z; gp[i][3] = g4.w;
     }
   };
   float gcur[EPT][4], gnext[EPT][4];
   load_g(gcur, 0);
+  float bgate[EPT][4];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i)
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+      bgate[i][gt] = (fuse && e_ok[i]) ? p.bias0[dir * p.NP + ugi * 4 * UG + ((tid + NTHR * i) % UG) * 4 + gt] : 0.0f;
+  // input fragments of a step (A operand: batch rows x 32-wide k chunk), chunks wave, wave + NW (< KC0 <= 5);
+  // like G they are fetched one step ahead into a second register set
+  constexpr int XS = KCMAX / NW + (KCMAX % NW != 0);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.ximg, 0, fuse ? (int)((long)p.T * p.B * p.KC0 * 128) : 0, 0x00020000);
+  auto load_x = [&](u32x4 (&xf)[XS][2], int step) {
+    const int t = dir == 0 ? step : p.T - 1 - step;
+    const int b = b0 + (lane & 15);
+#pragma unroll
+    for (int ci = 0; ci < XS; ++ci) {
+      const int c = wave + NW * ci;
+      const bool ok = fuse && c < p.KC0 && (lane & 15) < p.RG && b < p.B && step < p.T;
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl)
+        xf[ci][hl] = __builtin_amdgcn_raw_buffer_load_b128(
+            rx, ok ? (unsigned)((((long)(t * p.B + b) * p.KC0 + c) * 2 + hl) * 64 + (lane >> 4) * 16) : 0x7ffffff0u, 0, 0);
+    }
+  };
+  u32x4 xcur[XS][2], xnext[XS][2];
+  load_x(xcur, 0);
 
   // One flag per WAVE of every member (128 per group, 1 KiB): a wave raises its own flag as soon as its own
   // stores are acknowledged, and every wave polls for itself with one 16-byte load per lane -- no workgroup
@@ -1531,59 +1573,69 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
     };
     // one time step; `guse` holds this step's input projection, `gpre` receives the next step's (the two
     // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
-    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4]) {
+    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4], u32x4 (&xuse)[XS][2], u32x4 (&xpre)[XS][2]) {
       const int t = dir == 0 ? step : p.T - 1 - step;
       float* redb = red + (step & 1) * (NW * NT * 4 * RLD);
       if (stamp) p.dbg[step * 8 + 0] = clock64();
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (fuse) {   // x_t W_ih^T: independent of the exchange -- issued BEFORE the flag wait, the MFMAs run under it
+#pragma unroll
+        for (int ci = 0; ci < XS; ++ci) {
+          const int c = wave + NW * ci;
+          if (c < p.KC0) {
+            const s16x8 xh = __builtin_bit_cast(s16x8, xuse[ci][0]), xl = __builtin_bit_cast(s16x8, xuse[ci][1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const s16x8 wh = *reinterpret_cast<const s16x8*>(wih_s + ((c * NT + nt) * 2 + 0) * 512 + lane * 8);
+              const s16x8 wl = *reinterpret_cast<const s16x8*>(wih_s + ((c * NT + nt) * 2 + 1) * 512 + lane * 8);
+              acc[nt] = mfma_bf16(xl, wh, acc[nt]);
+              acc[nt] = mfma_bf16(xh, wl, acc[nt]);
+              acc[nt] = mfma_bf16(xh, wh, acc[nt]);
+            }
+          }
+        }
+      }
+      u32x4 a[CPW][2];
       if (step > 0) {
         wait_flags((unsigned)step);
         if (stamp) p.dbg[step * 8 + 1] = clock64();
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
-        u32x4 a[CPW][2];
 #pragma unroll
         for (int i = 0; i < CPW; ++i)
 #pragma unroll
           for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
             a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(
                 rh, ((p.ablate & 1) || (lane & 15) >= p.RG) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
-        if (stamp) p.dbg[step * 8 + 6] = clock64();
-        load_g(gpre, step + 1);
-        if (stamp) p.dbg[step * 8 + 7] = clock64();
-        f32x4 acc[NT];
+      }
+      if (stamp) p.dbg[step * 8 + 6] = clock64();
+      load_g(gpre, step + 1);
+      load_x(xpre, step + 1);
+      if (stamp) p.dbg[step * 8 + 7] = clock64();
+      if (step > 0 && !(p.ablate & 4)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(p.ablate & 4)) {
+        for (int i = 0; i < CPW; ++i) {
+          if (wave + NW * i < p.KQ2) {
+            const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
+            // term-major: NT independent accumulators between two MFMAs on the same one
 #pragma unroll
-          for (int i = 0; i < CPW; ++i) {
-            if (wave + NW * i < p.KQ2) {
-              const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
-              // term-major: NT independent accumulators between two MFMAs on the same one
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
-            }
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
           }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
-        if (stamp) p.dbg[step * 8 + 2] = clock64();
-        __syncthreads();
-        if (stamp) p.dbg[step * 8 + 3] = clock64();
-      } else {
-        load_g(gpre, 1);
-        // step 0 has no recurrent term: publish zero partial sums so that the epilogue below is branch-free
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = 0.0f;
-        __syncthreads();
       }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
+      if (stamp) p.dbg[step * 8 + 2] = clock64();
+      __syncthreads();
+      if (stamp) p.dbg[step * 8 + 3] = clock64();
 
       // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1607,7 +1659,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
           for (int gt = 0; gt < 4; ++gt) {
             float sum = (part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3]);
             if constexpr (NW == 8) sum += (part[gt][4] + part[gt][5]) + (part[gt][6] + part[gt][7]);
-            pre[gt] = sum + guse[i][gt];
+            pre[gt] = sum + (fuse ? bgate[i][gt] : guse[i][gt]);
           }
           const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
           const float cn = fg2 * cst[i] + ig * gg;
@@ -1648,8 +1700,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
       }
     };
     for (int step = 0; step < p.T; step += 2) {
-      body(step, gcur, gnext);
-      if (step + 1 < p.T) body(step + 1, gnext, gcur);
+      body(step, gcur, gnext, xcur, xnext);
+      if (step + 1 < p.T) body(step + 1, gnext, gcur, xnext, xcur);
     }
     // member 0 closes the launch: once every wave of the group has published its last step (so nobody can
     // still be comparing against this generation), bump it
@@ -2084,7 +2136,19 @@ int onssen_lstm_pack_whh_bf16x3(const float* w_hh, int H, int ug, uint16_t* whh_
   ONSSEN_CLEAR_ERROR();
   const long n = we / 2;
   hipLaunchKernelGGL(pack_whh_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, w_hh, H, Hp, ug, KQ2, whh_x3);
+                     dim3(256), 0, (hipStream_t)stream, w_hh, H, Hp, ug, KQ2, H, whh_x3);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+int onssen_lstm_pack_wih_bf16x3(const float* w_ih, int in_dim, int H, int ug, uint16_t* wih_x3, void* stream) {
+  int Hp;
+  if (!w_ih || !wih_x3 || in_dim <= 0 || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK)
+    return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const int KC = ceil_div(in_dim, 32);
+  const long n = (long)(Hp / ug) * KC * (ug / 4) * 512;
+  hipLaunchKernelGGL(pack_whh_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, w_ih, H, Hp, ug, KC, in_dim, wih_x3);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -2365,13 +2429,16 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;
     const float* yin = ((L - 1 - l) % 2 == 0) ? ybuf : y;
     int rc;
+    const bool fuse0 = images && l == 0 && (flags & ONSSEN_BLSTM_FUSE_IN0);
+    if (fuse0 && in_dim > 160) return ONSSEN_E_ARG;
     if (images) {
       const uint16_t* a_img = l == 0 ? img_x : img_ab[(L - l) % 2];   // layer l-1 wrote buffer (L-1-(l-1)) % 2
       if (l == 0) {
         rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
         if (rc != ONSSEN_OK) return rc;
       }
-      rc = onssen_linear_x3p(a_img, T * B, l == 0 ? in_dim : 2 * Hp, (const uint16_t*)wih_p_host[l], bias_p_host[l],
+      if (fuse0) rc = ONSSEN_OK;   // x_t W_ih^T is computed inside the recurrence launch: no G, no GEMM
+      else rc = onssen_linear_x3p(a_img, T * B, l == 0 ? in_dim : 2 * Hp, (const uint16_t*)wih_p_host[l], bias_p_host[l],
                              2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G, B, (int64_t)B * 2 * NP, 2 * NP, stream);
     } else if (x3) {   // wih_p_host[l]: split-bf16 planes [2][2*NP][ld], ld = K rounded up to 32
       const int K = l == 0 ? in_dim : 2 * Hp, ld = ceil_div(K, 32) * 32;
@@ -2390,11 +2457,16 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
     if (rc != ONSSEN_OK) return rc;
     if (flags & ONSSEN_BLSTM_XCD) {
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
+      // bounded waits: ~0.2 s of polling on the GPU; ONSSEN_XCD_SPIN_LIMIT overrides (the host-side emulation, where a
+      // 'workgroup' is a process at the mercy of the OS scheduler, raises it)
+      static const unsigned xcd_spin = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
       XcdArgs xa;
       // fp32 rows only where somebody reads them (the caller's y); every layer leaves its x3 image
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = l == L - 1 ? y : nullptr; xa.hx = hsb; xa.sync = syncw; xa.B = B;
       xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = 400000u; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
+      xa.wih0 = fuse0 ? (const unsigned short*)wih_p_host[0] : nullptr; xa.ximg = img_x; xa.bias0 = bias_p_host[0];
+      xa.KC0 = fuse0 ? ceil_div(in_dim, 32) : 0;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
       // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase

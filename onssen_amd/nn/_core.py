@@ -165,6 +165,7 @@ class _PackedImages:
         H, L = p.hidden_size, p.num_layers
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
         self.wih, self.whh, self.bias, self.whh_x3, self.wih_x3, self.wih_img = [], [], [], [], [], []
+        self.wih_frag0 = None
         _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
         for l in range(L):
@@ -191,6 +192,13 @@ class _PackedImages:
             lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
             self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
             self.wih_img.append(ai)
+            if l == 0 and in_l <= 160:   # fragment image for the fused first-layer input projection (FUSE_IN0)
+                kc = (in_l + 31) // 32
+                f0 = torch.empty(2, (self.Hp // self.ug) * kc * (self.ug // 4) * 1024, device=dev, dtype=torch.int16)
+                for d in range(2):
+                    w_ih = flat[(2 * l + d) * 4].detach().contiguous()
+                    lib.lstm_pack_wih_bf16x3(w_ih.data_ptr(), in_l, H, self.ug, f0[d].data_ptr(), st)
+                self.wih_frag0 = f0
         self.key = key
         return self
 
@@ -275,6 +283,12 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
+    # measured (dc / chimera, H=600): +2.7 % at B=64, +0.7 % at B=32, -3 % at B=16 -- the fused MFMAs cost every
+    # time step the same, the GEMM they replace shrinks with the batch
+    fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
+    if flags & _abi.BLSTM_XCD and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 32)):
+        flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
+        wih = [pk.wih_frag0] + list(wih[1:])
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],

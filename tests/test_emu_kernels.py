@@ -324,14 +324,15 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     return a
 
 
-@pytest.mark.parametrize("scramble", ["0", "1"])
+@pytest.mark.parametrize("scramble,fuse", [("0", 0), ("1", 0), ("0", 1)])
 @pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3)])
-def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble):
+def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fuse):
     """ONSSEN_BLSTM_XCD: one persistent launch per layer, h exchanged inside the launch.  The mock runtime runs
     every workgroup concurrently (forked) over shared memory; scramble=1 makes the members of a group report
     different XCC ids, which must select the placement-independent protocol (status word 281)."""
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
+    monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")   # emulated workgroups are OS processes: be patient
     F, L = 9, 2
     sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
     rng = np.random.default_rng(3)
@@ -355,11 +356,18 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble):
             lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
         pl = _shm((2 * NP, (K + 31) // 32, 2, 32), dtype=np.uint16)      # x3 image of the [2*NP][K] projection matrix
         lib.x3_image(P(a), Kp, 0, 1, 2 * NP, K, P(pl), None)
+        if fuse and l == 0:   # ONSSEN_BLSTM_FUSE_IN0: B-fragment image of the two W_ih, x W_ih^T inside the recurrence launch
+            kc = (K + 31) // 32
+            pl = _shm((2, (Hp // ug) * kc * (ug // 4) * 1024), dtype=np.uint16)
+            for d, sfx in enumerate(("", "_reverse")):
+                wsrc = _shm(sd[f"rnn.weight_ih_l0{sfx}"].shape); wsrc[...] = sd[f"rnn.weight_ih_l0{sfx}"]
+                lib.lstm_pack_wih_bf16x3(P(wsrc), K, H, ug, P(pl[d]), None)
         wih3.append(pl), whh3.append(b3), bias.append(c)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
     y = _shm((T, B, 2, Hp), fill=np.nan)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
-                      [P(a) for a in bias], P(y), P(ws), ws.nbytes, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD, None)
+                      [P(a) for a in bias], P(y), P(ws), ws.nbytes,
+                      _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD | (_abi.BLSTM_FUSE_IN0 if fuse else 0), None)
     status = ws.view(np.uint32)
     assert status[280] == 0, f"launch aborted (code {status[280]})"
     assert status[281] == (1 if scramble == "1" else 0)
@@ -375,7 +383,7 @@ def test_blstm_xcd_eight_wave_variant():
     import subprocess
     import sys
     env = dict(os.environ, ONSSEN_XCD_WAVES="8")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3"],
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3 and not 1-0"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -1,19 +1,14 @@
 #!/bin/bash
 export TMPDIR=/tmp
-run() { name=$1; shift; timeout 400 env "$@" python bench.py ${BENCH_ARGS} > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; python - <<PY
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+timeout 200 python tools/xcd_graph_probe.py 2>&1 | tail -3
+for c in dc_l2 dc_l3 chimera_l4; do
+for f in 1 0; do
+ONSSEN_FUSE_IN0=$f timeout 300 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err
+python - <<PY
 import json
-try:
-    r = json.loads(open("gpurun_out/bench_$name.json").read().strip().splitlines()[-1])
-    print("$name", "ms/step %.3f" % r["ms_per_step"], "xRT %.0f" % r["value"], "fps %.0f" % r["frames_per_s"], "rec us/step %.2f" % r["roofline"]["us_per_time_step"], "frac %.3f" % r["roofline"]["frac"], "|", r["config"].get("recurrence"), "| cpu", round(r["cpu_baseline"]["value"]) if r.get("cpu_baseline") else None, r["roofline"]["other_kernels"]["ms_by_call"])
-except Exception as e:
-    print("$name FAILED", e, open("gpurun_out/bench_$name.err").read()[-400:])
+r = json.loads(open("gpurun_out/bench_$c.json").read().strip().splitlines()[-1])
+print("$c fuse=$f", "ms/step", r["ms_per_step"], "xRT", r["value"], "rec us/step", r["roofline"].get("us_per_time_step"), "safe", r["config"].get("xcd_placement_independent_protocol_used"))
 PY
-}
-BENCH_ARGS="--config dc_l2" run dc_l2_bf16x3 A=1
-BENCH_ARGS="--config dc_l2 --precision f32 --no-cpu-baseline" run dc_l2_f32 A=1
-BENCH_ARGS="--config dc_l2 --no-cpu-baseline" run dc_l2_bf16x3_steps ONSSEN_XCD=0
-BENCH_ARGS="--config dc_l3 --no-cpu-baseline" run dc_l3 A=1
-BENCH_ARGS="--config chimera_l4 --no-cpu-baseline" run chimera_l4 A=1
-BENCH_ARGS="--config phase_l4 --no-cpu-baseline" run phase_l4 A=1
-bash tools/profile_round.sh r01f > gpurun_out/profile_round.log 2>&1
-head -8 gpurun_out/prof_r01f/kernel_stats.csv | cut -c1-150
+done
+done
