@@ -59,6 +59,9 @@ extern "C" {
                                      recurrence launch: wih_p_host[0] must be the B-fragment image made by
                                      onssen_lstm_pack_wih_bf16x3 of the layer's two W_ih, back to back; no G is
                                      written or read for that layer. */
+#define ONSSEN_BLSTM_FUSE_TAIL 32   /* (with FUSE_IN0, in_dim = 32k + 1, e.g. F = 129) the lone last input column is a rank-1
+                                     update on the VALU instead of a whole MFMA k-chunk: bias_p_host[0] then holds 4*NP
+                                     floats -- the bias, then column in_dim-1 of the packed W_ih ([2*NP]). */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */

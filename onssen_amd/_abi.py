@@ -13,6 +13,7 @@ BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
 BLSTM_FUSE_IN0 = 16
+BLSTM_FUSE_TAIL = 32
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t

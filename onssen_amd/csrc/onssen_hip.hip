@@ -1377,6 +1377,11 @@ struct XcdArgs {
   const unsigned short* ximg;   // FUSE_IN0: x3 image of the layer's input rows [T*B][KC0][2][32]
   const float* bias0;           // FUSE_IN0: [2*NP] packed bias (G column order)
   int KC0;                      // FUSE_IN0: ceil(in_dim / 32) <= 5, else 0
+  int KCM;                      // FUSE_IN0: chunks multiplied on the MFMA pipe: KC0, or KC0 - 1 when in_dim = 32*KCM + 1 (129, 257:
+                                // the lone last column is a rank-1 update on the VALU in the cell update instead)
+  const float* x0;              // FUSE_IN0 tail: fp32 input, element (b, t, k) at x0 + b*xs_b + t*xs_t + k
+  long xs_b, xs_t;
+  const float* wtail;           // FUSE_IN0 tail: column in_dim-1 of the packed W_ih, [2*NP] (G column order)
   int RG;                       // batch rows per exchange group: 16, or 8 / 4 when the batch is small enough to give
                                 // every XCD a group anyway (the MFMA tile stays 16 rows; less h to move and to update)
   unsigned spin_limit;
@@ -1386,7 +1391,9 @@ struct XcdArgs {
   int KBI;                      // ceil(2*Hp / 32)
 };
 
-template <int NT, int NW>
+// FUSE: the first layer's input projection is computed in here (ONSSEN_BLSTM_FUSE_IN0); a compile-time switch so that
+// the plain instantiation carries none of its registers
+template <int NT, int NW, bool FUSE>
 __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   using namespace rec;
   constexpr int UG = 4 * NT;
@@ -1397,7 +1404,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   constexpr unsigned kOOB = 0x7ffffff0u;
   __shared__ float red[2 * NW * NT * 4 * RLD];   // two step parities
   constexpr int KCMAX = 5;                       // fused layer-0 input projection: in_dim <= 160
-  __shared__ __attribute__((aligned(16))) unsigned short wih_s[KCMAX * NT * 1024];   // [chunk][nt][hi|lo][64][8]
+  __shared__ __attribute__((aligned(16))) unsigned short wih_s[FUSE ? KCMAX * NT * 1024 : 8];   // [chunk][nt][hi|lo][64][8]
   __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
@@ -1462,8 +1469,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
   // ---- fused input projection of the first layer (in_dim <= 160): this member's W_ih slice lives in LDS, the
   //      products x_t W_ih^T are accumulated into the same MFMA accumulators as h_{t-1} W_hh^T -- behind the latency
   //      of the h exchange, which they do not depend on -- and G never exists in memory
-  const bool fuse = p.KC0 > 0;
-  if (fuse) {
+  constexpr bool fuse = FUSE;
+  if constexpr (FUSE) {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.wih0 + (long)(dir * p.NU + ugi) * p.KC0 * NT * 1024);
     for (int i = tid; i < p.KC0 * NT * 128; i += NTHR) reinterpret_cast<u32x4*>(wih_s)[i] = src[i];
     __syncthreads();
@@ -1508,7 +1515,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
     }
   };
   float gcur[EPT][4], gnext[EPT][4];
-  load_g(gcur, 0);
+  if constexpr (!FUSE) load_g(gcur, 0);
   float bgate[EPT][4];
 #pragma unroll
   for (int i = 0; i < EPT; ++i)
@@ -1517,7 +1524,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
       bgate[i][gt] = (fuse && e_ok[i]) ? p.bias0[dir * p.NP + ugi * 4 * UG + ((tid + NTHR * i) % UG) * 4 + gt] : 0.0f;
   // input fragments of a step (A operand: batch rows x 32-wide k chunk), chunks wave, wave + NW (< KC0 <= 5);
   // like G they are fetched one step ahead into a second register set
-  constexpr int XS = KCMAX / NW + (KCMAX % NW != 0);
+  constexpr int XS = FUSE ? KCMAX / NW + (KCMAX % NW != 0) : 1;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)p.ximg, 0, fuse ? (int)((long)p.T * p.B * p.KC0 * 128) : 0, 0x00020000);
   auto load_x = [&](u32x4 (&xf)[XS][2], int step) {
@@ -1526,7 +1533,7 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
 #pragma unroll
     for (int ci = 0; ci < XS; ++ci) {
       const int c = wave + NW * ci;
-      const bool ok = fuse && c < p.KC0 && (lane & 15) < p.RG && b < p.B && step < p.T;
+      const bool ok = fuse && c < p.KCM && (lane & 15) < p.RG && b < p.B && step < p.T;
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl)
         xf[ci][hl] = __builtin_amdgcn_raw_buffer_load_b128(
@@ -1534,7 +1541,25 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
     }
   };
   u32x4 xcur[XS][2], xnext[XS][2];
-  load_x(xcur, 0);
+  if constexpr (FUSE) load_x(xcur, 0);
+  // lone last input column (in_dim = 32*KCM + 1): w_tail per (element, gate) in registers, x_tail fetched one step ahead
+  const bool tail = fuse && p.KCM < p.KC0;
+  float wt[EPT][4];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i)
+#pragma unroll
+    for (int gt = 0; gt < 4; ++gt)
+      wt[i][gt] = (tail && e_ok[i]) ? p.wtail[dir * p.NP + ugi * 4 * UG + ((tid + NTHR * i) % UG) * 4 + gt] : 0.0f;
+  auto load_xt = [&](float (&xt)[EPT], int step) {
+    const int t = dir == 0 ? step : p.T - 1 - step;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int b = b0 + ((tid + NTHR * i) / UG);
+      xt[i] = (tail && e_inb[i] && step < p.T) ? p.x0[(long)b * p.xs_b + (long)t * p.xs_t + 32 * p.KCM] : 0.0f;
+    }
+  };
+  float xtcur[EPT], xtnext[EPT];
+  if constexpr (FUSE) load_xt(xtcur, 0);
 
   // One flag per WAVE of every member (128 per group, 1 KiB): a wave raises its own flag as soon as its own
   // stores are acknowledged, and every wave polls for itself with one 16-byte load per lane -- no workgroup
@@ -1573,18 +1598,19 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
     };
     // one time step; `guse` holds this step's input projection, `gpre` receives the next step's (the two
     // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
-    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4], u32x4 (&xuse)[XS][2], u32x4 (&xpre)[XS][2]) {
+    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4], u32x4 (&xuse)[XS][2], u32x4 (&xpre)[XS][2],
+                    float (&xtuse)[EPT], float (&xtpre)[EPT]) {
       const int t = dir == 0 ? step : p.T - 1 - step;
       float* redb = red + (step & 1) * (NW * NT * 4 * RLD);
       if (stamp) p.dbg[step * 8 + 0] = clock64();
       f32x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (fuse) {   // x_t W_ih^T: independent of the exchange -- issued BEFORE the flag wait, the MFMAs run under it
+      if constexpr (FUSE) {   // x_t W_ih^T: independent of the exchange -- issued BEFORE the flag wait, the MFMAs run under it
 #pragma unroll
         for (int ci = 0; ci < XS; ++ci) {
           const int c = wave + NW * ci;
-          if (c < p.KC0) {
+          if (c < p.KCM) {
             const s16x8 xh = __builtin_bit_cast(s16x8, xuse[ci][0]), xl = __builtin_bit_cast(s16x8, xuse[ci][1]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -1611,8 +1637,12 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
                 rh, ((p.ablate & 1) || (lane & 15) >= p.RG) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
       }
       if (stamp) p.dbg[step * 8 + 6] = clock64();
-      load_g(gpre, step + 1);
-      load_x(xpre, step + 1);
+      if constexpr (FUSE) {
+        load_x(xpre, step + 1);
+        load_xt(xtpre, step + 1);
+      } else {
+        load_g(gpre, step + 1);
+      }
       if (stamp) p.dbg[step * 8 + 7] = clock64();
       if (step > 0 && !(p.ablate & 4)) {
 #pragma unroll
@@ -1659,7 +1689,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
           for (int gt = 0; gt < 4; ++gt) {
             float sum = (part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3]);
             if constexpr (NW == 8) sum += (part[gt][4] + part[gt][5]) + (part[gt][6] + part[gt][7]);
-            pre[gt] = sum + (fuse ? bgate[i][gt] : guse[i][gt]);
+            if constexpr (FUSE) pre[gt] = sum + bgate[i][gt] + xtuse[i] * wt[i][gt];
+            else pre[gt] = sum + guse[i][gt];
           }
           const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
           const float cn = fg2 * cst[i] + ig * gg;
@@ -1700,8 +1731,8 @@ __global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
       }
     };
     for (int step = 0; step < p.T; step += 2) {
-      body(step, gcur, gnext, xcur, xnext);
-      if (step + 1 < p.T) body(step + 1, gnext, gcur, xnext, xcur);
+      body(step, gcur, gnext, xcur, xnext, xtcur, xtnext);
+      if (step + 1 < p.T) body(step + 1, gnext, gcur, xnext, xcur, xtnext, xtcur);
     }
     // member 0 closes the launch: once every wave of the group has published its last step (so nobody can
     // still be comparing against this generation), bump it
@@ -1914,8 +1945,14 @@ static int launch_xcd(XcdArgs xa, int nw, hipStream_t st) {
     const int rows = xa.B - r0 < 4 * xa.RG ? xa.B - r0 : 4 * xa.RG;
     xa.row0 = r0;
     xa.nbg = ceil_div(rows, xa.RG);
-    if (nw == 8) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
-    else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
+    const bool fz = xa.KC0 > 0;
+    if (nw == 8) {
+      if (fz) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8, true>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
+      else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8, false>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
+    } else {
+      if (fz) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4, true>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
+      else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4, false>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
+    }
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? ONSSEN_OK : (int)e;
@@ -2466,6 +2503,10 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
       xa.wih0 = fuse0 ? (const unsigned short*)wih_p_host[0] : nullptr; xa.ximg = img_x; xa.bias0 = bias_p_host[0];
       xa.KC0 = fuse0 ? ceil_div(in_dim, 32) : 0;
+      // in_dim = 32k + 1 (F = 129): the lone last column goes to the VALU; its weights follow the bias (FUSE_TAIL)
+      const bool vtail = fuse0 && (flags & ONSSEN_BLSTM_FUSE_TAIL) && (in_dim % 32) == 1 && in_dim > 1;
+      xa.KCM = vtail ? xa.KC0 - 1 : xa.KC0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
+      xa.wtail = vtail ? bias_p_host[0] + 2 * NP : nullptr;
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured

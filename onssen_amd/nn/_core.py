@@ -166,6 +166,7 @@ class _PackedImages:
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
         self.wih, self.whh, self.bias, self.whh_x3, self.wih_x3, self.wih_img = [], [], [], [], [], []
         self.wih_frag0 = None
+        self.bias0_tail = None
         _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
         for l in range(L):
@@ -199,6 +200,8 @@ class _PackedImages:
                     w_ih = flat[(2 * l + d) * 4].detach().contiguous()
                     lib.lstm_pack_wih_bf16x3(w_ih.data_ptr(), in_l, H, self.ug, f0[d].data_ptr(), st)
                 self.wih_frag0 = f0
+                # FUSE_TAIL (in_dim = 32k + 1): the bias followed by the last column of the packed W_ih
+                self.bias0_tail = torch.cat([c.reshape(-1), a[:, :, in_l - 1].reshape(-1)]).contiguous() if in_l % 32 == 1 and in_l > 1 else None
         self.key = key
         return self
 
@@ -283,16 +286,20 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
+    bias = pk.bias
     # measured (dc / chimera, H=600): +2.7 % at B=64, +0.7 % at B=32, -3 % at B=16 -- the fused MFMAs cost every
     # time step the same, the GEMM they replace shrinks with the batch
     fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
     if flags & _abi.BLSTM_XCD and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 32)):
         flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
         wih = [pk.wih_frag0] + list(wih[1:])
+        if pk.bias0_tail is not None:
+            flags |= _abi.BLSTM_FUSE_TAIL
+            bias = [pk.bias0_tail] + list(pk.bias[1:])
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
-                      [t.data_ptr() for t in pk.bias], y.data_ptr() if need_y or not flags & _abi.BLSTM_XCD else None,
+                      [t.data_ptr() for t in bias], y.data_ptr() if need_y or not flags & _abi.BLSTM_XCD else None,
                       wsb.data_ptr(), wsb.numel(), flags, _stream())
     y.x3_image = None
     y.fp32_valid = bool(need_y or not flags & _abi.BLSTM_XCD)

@@ -324,7 +324,7 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     return a
 
 
-@pytest.mark.parametrize("scramble,fuse", [("0", 0), ("1", 0), ("0", 1)])
+@pytest.mark.parametrize("scramble,fuse", [("0", 0), ("1", 0), ("0", 1), ("0", 2)])   # fuse 2: FUSE_IN0 + FUSE_TAIL, F = 33
 @pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3)])
 def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fuse):
     """ONSSEN_BLSTM_XCD: one persistent launch per layer, h exchanged inside the launch.  The mock runtime runs
@@ -333,7 +333,7 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
     monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")   # emulated workgroups are OS processes: be patient
-    F, L = 9, 2
+    F, L = (33 if fuse == 2 else 9), 2
     sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
     rng = np.random.default_rng(3)
     x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
@@ -362,12 +362,16 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
             for d, sfx in enumerate(("", "_reverse")):
                 wsrc = _shm(sd[f"rnn.weight_ih_l0{sfx}"].shape); wsrc[...] = sd[f"rnn.weight_ih_l0{sfx}"]
                 lib.lstm_pack_wih_bf16x3(P(wsrc), K, H, ug, P(pl[d]), None)
+            if fuse == 2:         # the bias, then the last column of the packed W_ih
+                ct = _shm((4, NP)); ct[:2] = c; ct[2:] = a[:, :, K - 1]
+                c = ct
         wih3.append(pl), whh3.append(b3), bias.append(c)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
     y = _shm((T, B, 2, Hp), fill=np.nan)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes,
-                      _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD | (_abi.BLSTM_FUSE_IN0 if fuse else 0), None)
+                      _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD | (_abi.BLSTM_FUSE_IN0 if fuse else 0) |
+                      (_abi.BLSTM_FUSE_TAIL if fuse == 2 else 0), None)
     status = ws.view(np.uint32)
     assert status[280] == 0, f"launch aborted (code {status[280]})"
     assert status[281] == (1 if scramble == "1" else 0)
