@@ -70,6 +70,8 @@ extern "C" {
 #define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
 #define ONSSEN_EPI_L2NORM 1   /* ... then x / max(||x||_2, eps) over `group` consecutive outputs        */
 #define ONSSEN_EPI_SIGMOID 2  /* ... then logistic                                                      */
+#define ONSSEN_EPI_RELU 3     /* ... then max(x, 0), times `resid` (laid out like C) if given -- onssen_linear_f32 only
+                                 (enhance: fc_pre / fc_post, onssen/nn/enhancement.py:49-51)           */
 
 int onssen_abi_version(void);
 const char* onssen_error_string(int code);

@@ -7,7 +7,7 @@ imports torch, so the same binding drives the product library
 """
 import ctypes as C
 
-EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = 0, 1, 2
+EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 ABI_VERSION = 3
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2

@@ -353,6 +353,10 @@ __global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
     if (off >= 0 && n0 + col < p.N) {
       float v = Cs[row * CLD + col];
       if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+      if (MODE == ONSSEN_EPI_RELU) {
+        v = fmaxf(v, 0.0f);
+        if (p.resid) v *= p.resid[off + n0 + col];      // relu(A W^T + b) * gate  (enhance: restoration layer x mask)
+      }
       p.C[off + n0 + col] = v;
     }
   }
@@ -2229,7 +2233,7 @@ int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, 
   if ((ldw % 4) != 0 || !aligned16(W)) return ONSSEN_E_ALIGN;
   if (mode == ONSSEN_EPI_L2NORM) {
     if (group <= 0 || (lin::BN % group) != 0 || (N % group) != 0) return ONSSEN_E_ARG;
-  } else if (resid) {
+  } else if (resid && mode != ONSSEN_EPI_RELU) {
     return ONSSEN_E_ARG;
   }
   ONSSEN_CLEAR_ERROR();
@@ -2247,6 +2251,8 @@ int onssen_linear_f32(const float* A, int64_t a_s0, int64_t a_s1, int R, int M, 
     if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_L2NORM); else ONSSEN_LIN(false, ONSSEN_EPI_L2NORM);
   } else if (mode == ONSSEN_EPI_SIGMOID) {
     if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_SIGMOID); else ONSSEN_LIN(false, ONSSEN_EPI_SIGMOID);
+  } else if (mode == ONSSEN_EPI_RELU) {
+    if (a_vec) ONSSEN_LIN(true, ONSSEN_EPI_RELU); else ONSSEN_LIN(false, ONSSEN_EPI_RELU);
   } else {
     return ONSSEN_E_ARG;
   }

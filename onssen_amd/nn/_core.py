@@ -351,4 +351,4 @@ def use_hip_path(module):
     return True
 
 
-EPI_BIAS, EPI_L2NORM, EPI_SIGMOID = _abi.EPI_BIAS, _abi.EPI_L2NORM, _abi.EPI_SIGMOID
+EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = _abi.EPI_BIAS, _abi.EPI_L2NORM, _abi.EPI_SIGMOID, _abi.EPI_RELU

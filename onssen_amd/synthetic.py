@@ -25,7 +25,7 @@ def lstm_param_shapes(in_dim, H, L, prefix="rnn."):
 def make_state_dict(kind, input_dim, hidden_dim, num_layers, embedding_dim=20,
                     num_speaker=2, seed=0, gain=1.0):
     """Reference-layout state_dict (numpy float32) for ``kind`` in
-    {"deep_clustering", "chimera", "phase_net"}.
+    {"deep_clustering", "chimera", "phase_net", "enhance"}.
 
     LSTM / Linear tensors ~ U(-1/sqrt(fan), 1/sqrt(fan)) like PyTorch's default
     init (times ``gain``); BatchNorm affine and running statistics are drawn
@@ -68,6 +68,12 @@ def make_state_dict(kind, input_dim, hidden_dim, num_layers, embedding_dim=20,
         lstm("chimera.rnn.", F)
         linear("chimera.fc_dc.", F * D, 2 * H)
         linear("chimera.fc_mi.", F * C, 2 * H)
+    elif kind == "enhance":
+        lstm("rnn.", F)
+        bn("bn.", 2 * H)
+        linear("fc_mi.", F, 2 * H)
+        linear("fc_pre.", F, F)
+        linear("fc_post.", F, F)
     else:
         raise ValueError(kind)
     return sd

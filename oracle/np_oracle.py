@@ -282,3 +282,16 @@ def loss_dc(embedding, one_hot, mag_mix):
     per = loss_dc_per_utt(embedding.reshape(B, -1, embedding.shape[-1]), one_hot.reshape(B, -1, one_hot.shape[-1]),
                           mag_mix.reshape(B, -1))
     return per[None, :] * np.asarray(mag_mix, np.float64).reshape(B, -1).sum(1)[:, None]
+
+
+# ----------------------------------------------------------------------------- N4: enhancement network
+def enhance_forward(sd, x, mag_noisy, dtype=np.float32):
+    """onssen/nn/enhancement.py:38-52 (eval mode): mask = sigmoid(fc_mi(bn(blstm(x)))) (:44-48), restoration layer
+    relu(fc_pre(mag_noisy)) (:49), product (:50), relu(fc_post(.)) (:51).  x, mag_noisy (B,T,F) -> clean (B,T,F)."""
+    sd = {k: np.asarray(v, dtype=dtype) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    x, mag = np.asarray(x, dtype=dtype), np.asarray(mag_noisy, dtype=dtype)
+    r = blstm_stack(x, sd, "rnn.", num_layers_of(sd))
+    r = batchnorm_eval(r, sd, "bn.")
+    mask = 1.0 / (1.0 + np.exp(-(r @ sd["fc_mi.weight"].T + sd["fc_mi.bias"])))
+    pre = np.maximum(mag @ sd["fc_pre.weight"].T + sd["fc_pre.bias"], 0)
+    return np.maximum((pre * mask) @ sd["fc_post.weight"].T + sd["fc_post.bias"], 0)

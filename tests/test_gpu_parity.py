@@ -459,3 +459,19 @@ def test_loss_dc_value_on_device_matches_reference_fixture(dev, golden_dir, monk
     with torch.no_grad():
         got = loss_dc([torch.from_numpy(emb).to(dev)], [torch.from_numpy(one_hot).to(dev), torch.from_numpy(mag).to(dev)])
     np.testing.assert_allclose(got.cpu().numpy(), O.loss_dc(emb, one_hot, mag), rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["g5_enhance_H16_L2", "g5_enhance_H32_L1"])
+def test_enhance_golden(dev, golden_dir, prec, name):
+    """N4: onssen.nn.enhance on the HIP path (BLSTM + BN-folded sigmoid mask head + the two ReLU restoration GEMMs)
+    against the reference's outputs."""
+    from onssen_amd import nn as onn
+    z = np.load(f"{golden_dir}/{name}.npz")
+    sd = make_state_dict("enhance", int(z["F"]), int(z["H"]), int(z["L"]), seed=int(z["seed"]), gain=float(z["gain"]))
+    m = onn.enhance(int(z["F"]), int(z["H"]), int(z["L"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        out, = m([torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["mag_noisy"]).to(dev)])
+    # outputs reach ~7; the mask carries the split-bf16 error, the two small layers are exact fp32
+    np.testing.assert_allclose(out.cpu().numpy(), z["out_clean"], atol=prec["atol"] * 4, rtol=1e-4)

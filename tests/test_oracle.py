@@ -133,3 +133,24 @@ def test_loss_dc_restatement_matches_reference_fixture(golden_dir):
     assert loss.shape == z["loss"].shape == (3, 3)
     np.testing.assert_allclose(loss, z["loss"], rtol=1e-4)
     np.testing.assert_allclose(loss.mean(), float(z["loss_mean"]), rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["g5_enhance_H16_L2", "g5_enhance_H32_L1"])
+def test_enhance_restatement_and_module_match_reference(golden_dir, name):
+    """N4: the oracle restatement of onssen.nn.enhance, and the drop-in module's autograd path with the reference's
+    parameter names loaded strictly, against the reference's own outputs (tools/gen_golden_enhance.py)."""
+    import torch
+    from onssen_amd import nn as onn
+    from onssen_amd.synthetic import make_state_dict
+    z = np.load(f"{golden_dir}/{name}.npz")
+    sd = make_state_dict("enhance", int(z["F"]), int(z["H"]), int(z["L"]), seed=int(z["seed"]), gain=float(z["gain"]))
+    out = O.enhance_forward(sd, z["x"], z["mag_noisy"])
+    np.testing.assert_allclose(out, z["out_clean"], atol=2e-5, rtol=1e-4)
+    m = onn.enhance(int(z["F"]), int(z["H"]), int(z["L"]))
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    with pytest.raises(AssertionError, match="two tensors"):
+        m([torch.from_numpy(z["x"])])
+    with torch.enable_grad():
+        got, = m([torch.from_numpy(z["x"]), torch.from_numpy(z["mag_noisy"])])      # CPU -> autograd path
+    np.testing.assert_allclose(got.detach().numpy(), z["out_clean"], atol=2e-5, rtol=1e-4)

@@ -1,3 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python tools/xcd_soak.py 2>&1 | grep -v amdgpu.ids | tail -4
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4

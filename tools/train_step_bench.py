@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""BASELINE config 4: one deep-clustering TRAINING step -- forward, loss_dc, backward, RCCL
+all-reduce of the gradients, clip, Adam -- on synthetic wsj0-2mix batches whose features and labels come from the HIP
+front end (STFT + label kernels).  The forward/backward of the network run on stock ATen ops (autograd); this is a
+harness measurement, not the product's hot path.  One JSON line like bench.py.
+
+    python tools/train_step_bench.py [--steps K --warmup W]            # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py --gpus N
+"""
+import argparse, json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=2)
+    args = ap.parse_args()
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from onssen_amd import nn as onn
+    from onssen_amd.data.synthetic_wsj0_2mix import wsj0_2mix_dataloader
+    from onssen_amd.dist import train_step
+    from onssen_amd.loss import loss_dc
+    fo = dict(batch_size=16, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
+    torch.manual_seed(0)
+    model = onn.deep_clustering(129, 600, args.layers, 20, dropout=0.3).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loader = wsj0_2mix_dataloader("dc", fo, "tr", device=str(dev))
+    batches = []
+    for i, b in enumerate(loader):
+        batches.append(b)
+        if i >= 3:
+            break
+    def step(i):
+        inp, lab = batches[i % len(batches)]
+        return train_step(model, opt, loss_dc, inp, lab, world=world)
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    if rank == 0:
+        frames = world * 16 * 400 * args.steps
+        print(json.dumps({"metric": "training real_time_factor (forward + loss_dc + backward + all-reduce + clip + Adam)",
+                          "value": frames * 64 / 8000 / dt, "unit": "audio-seconds trained per wall-second, whole job",
+                          "frames_per_s": frames / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32 (ATen / MIOpen autograd path)",
+                          "data": "synthetic", "last_loss": loss,
+                          "config": {"workload": f"deep_clustering {args.layers}xBLSTM-600 training, 16 x 400-frame chunks per GPU, features + labels from the HIP front end",
+                                     "parallelism": f"data parallel x{world}, RCCL all-reduce of per-layer gradient buckets before clipping"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
