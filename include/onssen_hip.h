@@ -239,6 +239,16 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
                        float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * N4  batch SI-SDR with the best source permutation (evaluation metric of tester.eval):
+ *   sdr_out[b] = max over permutations P of (1/C) sum_i SDR(est[b,i], org[b,P(i)]), signals zero-mean, optional
+ *   (B, n) mask applied after centring; perm_out[b] (nullable) = index of P in lexicographic order.
+ * Replaces calc_sdr_torch + batch_SDR_torch (onssen/evaluate/sdr.py:11-87).  est, org (B, C, n); C <= 4.
+ */
+size_t onssen_batch_sdr_workspace_bytes(int B);
+int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
+                         int* perm_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10  mask-apply + inverse STFT overlap-add.
  * Replaces `stft_est = stft_mix * mask; librosa.core.istft(stft_est[i].T, hop_length, length)` at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:42-45 and egs/wsj0-2mix/chimera/evaluate.py:40-43.

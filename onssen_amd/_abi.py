@@ -43,6 +43,8 @@ SIGNATURES = {
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
     "onssen_loss_dc_workspace_bytes": (_sz, [_i]),
+    "onssen_batch_sdr_workspace_bytes": (_sz, [_i]),
+    "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -86,6 +88,13 @@ class Lib:
 
     def lstm_pack_wih_bf16x3(self, w_ih, in_dim, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_wih_bf16x3(w_ih, in_dim, H, ug, out, stream), "onssen_lstm_pack_wih_bf16x3")
+
+    def batch_sdr_workspace_bytes(self, B):
+        return int(self.dll.onssen_batch_sdr_workspace_bytes(B))
+
+    def batch_sdr(self, est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_batch_sdr_f32(est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream),
+                   "onssen_batch_sdr_f32")
 
     def loss_dc_workspace_bytes(self, B):
         return int(self.dll.onssen_loss_dc_workspace_bytes(B))

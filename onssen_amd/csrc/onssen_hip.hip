@@ -2100,6 +2100,114 @@ __global__ __launch_bounds__(256) void loss_dc_final_kernel(const float* __restr
 }
 
 // =================================================================================================
+// N4: batch SI-SDR with best permutation, onssen/evaluate/sdr.py:11-87 (calc_sdr_torch + batch_SDR_torch).
+// Everything the metric needs per utterance is the Gram matrix of the 2C zero-mean (optionally masked) signals
+// [est_0..est_{C-1}, org_0..org_{C-1}]: pass 1 sums the signals (means), pass 2 the centred products, a last
+// workgroup per utterance forms the C x C SDR table and scans the C! permutations in the reference's
+// (lexicographic) order.  The separated waveforms never leave the device.
+// =================================================================================================
+namespace sdr {
+constexpr int NBLK = 32, CMAX = 4, SMAX = 2 * CMAX, TS = 256;
+constexpr int PSTRIDE = SMAX * SMAX + SMAX;     // per (b, block): Gram then sums
+}  // namespace sdr
+
+template <int PASS>
+__global__ __launch_bounds__(256) void sdr_partial_kernel(const float* __restrict__ est, const float* __restrict__ org,
+                                                          const float* __restrict__ mask, int C, int n,
+                                                          const float* __restrict__ means, float* __restrict__ partial) {
+  using namespace sdr;
+  __shared__ float tile[SMAX][TS + 1];
+  const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y, S = 2 * C;
+  const int per = (n + NBLK - 1) / NBLK, s0 = blk * per, s1 = s0 + per < n ? s0 + per : n;
+  float mu[SMAX];
+#pragma unroll
+  for (int k = 0; k < SMAX; ++k) mu[k] = (PASS == 1 && k < S) ? means[b * SMAX + k] : 0.0f;
+  float acc = 0.0f;                               // PASS 0: thread k < S sums signal k; PASS 1: thread o < S*S -> G[o/S][o%S]
+  for (int t0 = s0; t0 < s1; t0 += TS) {
+    const int nt = s1 - t0 < TS ? s1 - t0 : TS;
+    __syncthreads();
+    for (int e = tid; e < S * TS; e += 256) {
+      const int k = e / TS, i = e % TS;
+      float v = 0.0f;
+      if (i < nt) {
+        const float* src = (k < C ? est + ((long)b * C + k) * n : org + ((long)b * C + (k - C)) * n);
+        v = src[t0 + i];
+        if (PASS == 1) {
+          v -= mu[k];
+          if (mask) v *= mask[(long)b * n + t0 + i];
+        }
+      }
+      tile[k][i] = v;
+    }
+    __syncthreads();
+    if (PASS == 0) {
+      if (tid < S) for (int i = 0; i < nt; ++i) acc += tile[tid][i];
+    } else if (tid < S * S) {
+      const int k = tid / S, l = tid % S;
+      for (int i = 0; i < nt; ++i) acc += tile[k][i] * tile[l][i];
+    }
+  }
+  float* dst = partial + ((long)b * NBLK + blk) * PSTRIDE;
+  if (PASS == 0) {
+    if (tid < S) dst[SMAX * SMAX + tid] = acc;
+  } else if (tid < S * S) {
+    dst[tid] = acc;
+  }
+}
+
+__global__ void sdr_means_kernel(const float* __restrict__ partial, int C, int n, float* __restrict__ means) {
+  using namespace sdr;
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k < 2 * C) {
+    double s = 0.0;
+    for (int blk = 0; blk < NBLK; ++blk) s += partial[((long)b * NBLK + blk) * PSTRIDE + SMAX * SMAX + k];
+    means[b * SMAX + k] = (float)(s / n);
+  }
+}
+
+__global__ void sdr_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ sdr_out, int* __restrict__ perm_out) {
+  using namespace sdr;
+  __shared__ float G[SMAX][SMAX];
+  __shared__ float tab[CMAX][CMAX];
+  const int b = blockIdx.x, tid = threadIdx.x, S = 2 * C;
+  if (tid < S * S) {
+    double s = 0.0;
+    for (int blk = 0; blk < NBLK; ++blk) s += partial[((long)b * NBLK + blk) * PSTRIDE + tid];
+    G[tid / S][tid % S] = (float)s;
+  }
+  __syncthreads();
+  if (tid < C * C) {       // SDR[i][j] of estimate i against source j (sdr.py:23-33)
+    const int i = tid / C, j = tid % C;
+    const float oo = G[C + j][C + j], ee = G[i][i], eo = G[i][C + j];
+    const float scale = eo / (oo + 1e-8f);
+    const float true_p = scale * scale * oo + 1e-8f;
+    const float res_p = ee - 2.0f * scale * eo + scale * scale * oo + 1e-8f;
+    tab[i][j] = 10.0f * log10f(true_p) - 10.0f * log10f(res_p);
+  }
+  __syncthreads();
+  if (tid == 0) {          // permutations in lexicographic order (sorted(set(permutations(range(C)))), sdr.py:74)
+    int perm[CMAX], best_idx = 0, idx = 0;
+    for (int k = 0; k < C; ++k) perm[k] = k;
+    float best = -3.0e38f;
+    for (;;) {
+      float v = 0.0f;
+      for (int k = 0; k < C; ++k) v += tab[k][perm[k]];
+      if (v > best) { best = v; best_idx = idx; }      // torch.max keeps the first maximum
+      ++idx;
+      int a = C - 2;                                   // next lexicographic permutation
+      while (a >= 0 && perm[a] > perm[a + 1]) --a;
+      if (a < 0) break;
+      int c = C - 1;
+      while (perm[c] < perm[a]) --c;
+      int t = perm[a]; perm[a] = perm[c]; perm[c] = t;
+      for (int l = a + 1, r = C - 1; l < r; ++l, --r) { t = perm[l]; perm[l] = perm[r]; perm[r] = t; }
+    }
+    sdr_out[b] = best / (float)C;
+    if (perm_out) perm_out[b] = best_idx;
+  }
+}
+
+// =================================================================================================
 // C ABI
 // =================================================================================================
 extern "C" {
@@ -2379,6 +2487,28 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
   hipLaunchKernelGGL(loss_dc_partial_kernel, dim3(lossdc::NBLK, (unsigned)B), dim3(256), 0, st, emb, one_hot, mag, TF, D, C,
                      (float*)ws);
   hipLaunchKernelGGL(loss_dc_final_kernel, dim3((unsigned)B), dim3(256), 0, st, (const float*)ws, D, C, per_utt, total_mag);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+
+size_t onssen_batch_sdr_workspace_bytes(int B) {
+  return B > 0 ? ((size_t)B * sdr::NBLK * sdr::PSTRIDE + (size_t)B * sdr::SMAX) * sizeof(float) : 0;
+}
+
+int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
+                         int* perm_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!est || !org || !sdr_out || !ws || B <= 0 || C <= 0 || C > sdr::CMAX || n <= C) return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_batch_sdr_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)ws;
+  float* means = partial + (size_t)B * sdr::NBLK * sdr::PSTRIDE;
+  const dim3 grid(sdr::NBLK, (unsigned)B);
+  hipLaunchKernelGGL((sdr_partial_kernel<0>), grid, dim3(256), 0, st, est, org, mask, C, n, (const float*)nullptr, partial);
+  hipLaunchKernelGGL(sdr_means_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)partial, C, n, means);
+  hipLaunchKernelGGL((sdr_partial_kernel<1>), grid, dim3(256), 0, st, est, org, mask, C, n, (const float*)means, partial);
+  hipLaunchKernelGGL(sdr_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)partial, C, sdr_out, perm_out);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

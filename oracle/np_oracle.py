@@ -295,3 +295,30 @@ def enhance_forward(sd, x, mag_noisy, dtype=np.float32):
     mask = 1.0 / (1.0 + np.exp(-(r @ sd["fc_mi.weight"].T + sd["fc_mi.bias"])))
     pre = np.maximum(mag @ sd["fc_pre.weight"].T + sd["fc_pre.bias"], 0)
     return np.maximum((pre * mask) @ sd["fc_post.weight"].T + sd["fc_post.bias"], 0)
+
+
+# ----------------------------------------------------------------------------- N4: SI-SDR with best permutation
+def batch_sdr(estimation, origin, mask=None):
+    """onssen/evaluate/sdr.py:11-87 in fp64: zero-mean both (:62-63), optional mask AFTER centring (:19-21), scale-
+    invariant SDR of every (estimate, source) pair (:23-33), best permutation in sorted(permutations) order (:72-82).
+    (B, C, n) -> sdr (B,), perm index (B,)"""
+    from itertools import permutations
+    e = np.asarray(estimation, np.float64)
+    o = np.asarray(origin, np.float64)
+    B, C, n = e.shape
+    e = e - e.mean(2, keepdims=True)
+    o = o - o.mean(2, keepdims=True)
+    if mask is not None:
+        m = np.asarray(mask, np.float64)[:, None, :]
+        e, o = e * m, o * m
+    tab = np.zeros((B, C, C))
+    for i in range(C):
+        for j in range(C):
+            op = (o[:, j] ** 2).sum(1, keepdims=True) + 1e-8
+            scale = (o[:, j] * e[:, i]).sum(1, keepdims=True) / op
+            true = scale * o[:, j]
+            res = e[:, i] - true
+            tab[:, i, j] = 10 * np.log10((true ** 2).sum(1) + 1e-8) - 10 * np.log10((res ** 2).sum(1) + 1e-8)
+    perms = sorted(set(permutations(range(C))))
+    tot = np.stack([sum(tab[:, k, p[k]] for k in range(C)) for p in perms], 1)
+    return tot.max(1) / C, tot.argmax(1)

@@ -410,3 +410,20 @@ def test_loss_dc_value(lib, B, TF, D, C):
     ref = O.loss_dc_per_utt(emb, one_hot, mag)
     np.testing.assert_allclose(total, mag.sum(1), rtol=1e-5)
     np.testing.assert_allclose(per_utt, ref, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,C,n,use_mask", [(2, 2, 1500, False), (1, 3, 900, True), (1, 4, 700, False)])
+def test_batch_sdr(lib, B, C, n, use_mask):
+    """onssen_batch_sdr_f32 against the NumPy restatement of batch_SDR_torch (values and permutation index)."""
+    rng = np.random.default_rng(21)
+    org = rand(rng, B, C, n)
+    est = np.ascontiguousarray(org[:, ::-1] * 0.7 + 0.4 * rand(rng, B, C, n) + 0.1).astype(np.float32)
+    mask = None
+    if use_mask:
+        mask = np.ones((B, n), np.float32); mask[:, n - 200:] = 0
+    sdr = np.full(B, np.nan, np.float32); perm = np.full(B, -1, np.int32)
+    ws = aligned_f32(lib.batch_sdr_workspace_bytes(B) // 4 + 64)
+    lib.batch_sdr(P(est), P(org), P(mask), B, C, n, P(sdr), P(perm), P(ws), ws.nbytes, None)
+    ref_sdr, ref_perm = O.batch_sdr(est, org, mask)
+    np.testing.assert_allclose(sdr, ref_sdr, rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(perm, ref_perm)

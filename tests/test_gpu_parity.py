@@ -475,3 +475,21 @@ def test_enhance_golden(dev, golden_dir, prec, name):
         out, = m([torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["mag_noisy"]).to(dev)])
     # outputs reach ~7; the mask carries the split-bf16 error, the two small layers are exact fp32
     np.testing.assert_allclose(out.cpu().numpy(), z["out_clean"], atol=prec["atol"] * 4, rtol=1e-4)
+
+
+def test_batch_sdr_on_device_matches_reference_fixture(dev, golden_dir):
+    """N4: onssen_amd.evaluate.batch_SDR_torch (HIP) against the reference's own outputs, and on separated-waveform
+    sized inputs against the oracle."""
+    from onssen_amd.evaluate import batch_SDR_torch
+    z = np.load(f"{golden_dir}/g6_batch_sdr.npz")
+    for tag in ("c2", "c3m"):
+        mask = torch.from_numpy(z[f"{tag}_mask"]).to(dev) if f"{tag}_mask" in z.files else None
+        sdr, perm = batch_SDR_torch(torch.from_numpy(z[f"{tag}_est"]).to(dev), torch.from_numpy(z[f"{tag}_org"]).to(dev),
+                                    mask, return_perm=True)
+        np.testing.assert_allclose(sdr.cpu().numpy(), z[f"{tag}_sdr"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(perm.cpu().numpy(), z[f"{tag}_perm"])
+    rng = np.random.default_rng(3)
+    org = rng.standard_normal((32, 2, 25536)).astype(np.float32)
+    est = (org[:, ::-1] + 0.5 * rng.standard_normal(org.shape)).astype(np.float32)
+    got = batch_SDR_torch(torch.from_numpy(est.copy()).to(dev), torch.from_numpy(org).to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), O.batch_sdr(est, org)[0], rtol=1e-4, atol=1e-4)

@@ -154,3 +154,12 @@ def test_enhance_restatement_and_module_match_reference(golden_dir, name):
     with torch.enable_grad():
         got, = m([torch.from_numpy(z["x"]), torch.from_numpy(z["mag_noisy"])])      # CPU -> autograd path
     np.testing.assert_allclose(got.detach().numpy(), z["out_clean"], atol=2e-5, rtol=1e-4)
+
+
+def test_batch_sdr_restatement_matches_reference_fixture(golden_dir):
+    """N4: oracle/np_oracle.batch_sdr against the reference's batch_SDR_torch (tools/gen_golden_sdr.py)."""
+    z = np.load(f"{golden_dir}/g6_batch_sdr.npz")
+    for tag in ("c2", "c3m"):
+        sdr, perm = O.batch_sdr(z[f"{tag}_est"], z[f"{tag}_org"], z[f"{tag}_mask"] if f"{tag}_mask" in z.files else None)
+        np.testing.assert_allclose(sdr, z[f"{tag}_sdr"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(perm, z[f"{tag}_perm"])
