@@ -1,3 +1,22 @@
 #!/bin/bash
+# Round-end validation on the GPU box: parity suite, smoke, every bench configuration, rocprofv3 passes.
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -2 gpurun_out/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -1
+run() { name=$1; shift; timeout 400 env "$@" python bench.py ${BENCH_ARGS} > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err; python - <<PY
+import json
+try:
+    r = json.loads(open("gpurun_out/bench_$name.json").read().strip().splitlines()[-1])
+    print("$name", "ms/step %.3f" % r["ms_per_step"], "xRT %.0f" % r["value"], "fps %.0f" % r["frames_per_s"], "rec us/step %.2f" % r["roofline"]["us_per_time_step"], "frac %.3f" % r["roofline"]["frac"], "|", r["config"].get("recurrence"), "| cpu", round(r["cpu_baseline"]["value"]) if r.get("cpu_baseline") else None, r["roofline"]["other_kernels"]["ms_by_call"])
+except Exception as e:
+    print("$name FAILED", e, open("gpurun_out/bench_$name.err").read()[-400:])
+PY
+}
+BENCH_ARGS="" run dc_l2_bf16x3 A=1
+BENCH_ARGS="--config dc_l2 --precision f32 --no-cpu-baseline" run dc_l2_f32 A=1
+BENCH_ARGS="--config dc_l2 --no-cpu-baseline" run dc_l2_bf16x3_steps ONSSEN_XCD=0
+BENCH_ARGS="--config dc_l3 --no-cpu-baseline" run dc_l3 A=1
+BENCH_ARGS="--config chimera_l4 --no-cpu-baseline" run chimera_l4 A=1
+BENCH_ARGS="--config phase_l4 --no-cpu-baseline" run phase_l4 A=1
+bash tools/profile_round.sh r01g > gpurun_out/profile_round.log 2>&1
+head -7 gpurun_out/prof_r01g/kernel_stats.csv | cut -c1-150
