@@ -210,10 +210,11 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     """Roofline block for the dominant kernel, timed live with HIP events on the launch stream
     (each call captured in its own hipGraph and replayed, so host launch cost is excluded).
 
-    The recurrence and the GEMMs are both bound by the exact-fp32 MFMA rate (157.3 TFLOP/s dense).
-    Persistent form: lstm_persistent_kernel is ONE launch per layer whose duration is the event span
-    of a single-layer call minus its input-projection GEMM.  Launch-per-step form: the span of the T
-    dependent launches / T (includes the dependent-launch gap the serial chain really pays)."""
+    The recurrence and the GEMMs are priced against the MFMA rate of their arithmetic: dense bf16 / 3 for the
+    split-bf16 form, the exact-fp32 MFMA rate otherwise.  XCD-local persistent form: lstm_xcd_kernel is ONE launch
+    per layer (and 64 batch rows) whose duration is the event span of a single-layer call minus its input-projection
+    GEMM and input split.  Launch-per-step form: the span of the T dependent launches / T (it includes the
+    dependent-launch gap the serial chain really pays)."""
     from onssen_amd.features import stft_logmag
     from onssen_amd import _abi
     from onssen_amd.hip import get_lib
