@@ -16,8 +16,11 @@
  *  - Return value: 0 = ok; >0 = hipError_t of a failed launch; <0 = ONSSEN_E_*.
  *    No exceptions cross the ABI.  Functions are re-entrant; one in-flight call
  *    per workspace.
- *  - dtype: fp32 storage and arithmetic (exact-fp32 MFMA v_mfma_f32_16x16x4_f32);
- *    STFT / iSTFT butterflies run in fp64 like the reference's NumPy FFT.
+ *  - dtype: fp32 at every boundary.  Contractions run either on the exact-fp32 MFMA
+ *    (v_mfma_f32_16x16x4_f32; the *_f32 GEMM and the default BLSTM flags) or in split-bf16
+ *    (three v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulate, ~1e-5 relative;
+ *    ONSSEN_BLSTM_BF16X3, *_bf16x3, *_x3p) -- the caller chooses.  STFT / iSTFT butterflies
+ *    run in fp64 like the reference's NumPy FFT.
  */
 #ifndef ONSSEN_HIP_H
 #define ONSSEN_HIP_H

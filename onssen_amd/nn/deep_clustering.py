@@ -12,8 +12,8 @@ class deep_clustering(nn.Module):
 
     forward([x (B,T,F)]) -> [embedding (B,T,F,D)], unit L2 norm per TF bin.
     In eval mode without autograd the arithmetic runs in libonssen_hip.so
-    (input-projection GEMM, per-step recurrence kernels, BatchNorm folded into
-    the fc_dc GEMM whose epilogue normalises each bin).
+    (input-projection GEMMs, the XCD-local persistent recurrence, BatchNorm folded
+    into the fc_dc GEMM whose epilogue normalises each bin).
     """
 
     def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3):
