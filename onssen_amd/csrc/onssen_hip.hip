@@ -1775,6 +1775,12 @@ __device__ __forceinline__ int fft_perm(int n) {
   return (P::kOdd ? (n & 1) * P::M : 0) + r;
 }
 
+// LDS position of logical element i: two doubles of padding per 16, so that the strided accesses of the first
+// radix-4 stages (4 consecutive doubles every 16 / one double every 4) spread over all banks instead of 8
+__device__ __forceinline__ int fft_idx(int i) { return i + ((i >> 4) << 1); }
+template <int N>
+constexpr int fft_buf_len() { return N + N / 8; }
+
 template <int N>
 __device__ __forceinline__ double fft_win(int i) { return 0.5 - 0.5 * kCos1024[i * (1024 / N)]; }   // periodic Hann
 
@@ -1796,7 +1802,7 @@ __device__ __forceinline__ void fft_wave(double* re, double* im, int lane, bool 
       double xr[4], xi[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double ar = re[base + q * Ls], ai = im[base + q * Ls];
+        const double ar = re[fft_idx(base + q * Ls)], ai = im[fft_idx(base + q * Ls)];
         if (q == 0 || d == 0) {
           xr[q] = ar;
           xi[q] = ai;
@@ -1809,21 +1815,23 @@ __device__ __forceinline__ void fft_wave(double* re, double* im, int lane, bool 
       // y0 = x0+x1+x2+x3, y1 = x0 + s*i*x1 - x2 - s*i*x3 (s = sg: -i forward), y2 = x0-x1+x2-x3, y3 = x0 - s*i*x1 - x2 + s*i*x3
       const double ar = xr[0] + xr[2], ai = xi[0] + xi[2], br = xr[0] - xr[2], bi = xi[0] - xi[2];
       const double cr = xr[1] + xr[3], ci = xi[1] + xi[3], dr = xr[1] - xr[3], di = xi[1] - xi[3];
-      re[base] = ar + cr;           im[base] = ai + ci;
-      re[base + 2 * Ls] = ar - cr;  im[base + 2 * Ls] = ai - ci;
+      const int p0 = fft_idx(base), p1 = fft_idx(base + Ls), p2 = fft_idx(base + 2 * Ls), p3 = fft_idx(base + 3 * Ls);
+      re[p0] = ar + cr;  im[p0] = ai + ci;
+      re[p2] = ar - cr;  im[p2] = ai - ci;
       // s*i*(dr + i di) = s*(-di + i dr)
-      re[base + Ls] = br - sg * di;      im[base + Ls] = bi + sg * dr;
-      re[base + 3 * Ls] = br + sg * di;  im[base + 3 * Ls] = bi - sg * dr;
+      re[p1] = br - sg * di;  im[p1] = bi + sg * dr;
+      re[p3] = br + sg * di;  im[p3] = bi - sg * dr;
     }
   }
   if (P::kOdd) {   // X[k] = E[k] + W_N^k O[k], X[k + N/2] = E[k] - W_N^k O[k]
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < N / 2; k += 64) {
       const double wr = kCos1024[k * (1024 / N)], wi = sg * kSin1024[k * (1024 / N)];
-      const double er = re[k], ei = im[k], orr = re[k + N / 2], oi = im[k + N / 2];
+      const int pe = fft_idx(k), po = fft_idx(k + N / 2);
+      const double er = re[pe], ei = im[pe], orr = re[po], oi = im[po];
       const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
-      re[k] = er + tr;          im[k] = ei + ti;
-      re[k + N / 2] = er - tr;  im[k + N / 2] = ei - ti;
+      re[pe] = er + tr;  im[pe] = ei + ti;
+      re[po] = er - tr;  im[po] = ei - ti;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1833,7 +1841,7 @@ template <int N>
 __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ wav, int B, int n_samples,
                                                           long wav_stride, int hop, int T, float eps,
                                                           float* __restrict__ logmag, float* __restrict__ stft_ri) {
-  __shared__ double buf_re[4][N], buf_im[4][N];
+  __shared__ double buf_re[4][fft_buf_len<N>()], buf_im[4][fft_buf_len<N>()];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int F = N / 2 + 1;
   const long total = (long)B * T;
@@ -1847,13 +1855,13 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
       int pidx = t * hop + i - N / 2;  // centred frame, reflect padding (edge sample not repeated)
       if (pidx < 0) pidx = -pidx;
       if (pidx >= n_samples) pidx = 2 * (n_samples - 1) - pidx;
-      const int j = fft_perm<N>(i);
+      const int j = fft_idx(fft_perm<N>(i));
       re[j] = (double)sig[pidx] * fft_win<N>(i);
       im[j] = 0.0;
     }
     fft_wave<N>(re, im, lane, false);
     for (int f = lane; f < F; f += 64) {
-      const float xr = (float)re[f], xi = (float)im[f];  // complex128 -> complex64 like the reference
+      const float xr = (float)re[fft_idx(f)], xi = (float)im[fft_idx(f)];  // complex128 -> complex64 like the reference
       const long o = (frame * F + f);
       logmag[o] = log10f(hypotf(xr, xi) + eps);
       if (stft_ri) {
@@ -1872,7 +1880,7 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
                                                          const float* __restrict__ mask, long m_sb, long m_sc,
                                                          long m_st, long m_sf, int C, int T, int hop, int length,
                                                          int FR, float* __restrict__ out) {
-  __shared__ double buf_re[4][N], buf_im[4][N];
+  __shared__ double buf_re[4][fft_buf_len<N>()], buf_im[4][fft_buf_len<N>()];
   __shared__ double fr[FB][N];  // windowed time-domain frames of this chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int F = N / 2 + 1;
@@ -1898,17 +1906,17 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
         xi = (double)xs[2 * f + 1] * (double)mv;
       }
       if (f == 0 || f == N / 2) xi = 0.0;  // c2r transforms ignore the imaginary part of DC / Nyquist
-      const int j = fft_perm<N>(f);
+      const int j = fft_idx(fft_perm<N>(f));
       re[j] = xr;
       im[j] = xi;
       if (f > 0 && f < N / 2) {  // Hermitian mirror
-        const int jm = fft_perm<N>(N - f);
+        const int jm = fft_idx(fft_perm<N>(N - f));
         re[jm] = xr;
         im[jm] = -xi;
       }
     }
     fft_wave<N>(re, im, lane, true);
-    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? fft_win<N>(i) * (re[i] * inv_n) : 0.0;
+    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? fft_win<N>(i) * (re[fft_idx(i)] * inv_n) : 0.0;
     __builtin_amdgcn_wave_barrier();   // the wave's next round overwrites its buffer
   }
   __syncthreads();
