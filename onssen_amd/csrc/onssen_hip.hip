@@ -1875,16 +1875,22 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restric
 
 // FB = frames transformed per workgroup (FB/4 rounds of 4 waves); sized so that the LDS image
 // (tables + 4 FFT buffers + FB windowed frames, all fp64) stays under 160 KiB.
-template <int N, int FB>
+// PAIR: two speakers per workgroup through ONE complex inverse FFT per frame: with Z = S_a + i S_b (both Hermitian),
+// ifft(Z) = s_a + i s_b because s_a and s_b are real -- half the butterflies of two real transforms.  blockIdx.y then
+// counts speaker pairs (the last pair of an odd C repeats its only speaker and drops the copy).
+template <int N, int FB, bool PAIR>
 __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ stft_ri,
                                                          const float* __restrict__ mask, long m_sb, long m_sc,
                                                          long m_st, long m_sf, int C, int T, int hop, int length,
                                                          int FR, float* __restrict__ out) {
+  constexpr int NS = PAIR ? 2 : 1;
   __shared__ double buf_re[4][fft_buf_len<N>()], buf_im[4][fft_buf_len<N>()];
-  __shared__ double fr[FB][N];  // windowed time-domain frames of this chunk
+  __shared__ float fr[NS][FB][N];   // windowed time-domain frames of this chunk (the reference's istft keeps them in
+                                    // float32 too); 50 KB per workgroup with the FFT buffers: three workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int F = N / 2 + 1;
-  const int chunk = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+  const int chunk = blockIdx.x, b = blockIdx.z;
+  const int c0 = PAIR ? 2 * (int)blockIdx.y : (int)blockIdx.y, c1 = (PAIR && c0 + 1 < C) ? c0 + 1 : c0;
   // output samples n in [chunk*FR*hop, +FR*hop); padded position p = n + N/2 is covered by frames
   // t with t*hop <= p < t*hop + N
   const int p0 = chunk * FR * hop + N / 2;
@@ -1897,26 +1903,37 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
     double* re = buf_re[wave];
     double* im = buf_im[wave];
     const float* xs = stft_ri + ((long)(b * T + (active ? t : 0)) * F) * 2;
-    const float* ms = mask ? mask + (long)b * m_sb + (long)c * m_sc + (long)(active ? t : 0) * m_st : nullptr;
+    const float* ms0 = mask ? mask + (long)b * m_sb + (long)c0 * m_sc + (long)(active ? t : 0) * m_st : nullptr;
+    const float* ms1 = mask ? mask + (long)b * m_sb + (long)c1 * m_sc + (long)(active ? t : 0) * m_st : nullptr;
     for (int f = lane; f < F; f += 64) {
-      double xr = 0.0, xi = 0.0;
+      // S_a = X * m_a (and S_b = X * m_b); c2r transforms ignore the imaginary part of DC / Nyquist
+      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
       if (active) {
-        const float mv = ms ? ms[(long)f * m_sf] : 1.0f;
-        xr = (double)xs[2 * f] * (double)mv;
-        xi = (double)xs[2 * f + 1] * (double)mv;
+        const double xr = (double)xs[2 * f], xi = (f == 0 || f == N / 2) ? 0.0 : (double)xs[2 * f + 1];
+        const double ma = ms0 ? (double)ms0[(long)f * m_sf] : 1.0;
+        ar = xr * ma;
+        ai = xi * ma;
+        if (PAIR) {
+          const double mb = ms1 ? (double)ms1[(long)f * m_sf] : 1.0;
+          br = xr * mb;
+          bi = xi * mb;
+        }
       }
-      if (f == 0 || f == N / 2) xi = 0.0;  // c2r transforms ignore the imaginary part of DC / Nyquist
       const int j = fft_idx(fft_perm<N>(f));
-      re[j] = xr;
-      im[j] = xi;
-      if (f > 0 && f < N / 2) {  // Hermitian mirror
+      re[j] = ar - bi;           // Z[f] = S_a[f] + i S_b[f]
+      im[j] = ai + br;
+      if (f > 0 && f < N / 2) {  // Hermitian mirrors: Z[N-f] = conj(S_a[f]) + i conj(S_b[f])
         const int jm = fft_idx(fft_perm<N>(N - f));
-        re[jm] = xr;
-        im[jm] = -xi;
+        re[jm] = ar + bi;
+        im[jm] = -ai + br;
       }
     }
     fft_wave<N>(re, im, lane, true);
-    for (int i = lane; i < N; i += 64) fr[fidx][i] = active ? fft_win<N>(i) * (re[fft_idx(i)] * inv_n) : 0.0;
+    for (int i = lane; i < N; i += 64) {
+      const double w = active ? fft_win<N>(i) * inv_n : 0.0;
+      fr[0][fidx][i] = (float)(w * re[fft_idx(i)]);
+      if (PAIR) fr[1][fidx][i] = (float)(w * im[fft_idx(i)]);
+    }
     __builtin_amdgcn_wave_barrier();   // the wave's next round overwrites its buffer
   }
   __syncthreads();
@@ -1925,22 +1942,26 @@ __global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict
     const int n = chunk * FR * hop + idx;
     if (n >= length) continue;
     const int pp = n + N / 2;
-    double y = 0.0;
+    double y0 = 0.0, y1 = 0.0;
     if (pp < exp_len) {
       int tlo = (pp - N + hop) / hop;
       if (pp - N + 1 <= 0) tlo = 0;
       int thi = pp / hop;
       if (thi > T - 1) thi = T - 1;
-      double s = 0.0, wss = 0.0;
+      double s0 = 0.0, s1 = 0.0, wss = 0.0;
       for (int t = tlo; t <= thi && t - tfirst < FB; ++t) {
         const int i = pp - t * hop;
-        s += fr[t - tfirst][i];
+        s0 += (double)fr[0][t - tfirst][i];
+        if (PAIR) s1 += (double)fr[1][t - tfirst][i];
         const double w = fft_win<N>(i);
         wss += w * w;
       }
-      y = (wss > 2.2250738585072014e-308) ? s / wss : s;
+      const bool norm = wss > 2.2250738585072014e-308;
+      y0 = norm ? s0 / wss : s0;
+      y1 = norm ? s1 / wss : s1;
     }
-    out[((long)b * C + c) * length + n] = (float)y;
+    out[((long)b * C + c0) * length + n] = (float)y0;
+    if (PAIR && c1 != c0) out[((long)b * C + c1) * length + n] = (float)y1;
   }
 }
 
@@ -2756,23 +2777,27 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
   if (!stft_ri || !out || B <= 0 || C <= 0 || T <= 0 || hop <= 0 || length <= 0 || hop > n_fft) return ONSSEN_E_ARG;
   // a chunk of FR hops of output needs FR + ceil(n_fft/hop) - 1 frames (one more when the chunk
   // origin n_fft/2 is not hop-aligned); FB frames fit in LDS
-  const int FB = n_fft <= 512 ? 16 : 8;
-  const int halo = ceil_div(n_fft, hop) - 1;
+  // speakers go through the inverse FFT in pairs (one complex transform for two real frames) when there are at least
+  // two; FB frames of both speakers then share the LDS, so the longer transforms keep fewer frames per workgroup
   const bool hop_aligned = (n_fft % hop) == 0 && ((n_fft / 2) % hop) == 0;
-  const int FR = FB - halo - (hop_aligned ? 0 : 1);
+  const int halo = ceil_div(n_fft, hop) - 1 + (hop_aligned ? 0 : 1);
+  bool pair = C >= 2 && n_fft <= 512;
+  int FB = pair ? (n_fft <= 256 ? 16 : 8) : (n_fft <= 512 ? 16 : 8);
+  if (pair && FB - halo <= 0) {      // very small hops: the unpaired form keeps more frames per workgroup
+    pair = false;
+    FB = 16;
+  }
+  const int FR = FB - halo;
   if (FR <= 0) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
-  const dim3 grid((unsigned)ceil_div(length, FR * hop), (unsigned)C, (unsigned)B), block(256);
+  const dim3 grid((unsigned)ceil_div(length, FR * hop), (unsigned)(pair ? ceil_div(C, 2) : C), (unsigned)B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (n_fft == 256)
-    hipLaunchKernelGGL((mask_istft_kernel<256, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
-                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
-  else if (n_fft == 512)
-    hipLaunchKernelGGL((mask_istft_kernel<512, 16>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
-                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
-  else if (n_fft == 1024)
-    hipLaunchKernelGGL((mask_istft_kernel<1024, 8>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc,
-                       (long)m_st, (long)m_sf, C, T, hop, length, FR, out);
+#define ONSSEN_ISTFT(N_, FB_, PAIR_)                                                                                    \
+  hipLaunchKernelGGL((mask_istft_kernel<N_, FB_, PAIR_>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc, \
+                     (long)m_st, (long)m_sf, C, T, hop, length, FR, out)
+  if (n_fft == 256) { if (pair) ONSSEN_ISTFT(256, 16, true); else ONSSEN_ISTFT(256, 16, false); }
+  else if (n_fft == 512) { if (pair) ONSSEN_ISTFT(512, 8, true); else ONSSEN_ISTFT(512, 16, false); }
+  else if (n_fft == 1024) ONSSEN_ISTFT(1024, 8, false);
   else
     return ONSSEN_E_ARG;
   ONSSEN_LAUNCH_CHECK();

@@ -157,6 +157,11 @@ def test_mask_istft_matches_oracle(lib, n_fft, hop, n, length):
     out1 = np.zeros((B, 1, length), np.float32)
     lib.mask_istft(P(ri), None, 0, 0, 0, 0, B, 1, T, n_fft, hop, length, P(out1), None)
     np.testing.assert_allclose(out1[0, 0], O.istft(specs[0], hop, length), atol=2e-6)
+    if hop == 64 and length == 2000:       # odd speaker count: speakers go through the FFT in pairs, the last one alone
+        m3 = rng.random((B, 3, T, F)).astype(np.float32)
+        out3 = np.full((B, 3, length), np.nan, np.float32)
+        lib.mask_istft(P(ri), P(m3), 3 * T * F, T * F, F, 1, B, 3, T, n_fft, hop, length, P(out3), None)
+        np.testing.assert_allclose(out3[1], O.mask_istft(specs[1], m3[1], hop, length), atol=2e-6)
 
 
 def _shm(shape, fill=0.0, dtype=np.float32):
