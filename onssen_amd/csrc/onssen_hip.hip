@@ -53,2188 +53,13 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// =================================================================================================
-// Weight packing
-// =================================================================================================
-
-// packed gate column p of a direction  <->  (unit-group, unit-in-group, gate), gate fastest: the four gate
-// pre-activations of one hidden unit are one aligned float4 of G for the recurrence epilogue
-//   p = ugi*(4*UG) + ju*4 + gate ;  original nn.LSTM row = gate*H + ugi*UG + ju  (gate order i,f,g,o)
-__global__ void pack_wih_kernel(const float* __restrict__ w_ih, const float* __restrict__ b_ih,
-                                const float* __restrict__ b_hh, int in_dim, int bidir_in, int H, int Hp, int UG,
-                                int Kp, float* __restrict__ wih_p, float* __restrict__ bias_p) {
-  const int NP = 4 * Hp;
-  const long total = (long)NP * Kp;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int p = (int)(e / Kp), kk = (int)(e % Kp);
-    const int ugi = p / (4 * UG), rem = p % (4 * UG), ju = rem / 4, gate = rem % 4;
-    const int u = ugi * UG + ju;
-    int k;
-    bool ok = u < H;
-    if (bidir_in) {
-      const int d = kk / Hp, j = kk % Hp;
-      k = d * H + j;
-      ok = ok && (j < H);
-    } else {
-      k = kk;
-      ok = ok && (kk < in_dim);
-    }
-    const int n = gate * H + u;
-    wih_p[e] = ok ? w_ih[(long)n * in_dim + k] : 0.0f;
-    if (kk == 0) bias_p[p] = (u < H) ? (b_ih[n] + b_hh[n]) : 0.0f;
-  }
-}
-
-// MFMA B-fragment image of W_hh: [ugi][q][nt][lane][r] with
-//   column = nt*16 + (lane&15) (local packed column = gate*UG + ju),  k = 16q + 4(lane>>4) + r
-__global__ void pack_whh_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ,
-                                float* __restrict__ whh_p) {
-  const int NTl = UG / 4, NU = Hp / UG;
-  const long total = (long)NU * KQ * NTl * 256;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(e & 3), lane = (int)((e >> 2) & 63);
-    long rest = e >> 8;
-    const int nt = (int)(rest % NTl);
-    rest /= NTl;
-    const int q = (int)(rest % KQ);
-    const int ugi = (int)(rest / KQ);
-    const int pl = nt * 16 + (lane & 15);
-    const int gate = pl / UG, ju = pl % UG;
-    const int u = ugi * UG + ju;
-    const int k = 16 * q + 4 * (lane >> 4) + r;
-    whh_p[e] = (u < H && k < H) ? w_hh[(long)(gate * H + u) * H + k] : 0.0f;
-  }
-}
-
-// split-bf16 MFMA B-fragment image of W_hh for v_mfma_f32_16x16x32_bf16: [ugi][q][nt][hi|lo][lane][8] with
-//   column = nt*16 + (lane&15),  k = 32q + 8(lane>>4) + j
-// w: [4H][K] (W_hh with K = H, or a layer's W_ih with K = its input width); KQ2 = ceil(K / 32) chunks
-__global__ void pack_whh_bf16x3_kernel(const float* __restrict__ w_hh, int H, int Hp, int UG, int KQ2, int K,
-                                       unsigned short* __restrict__ out) {
-  const int NTl = UG / 4, NU = Hp / UG;
-  const long total = (long)NU * KQ2 * NTl * 512;   // (lane, j) pairs; each writes hi and lo
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
-    long rest = e >> 9;
-    const int nt = (int)(rest % NTl);
-    rest /= NTl;
-    const int q = (int)(rest % KQ2);
-    const int ugi = (int)(rest / KQ2);
-    const int pl = nt * 16 + (lane & 15);
-    const int gate = pl / UG, ju = pl % UG;
-    const int u = ugi * UG + ju;
-    const int k = 32 * q + 8 * (lane >> 4) + j;
-    const float v = (u < H && k < K) ? w_hh[(long)(gate * H + u) * K + k] : 0.0f;
-    unsigned short hi, lo;
-    split_bf16(v, hi, lo);
-    const long base = (((long)(ugi * KQ2 + q) * NTl + nt) * 2) * 512 + lane * 8 + j;
-    out[base] = hi;
-    out[base + 512] = lo;
-  }
-}
-
-// one workgroup per output row n: scale the weight row by the BatchNorm factor, fold the shift into the bias
-__global__ void pack_head_kernel(const float* __restrict__ w, const float* __restrict__ b, int N, int H, int Hp,
-                                 const float* __restrict__ g, const float* __restrict__ beta,
-                                 const float* __restrict__ mean, const float* __restrict__ var, float bn_eps,
-                                 float* __restrict__ w_p, float* __restrict__ b_p) {
-  __shared__ float red[256];
-  const int n = blockIdx.x, tid = threadIdx.x;
-  float part = 0.0f;
-  for (int kk = tid; kk < 2 * Hp; kk += 256) {
-    const int d = kk / Hp, j = kk % Hp;
-    float v = 0.0f;
-    if (j < H) {
-      const int k = d * H + j;
-      const float wv = w[(long)n * 2 * H + k];
-      if (g) {
-        const float s = g[k] / sqrtf(var[k] + bn_eps);
-        v = wv * s;
-        part += wv * (beta[k] - mean[k] * s);
-      } else {
-        v = wv;
-      }
-    }
-    w_p[(long)n * 2 * Hp + kk] = v;
-  }
-  red[tid] = part;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  if (tid == 0) b_p[n] = b[n] + red[0];
-}
-
-// K11 glue: phase-network recurrent input  cat(x_mag * mask_s, x_phase.view(B,T,2F)) for every speaker s,
-// stacked on the batch axis so that the shared-weight BLSTM runs once with batch C*B.
-__global__ void phase_input_kernel(const float* __restrict__ x_mag, const float* __restrict__ mask, long m_sb,
-                                   long m_sc, long m_st, long m_sf, const float* __restrict__ x_phase, int B, int C,
-                                   int T, int F, float* __restrict__ out) {
-  const long total = (long)C * B * T * 3 * F;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(e % (3 * F));
-    long rest = e / (3 * F);
-    const int t = (int)(rest % T);
-    rest /= T;
-    const int b = (int)(rest % B), sidx = (int)(rest / B);
-    float v;
-    if (j < F)
-      v = x_mag[((long)b * T + t) * F + j] * mask[(long)b * m_sb + (long)sidx * m_sc + (long)t * m_st + (long)j * m_sf];
-    else
-      v = x_phase[((long)b * T + t) * 2 * F + (j - F)];
-    out[e] = v;
-  }
-}
-
-// =================================================================================================
-// K3/K7/K8/K9: exact-fp32 MFMA GEMM  C = epi(A W^T + bias)
-// =================================================================================================
-namespace lin {
-constexpr int BM = 128, BN = 80, BK = 16;
-constexpr int LD = 20;              // LDS row stride (floats) of the staged A / W tiles: 16 + 4 pad
-constexpr int CLD = 84;             // LDS row stride of the C tile in the epilogue
-constexpr int STAGE = 2 * (BM + BN) * LD;
-constexpr int SMEM = (BM * CLD > STAGE) ? BM * CLD : STAGE;
-}  // namespace lin
-
-struct LinearArgs {
-  const float* A;
-  long a_s0, a_s1;
-  const float* W;
-  const float* bias;
-  const float* resid;
-  float* C;
-  long c_s0, c_s1;
-  int R, M, N, K, ldw, group;
-  float eps;
-};
-
-__device__ __forceinline__ float f4c(const float4& v, int r) {
-  return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w));
-}
-
-template <bool A_VEC, int MODE>
-__global__ __launch_bounds__(256) void linear_kernel(LinearArgs p) {
-  using namespace lin;
-  __shared__ __attribute__((aligned(16))) float smem[SMEM];
-  __shared__ long c_rowoff[BM];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  float* As = smem;
-  float* Bs = smem + 2 * BM * LD;
-
-  // ---- staging coordinates: thread -> (row, 4-wide k quad) of the A tile (2 rows) and W tile (<=2 rows)
-  const int kq = tid & 3;
-  long a_off[2];
-  bool a_ok[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int m = m0 + (tid >> 2) + 64 * it;
-    a_ok[it] = m < p.M;
-    a_off[it] = a_ok[it] ? (long)(m / p.R) * p.a_s0 + (long)(m % p.R) * p.a_s1 : 0;
-  }
-  long w_off[2];
-  bool w_ok[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int row = (tid >> 2) + 64 * it;
-    w_ok[it] = (row < BN) && (n0 + row < p.N);
-    w_off[it] = w_ok[it] ? (long)(n0 + row) * p.ldw : 0;
-  }
-
-  float4 ra[2], rb[2];
-  auto g_load = [&](int k0) {
-    const int k = k0 + 4 * kq;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_ok[it]) {
-        const float* src = p.A + a_off[it] + k;
-        if (A_VEC) {
-          if (k < p.K) v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (k + 0 < p.K) v.x = src[0];
-          if (k + 1 < p.K) v.y = src[1];
-          if (k + 2 < p.K) v.z = src[2];
-          if (k + 3 < p.K) v.w = src[3];
-        }
-      }
-      ra[it] = v;
-      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (w_ok[it] && k < p.ldw) u = *reinterpret_cast<const float4*>(p.W + w_off[it] + k);
-      rb[it] = u;
-    }
-  };
-  auto s_store = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = (tid >> 2) + 64 * it;
-      *reinterpret_cast<float4*>(As + (buf * BM + row) * LD + 4 * kq) = ra[it];
-      if (row < BN) *reinterpret_cast<float4*>(Bs + (buf * BN + row) * LD + 4 * kq) = rb[it];
-    }
-  };
-
-  f32x4 acc[2][5];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkb = (p.K + BK - 1) / BK;
-  g_load(0);
-  s_store(0);
-  __syncthreads();
-  const int fi = lane & 15, fg = lane >> 4;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nkb) g_load((kb + 1) * BK);
-    const float* Ab = As + (cur * BM + wave * 32 + fi) * LD + 4 * fg;
-    const float* Bb = Bs + (cur * BN + fi) * LD + 4 * fg;
-    float4 av[2], bv[5];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const float4*>(Ab + mt * 16 * LD);
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) bv[nt] = *reinterpret_cast<const float4*>(Bb + nt * 16 * LD);
-    // the MFMA contracts over the 4 lane groups; with one float4 per lane, step r covers
-    // k = 4*group + r -- A and W use the same permutation, so the sum is the plain dot product
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 5; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(av[mt], r), f4c(bv[nt], r), acc[mt][nt], 0, 0, 0);
-    if (kb + 1 < nkb) s_store(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: accumulators (+bias) -> LDS C tile -> (residual) -> (group L2 norm) -> coalesced store
-  float* Cs = smem;
-#pragma unroll
-  for (int nt = 0; nt < 5; ++nt) {
-    const int col = nt * 16 + fi;
-    const float bv1 = (n0 + col < p.N) ? p.bias[n0 + col] : 0.0f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Cs[(wave * 32 + mt * 16 + 4 * fg + r) * CLD + col] = acc[mt][nt][r] + bv1;
-  }
-  if (tid < BM) {
-    const int m = m0 + tid;
-    c_rowoff[tid] = (m < p.M) ? (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1 : -1;
-  }
-  __syncthreads();
-  if (MODE == ONSSEN_EPI_L2NORM) {
-    if (p.resid) {
-      for (int e = tid; e < BM * BN; e += 256) {
-        const int row = e / BN, col = e % BN;
-        const long off = c_rowoff[row];
-        if (off >= 0 && n0 + col < p.N) Cs[row * CLD + col] += p.resid[off + n0 + col];
-      }
-      __syncthreads();
-    }
-    // 4 lanes per (row, group): strided partial sums, two xor-shuffles, in-place divide
-    const int ng = BN / p.group, items = BM * ng, sub = tid & 3;
-    for (int it = tid >> 2; it < items; it += 64) {
-      float* v = Cs + (it / ng) * CLD + (it % ng) * p.group;
-      float s = 0.0f;
-      for (int d = sub; d < p.group; d += 4) s += v[d] * v[d];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      const float den = fmaxf(sqrtf(s), p.eps);
-      for (int d = sub; d < p.group; d += 4) v[d] = v[d] / den;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < BM * BN; e += 256) {
-    const int row = e / BN, col = e % BN;
-    const long off = c_rowoff[row];
-    if (off >= 0 && n0 + col < p.N) {
-      float v = Cs[row * CLD + col];
-      if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-      if (MODE == ONSSEN_EPI_RELU) {
-        v = fmaxf(v, 0.0f);
-        if (p.resid) v *= p.resid[off + n0 + col];      // relu(A W^T + b) * gate  (enhance: restoration layer x mask)
-      }
-      p.C[off + n0 + col] = v;
-    }
-  }
-}
-
-
-// =================================================================================================
-// K3/K7/K8/K9, split-bf16 form:  C = epi(A W^T + bias) with every fp32 product evaluated as
-// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
-// 256x160x32 tile, 8 waves (4 along M x 2 along N, 64x80 per wave = 4x5 MFMA tiles, 60 MFMAs per k-step).
-// A arrives as fp32 and is split while it is staged into LDS (3 VALU ops per element, hidden behind the
-// MFMAs); W is pre-split at pack time ([N][ldw] hi plane, then lo plane).  Epilogues as linear_kernel;
-// the tile is 160 = 2 x lcm(16,20) columns wide so that a TF bin's 20 embedding outputs never straddle tiles.
-// =================================================================================================
-namespace lx3 {
-constexpr int BN = 160, BK = 32;
-constexpr int LD = 40;                       // LDS row stride in bf16 elements: 32 + 8 pad (80 B rows)
-constexpr int QR = 64, CLD = 164;            // epilogue: 64-row slices of the C tile, padded stride
-constexpr int EPI_BYTES = QR * CLD * 4;
-constexpr int stage_bytes(int bm) { return (2 * bm + 2 * BN) * LD * 2; }
-constexpr int smem_bytes(int bm) { return stage_bytes(bm) > EPI_BYTES ? stage_bytes(bm) : EPI_BYTES; }
-}  // namespace lx3
-
-struct LinearX3Args {
-  const float* A;
-  long a_s0, a_s1;
-  const unsigned short* Whi;
-  const unsigned short* Wlo;
-  const float* bias;
-  const float* resid;
-  float* C;
-  long c_s0, c_s1;
-  int R, M, N, K, ldw, group;
-  float eps;
-  int c_vec;    // C rows 16-byte aligned and N % 4 == 0
-  int tile_group;  // N-tiles walked together (L2 blocking)
-  int ablate;   // profiling only (ONSSEN_X3_ABLATE): 1 no global loads, 2 no split/LDS store, 4 no MFMA, 8 no fragment reads
-};
-
-__device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) { return (unsigned)a | ((unsigned)b << 16); }
-
-// WM = waves along M (64 rows each): WM=4 -> 256x160 tile, 512 threads, one workgroup per CU; WM=2 -> 128x160
-// tile, 256 threads, 46 KB of LDS: three workgroups per CU sit in different phases, so one's MFMAs cover
-// another's staging without any intra-workgroup choreography.
-template <bool A_VEC, int MODE, int WM>
-__global__ __launch_bounds__(128 * WM) void linear_x3_kernel(LinearX3Args p) {
-  using namespace lx3;
-  constexpr int BM = 64 * WM, NTHR = 128 * WM;
-  constexpr int WIT = (2 * BN * 4 + NTHR - 1) / NTHR;      // 16-byte W chunks per thread per k-step
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[smem_bytes(BM)];
-  __shared__ long c_rowoff[BM];
-  unsigned short* Ahi = reinterpret_cast<unsigned short*>(smem_raw);
-  unsigned short* Alo = Ahi + BM * LD;
-  unsigned short* Bhi = Alo + BM * LD;
-  unsigned short* Blo = Bhi + BN * LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: workgroup b is observed to run on XCD b % 8 (speed only, never correctness), so give
-  // every XCD a contiguous run of tiles -- neighbours then share their A row panel in that XCD's private L2
-  int n0, m0;
-  {
-    const int nbx = gridDim.x, nwg = nbx * gridDim.y, bid = blockIdx.y * nbx + blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // ... and walk the tiles in column groups of GN: the group's W panels (GN x ~0.8 MB split-bf16 at K=1200)
-    // stay resident in the XCD's 4 MB L2 while the row panels of A stream past them
-    const int GN = p.tile_group, nby = gridDim.y;
-    const int gfull = nbx / GN, nfull = gfull * GN * nby;
-    int tn, tm;
-    if (wg < nfull) {
-      const int rem = wg % (nby * GN);
-      tn = (wg / (nby * GN)) * GN + rem % GN;
-      tm = rem / GN;
-    } else {
-      const int gl = nbx - gfull * GN, rem = wg - nfull;
-      tn = gfull * GN + rem % gl;
-      tm = rem / gl;
-    }
-    n0 = tn * BN;
-    m0 = tm * BM;
-  }
-
-  // ---- staging coordinates.  A: 256 rows x 8 float4 per k-step -> 4 per thread; W: 160 rows x 4 x 16 B per plane
-  const int akq = tid & 7;
-  long a_off[4];
-  bool a_ok[4];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int m = m0 + (tid >> 3) + (NTHR / 8) * it;
-    a_ok[it] = m < p.M;
-    a_off[it] = a_ok[it] ? (long)(m / p.R) * p.a_s0 + (long)(m % p.R) * p.a_s1 : 0;
-  }
-  const int wc = tid & 3;                  // 16-byte chunk within the 64-byte row of a W plane tile
-  long w_off[WIT];
-  bool w_ok[WIT];
-  int w_row[WIT], w_plane[WIT];
-#pragma unroll
-  for (int it = 0; it < WIT; ++it) {
-    const int idx = (tid >> 2) + (NTHR / 4) * it;   // (plane, row)
-    w_plane[it] = idx >= BN;
-    w_row[it] = idx - (w_plane[it] ? BN : 0);
-    w_ok[it] = idx < 2 * BN && (n0 + w_row[it] < p.N);
-    w_off[it] = w_ok[it] ? (long)(n0 + w_row[it]) * p.ldw : 0;
-  }
-
-  // two register sets: tile kb+2 is requested while tile kb is being multiplied, so a global load has two
-  // k-steps (~2 x 60 MFMAs per wave) to land before it is split into LDS
-  float4 ra0[4], ra1[4];
-  u32x4 rw0[WIT], rw1[WIT];
-  auto g_load = [&](float4 (&ra)[4], u32x4 (&rw)[WIT], int k0) {
-    if (p.ablate & 1) return;
-    const int k = k0 + 4 * akq;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_ok[it]) {
-        const float* src = p.A + a_off[it] + k;
-        if (A_VEC) {
-          if (k < p.K) v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (k + 0 < p.K) v.x = src[0];
-          if (k + 1 < p.K) v.y = src[1];
-          if (k + 2 < p.K) v.z = src[2];
-          if (k + 3 < p.K) v.w = src[3];
-        }
-      }
-      ra[it] = v;
-    }
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-      u32x4 u = {0u, 0u, 0u, 0u};
-      if (w_ok[it] && k0 + 8 * wc < p.ldw)
-        u = *reinterpret_cast<const u32x4*>((w_plane[it] ? p.Wlo : p.Whi) + w_off[it] + k0 + 8 * wc);
-      rw[it] = u;
-    }
-  };
-  auto s_store = [&](const float4 (&ra)[4], const u32x4 (&rw)[WIT]) {
-    if (p.ablate & 2) return;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = (tid >> 3) + (NTHR / 8) * it;
-      unsigned short h0, l0, h1, l1, h2, l2, h3, l3;
-      split_bf16(ra[it].x, h0, l0);
-      split_bf16(ra[it].y, h1, l1);
-      split_bf16(ra[it].z, h2, l2);
-      split_bf16(ra[it].w, h3, l3);
-      *reinterpret_cast<uint2*>(Ahi + row * LD + 4 * akq) = make_uint2(pack2(h0, h1), pack2(h2, h3));
-      *reinterpret_cast<uint2*>(Alo + row * LD + 4 * akq) = make_uint2(pack2(l0, l1), pack2(l2, l3));
-    }
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-      const int idx = (tid >> 2) + (NTHR / 4) * it;
-      if (idx < 2 * BN)
-        *reinterpret_cast<u32x4*>((w_plane[it] ? Blo : Bhi) + w_row[it] * LD + 8 * wc) = rw[it];
-    }
-  };
-
-  f32x4 acc[4][5];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nkb = (p.K + BK - 1) / BK;
-  const int fi = lane & 15, fg = lane >> 4;
-  auto compute = [&]() {
-    s16x8 ah[4], al[4];
-    const int fsel = (p.ablate & 8) ? 0 : 1;     // profiling: all fragments from one LDS address
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int off = fsel * ((wm * 64 + mt * 16 + fi) * LD + 8 * fg);
-      ah[mt] = *reinterpret_cast<const s16x8*>(Ahi + off);
-      al[mt] = *reinterpret_cast<const s16x8*>(Alo + off);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      const int off = fsel * ((wn * 80 + nt * 16 + fi) * LD + 8 * fg);
-      const s16x8 bh = *reinterpret_cast<const s16x8*>(Bhi + off);
-      const s16x8 bl = *reinterpret_cast<const s16x8*>(Blo + off);
-      if (p.ablate & 4) {
-        acc[0][nt][0] += (float)(bh[0] + bl[0] + ah[0][0] + al[0][0]);   // keep the reads live
-        continue;
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        acc[mt][nt] = mfma_bf16(al[mt], bh, acc[mt][nt]);   // small terms first
-        acc[mt][nt] = mfma_bf16(ah[mt], bl, acc[mt][nt]);
-        acc[mt][nt] = mfma_bf16(ah[mt], bh, acc[mt][nt]);
-      }
-    }
-  };
-  g_load(ra0, rw0, 0);
-  if constexpr (WM == 4) {          // one fat workgroup per CU: prefetch two k-steps ahead
-    if (nkb > 1) g_load(ra1, rw1, BK);
-    for (int kb = 0; kb < nkb; kb += 2) {
-      s_store(ra0, rw0);
-      __syncthreads();
-      if (kb + 2 < nkb) g_load(ra0, rw0, (kb + 2) * BK);
-      compute();
-      __syncthreads();
-      if (kb + 1 < nkb) {
-        s_store(ra1, rw1);
-        __syncthreads();
-        if (kb + 3 < nkb) g_load(ra1, rw1, (kb + 3) * BK);
-        compute();
-        __syncthreads();
-      }
-    }
-  } else {                          // several workgroups per CU hide each other's latencies: one register set
-    for (int kb = 0; kb < nkb; ++kb) {
-      s_store(ra0, rw0);
-      __syncthreads();
-      if (kb + 1 < nkb) g_load(ra0, rw0, (kb + 1) * BK);
-      compute();
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue in four 64-row quarters (a full 256x160 fp32 tile would not fit in LDS next to nothing)
-  float* Cs = reinterpret_cast<float*>(smem_raw);
-  if (tid < BM) {
-    const int m = m0 + tid;
-    c_rowoff[tid] = (m < p.M) ? (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1 : -1;
-  }
-  for (int q = 0; q < WM; ++q) {
-    __syncthreads();
-    if (wm == q) {
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt) {
-        const int col = wn * 80 + nt * 16 + fi;
-        const float bv1 = (n0 + col < p.N) ? p.bias[n0 + col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(mt * 16 + 4 * fg + r) * CLD + col] = acc[mt][nt][r] + bv1;
-      }
-    }
-    __syncthreads();
-    if (MODE == ONSSEN_EPI_L2NORM) {
-      if (p.resid) {
-        for (int e = tid; e < QR * BN; e += NTHR) {
-          const int row = e / BN, col = e % BN;
-          const long off = c_rowoff[q * QR + row];
-          if (off >= 0 && n0 + col < p.N) Cs[row * CLD + col] += p.resid[off + n0 + col];
-        }
-        __syncthreads();
-      }
-      const int ng = BN / p.group, items = QR * ng, sub = tid & 3;
-      for (int it = tid >> 2; it < items; it += NTHR / 4) {
-        float* v = Cs + (it / ng) * CLD + (it % ng) * p.group;
-        float s = 0.0f;
-        for (int d = sub; d < p.group; d += 4) s += v[d] * v[d];
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        const float den = fmaxf(sqrtf(s), p.eps);
-        for (int d = sub; d < p.group; d += 4) v[d] = v[d] / den;
-      }
-      __syncthreads();
-    }
-    if (p.c_vec) {   // rows 16-byte aligned and N % 4 == 0: 16-byte stores, a quarter of the store instructions
-      for (int e = tid; e < QR * (BN / 4); e += NTHR) {
-        const int row = e / (BN / 4), col = 4 * (e % (BN / 4));
-        const long off = c_rowoff[q * QR + row];
-        if (off >= 0 && n0 + col < p.N) {
-          float4 v = *reinterpret_cast<const float4*>(Cs + row * CLD + col);
-          if (MODE == ONSSEN_EPI_SIGMOID) {
-            v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
-            v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
-          }
-          *reinterpret_cast<float4*>(p.C + off + n0 + col) = v;
-        }
-      }
-    } else {
-      for (int e = tid; e < QR * BN; e += NTHR) {
-        const int row = e / BN, col = e % BN;
-        const long off = c_rowoff[q * QR + row];
-        if (off >= 0 && n0 + col < p.N) {
-          float v = Cs[row * CLD + col];
-          if (MODE == ONSSEN_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-          p.C[off + n0 + col] = v;
-        }
-      }
-    }
-  }
-}
-
-// fp32 [N][ld_in] (K valid columns) -> split-bf16 planes [N][ld_out] hi, [N][ld_out] lo (zero beyond K)
-__global__ void pack_w_bf16x3_kernel(const float* __restrict__ w, int N, int K, int ld_in, int ld_out,
-                                     unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
-  const long total = (long)N * ld_out;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(e / ld_out), k = (int)(e % ld_out);
-    unsigned short h, l;
-    split_bf16(k < K ? w[(long)n * ld_in + k] : 0.0f, h, l);
-    hi[e] = h;
-    lo[e] = l;
-  }
-}
-
-
-// =================================================================================================
-// K3/K7/K8, split-bf16 form over PRE-SPLIT operands ("x3 images").
-//
-// x3 image of a row-major [rows][K] fp32 matrix:  [rows][KB][2][32] bf16, KB = ceil(K/32): for every row and
-// 32-wide k block, 64 bytes of hi = bf16(x) followed by 64 bytes of lo = bf16(x - hi) (zeros beyond K).  One
-// 128-byte cache line per (row, k-step), for the activations (written in this form by the recurrence epilogue
-// or by x3_image_kernel) and for the weights (packed once).
-//
-// 256x160 tile, 256 threads = 4 waves (2 along M x 2 along N), 128x80 per wave = 8x5 MFMA tiles, 120 MFMAs per
-// wave and 32-wide k-step.  Staging is a plain copy (16-byte buffer loads with out-of-range -> 0, no VALU), LDS
-// is double-buffered so a k-step costs ONE barrier, and the next tile's LDS writes / the one after's global
-// loads are spread between the MFMAs of the current one.  The MFMA operands are swapped (A operand = W rows,
-// B operand = activation rows) so that a lane ends up with 4 CONSECUTIVE output features of one row: the
-// epilogue (bias, sigmoid, grouped L2 normalisation) runs in registers and stores 16 bytes per lane.
-// =================================================================================================
-namespace lxp {
-constexpr int BM = 256, BN = 160;
-constexpr int RS = 144;                      // LDS row stride in bytes: 128 + 16 pad (conflict-free 16-byte fragment reads)
-constexpr int STAGE = (BM + BN) * RS;        // 59,904 B per stage, two stages
-}  // namespace lxp
-
-struct LinearXpArgs {
-  const unsigned short* A;      // x3 image [M][KB][2][32]
-  const unsigned short* W;      // x3 image [N][KB][2][32]
-  const float* bias;
-  float* C;
-  long c_s0, c_s1;
-  int R, M, N, KB, group;
-  float eps;
-  int tile_group;
-  int c_vec;                    // C rows 16-byte aligned and N % 4 == 0
-};
-
-// profiling builds only (-DONSSEN_XP_ABLATE=bits; compile time, a run-time test per load would wreck the
-// schedule being measured): 1 no global loads, 2 no LDS stores, 4 no MFMA, 8 no fragment reads, 16 no C stores
-#ifndef ONSSEN_XP_ABLATE
-#define ONSSEN_XP_ABLATE 0
-#endif
-
-// WMS = waves along M (2 waves along N always): 2 -> 4 waves x (128x80), one per SIMD; 4 -> 8 waves x (64x80), two
-// per SIMD (denser MFMA issue and the hardware overlaps one wave's waits with the other's MFMAs, for 38 % more
-// fragment reads)
-template <int MODE, int WMS>
-__global__ __launch_bounds__(128 * WMS) void linear_x3p_kernel(LinearXpArgs p) {
-  using namespace lxp;
-  constexpr int NTHR = 128 * WMS, MT = 16 / WMS, WROWS = BM / WMS;
-  constexpr int RSTEP = NTHR / 8;                                   // rows staged per pass of the workgroup
-  constexpr int A_IT = BM / RSTEP, W_IT = (BN + RSTEP - 1) / RSTEP;   // 16-byte chunks per thread per k-step
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fi = lane & 15, fg = lane >> 4;
-  // XCD-aware tile order (as linear_x3_kernel): each XCD walks a contiguous run of tiles, in column groups of GN
-  int n0, m0;
-  {
-    const int nbx = gridDim.x, nwg = nbx * gridDim.y, bid = blockIdx.y * nbx + blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GN = p.tile_group, nby = gridDim.y;
-    const int gfull = nbx / GN, nfull = gfull * GN * nby;
-    int tn, tm;
-    if (wg < nfull) {
-      const int rem = wg % (nby * GN);
-      tn = (wg / (nby * GN)) * GN + rem % GN;
-      tm = rem / GN;
-    } else {
-      const int gl = nbx - gfull * GN, rem = wg - nfull;
-      tn = gfull * GN + rem % gl;
-      tm = rem / gl;
-    }
-    n0 = tn * BN;
-    m0 = tm * BM;
-  }
-  const int pitch = p.KB * 128;                // bytes per image row
-  const int a_rows = p.M - m0 < BM ? p.M - m0 : BM, w_rows = p.N - n0 < BN ? p.N - n0 : BN;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.A + (long)m0 * p.KB * 64), 0, a_rows * pitch, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.W + (long)n0 * p.KB * 64), 0, w_rows * pitch, 0x00020000);
-  // staging: thread -> (row = tid/8 + RSTEP*it, 16-byte chunk tid%8); rows past the matrix are out of range -> 0
-  const int srow = tid >> 3, sch = tid & 7;
-  const unsigned g_voff = (unsigned)(srow * pitch + sch * 16);
-  const unsigned l_off = (unsigned)(srow * RS + sch * 16);
-  // two staging register sets: set (t & 1) carries tile t from its global load, issued THREE k-steps before the
-  // tile is multiplied (L2 -> CU round trips under this load are longer than one k-step), to its LDS write one
-  // k-step before
-  constexpr int NJ = A_IT + W_IT;
-  u32x4 rg[2][NJ];
-  auto g_load1 = [&](auto set_c, int j, int kb) {
-    constexpr int S = decltype(set_c)::value;
-    if constexpr ((ONSSEN_XP_ABLATE & 1) != 0) return;
-    // the k offset rides in the (range-checked) vector offset and k blocks past the matrix are sent out of range:
-    // they read zeros, never memory -- so the loop needs no "is there a next tile" predicate, its body exists
-    // exactly once per parity, and an odd number of k-steps is rounded up with a tile of zeros
-    const unsigned koff = kb < p.KB ? (unsigned)(kb * 128) : 0x40000000u;
-    if (j < A_IT) rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, g_voff + (unsigned)(j * RSTEP * pitch) + koff, 0, 0);
-    else rg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, g_voff + (unsigned)((j - A_IT) * RSTEP * pitch) + koff, 0, 0);
-  };
-  auto s_store1 = [&](auto set_c, int j, int stage) {
-    constexpr int S = decltype(set_c)::value;
-    if constexpr ((ONSSEN_XP_ABLATE & 2) != 0) return;
-    unsigned char* base = smem + stage * STAGE + (j < A_IT ? j * RSTEP * RS : BM * RS + (j - A_IT) * RSTEP * RS);
-    if (j < A_IT || (j - A_IT) * RSTEP + RSTEP <= BN || srow + (j - A_IT) * RSTEP < BN)   // last W pass may be partial
-      *reinterpret_cast<u32x4*>(base + l_off) = rg[S][j];
-  };
-
-  f32x4 acc[MT][5];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#ifdef ONSSEN_XP_CLOCK
-  const long long clk0 = clock64(), wclk0 = wall_clock64();
-#endif
-  const int nkb = p.KB;
-  const unsigned fa_off = (unsigned)((wm * WROWS + fi) * RS + fg * 16);             // + mt*16*RS (+64 for lo)
-  const unsigned fw_off = (unsigned)(BM * RS + (wn * 80 + fi) * RS + fg * 16);    // + nt*16*RS (+64 for lo)
-  constexpr bool FR = (ONSSEN_XP_ABLATE & 8) == 0;
-  auto frag = [&](const unsigned char* sb, unsigned off) {
-    if constexpr (FR) return *reinterpret_cast<const s16x8*>(sb + off);
-    else return s16x8{(short)off, 1, 2, 3, 4, 5, 6, 7};
-  };
-  using c0 = std::integral_constant<int, 0>;
-  using c1 = std::integral_constant<int, 1>;
-
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) g_load1(c0{}, j, 0);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) s_store1(c0{}, j, 0);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) g_load1(c1{}, j, 1);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) g_load1(c0{}, j, 2);
-  __syncthreads();
-
-  // k-step kb of parity E (tile kb sits in LDS stage E): tile kb+1 goes from staging set E^1 into stage E^1 and
-  // tile kb+3 is requested into the same set, spread between the five column tiles' MFMAs.  One barrier.
-  auto kstep = [&](int kb, auto e_c) {
-    constexpr int E = decltype(e_c)::value;
-    using eo = std::integral_constant<int, E ^ 1>;
-    const unsigned char* sb = smem + E * STAGE;
-    s16x8 xh[MT], xl[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      xh[mt] = frag(sb, fa_off + mt * 16 * RS);
-      xl[mt] = frag(sb, fa_off + mt * 16 * RS + 64);
-    }
-    s16x8 wh = frag(sb, fw_off), wl = frag(sb, fw_off + 64);
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      s16x8 wh2 = wh, wl2 = wl;
-      if (nt + 1 < 5) {   // next column tile's fragments land behind this one's 24 MFMAs
-        wh2 = frag(sb, fw_off + (nt + 1) * 16 * RS);
-        wl2 = frag(sb, fw_off + (nt + 1) * 16 * RS + 64);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (j >= nt * NJ / 5 && j < (nt + 1) * NJ / 5) {
-          s_store1(eo{}, j, E ^ 1);
-          g_load1(eo{}, j, kb + 3);
-        }
-      }
-      if constexpr ((ONSSEN_XP_ABLATE & 4) != 0) {
-        acc[0][nt][0] += (float)(wh[0] + wl[0] + xh[nt % MT][0] + xl[nt % MT][0] + xh[(nt + 3) % MT][0] + xl[(nt + 3) % MT][0]);
-      } else {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt][nt] = mfma_bf16(wh, xl[mt], acc[mt][nt]);   // small terms first
-          acc[mt][nt] = mfma_bf16(wl, xh[mt], acc[mt][nt]);
-          acc[mt][nt] = mfma_bf16(wh, xh[mt], acc[mt][nt]);
-        }
-      }
-      wh = wh2;
-      wl = wl2;
-    }
-    __syncthreads();
-  };
-  for (int kb = 0; kb < nkb; kb += 2) {
-    kstep(kb, c0{});
-    kstep(kb + 1, c1{});
-  }
-
-#ifdef ONSSEN_XP_CLOCK   // profiling builds: shader clocks and 100 MHz ticks of the main loop of workgroup 0 -> C[0], C[1]
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-    p.C[0] = (float)(clock64() - clk0);
-    p.C[1] = (float)(wall_clock64() - wclk0);
-    return;
-  }
-#endif
-  // ---- epilogue in registers: lane holds, per (mt, nt), features n = n0 + wn*80 + nt*16 + 4*fg + {0..3} of row
-  //      m = m0 + wm*WROWS + mt*16 + fi
-  float4 bv[5];
-#pragma unroll
-  for (int nt = 0; nt < 5; ++nt) {
-    const int n = n0 + wn * 80 + nt * 16 + 4 * fg;
-    bv[nt].x = n + 0 < p.N ? p.bias[n + 0] : 0.f;
-    bv[nt].y = n + 1 < p.N ? p.bias[n + 1] : 0.f;
-    bv[nt].z = n + 2 < p.N ? p.bias[n + 2] : 0.f;
-    bv[nt].w = n + 3 < p.N ? p.bias[n + 3] : 0.f;
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + wm * WROWS + mt * 16 + fi;
-    float4 v[5];
-#pragma unroll
-    for (int nt = 0; nt < 5; ++nt)
-      v[nt] = make_float4(acc[mt][nt][0] + bv[nt].x, acc[mt][nt][1] + bv[nt].y, acc[mt][nt][2] + bv[nt].z,
-                          acc[mt][nt][3] + bv[nt].w);
-    if (MODE == ONSSEN_EPI_L2NORM) {
-      // groups of p.group consecutive features (group % 4 == 0, 80 % group == 0, at most 4 groups per wave):
-      // a lane's float4 never straddles a group; partial sums per group, then across the 4 lane groups
-      float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt) {
-        const int q = (nt * 16 + 4 * fg) / p.group;
-        const float s4 = v[nt].x * v[nt].x + v[nt].y * v[nt].y + v[nt].z * v[nt].z + v[nt].w * v[nt].w;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) part[qq] += (q == qq) ? s4 : 0.f;
-      }
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        part[qq] += __shfl_xor(part[qq], 16);
-        part[qq] += __shfl_xor(part[qq], 32);
-        part[qq] = 1.0f / fmaxf(sqrtf(part[qq]), p.eps);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt) {
-        const int q = (nt * 16 + 4 * fg) / p.group;
-        const float sc = q == 0 ? part[0] : q == 1 ? part[1] : q == 2 ? part[2] : part[3];
-        // x / max(||x||, eps) like F.normalize: multiply by the reciprocal of the clamped norm
-        v[nt].x *= sc; v[nt].y *= sc; v[nt].z *= sc; v[nt].w *= sc;
-      }
-    } else if (MODE == ONSSEN_EPI_SIGMOID) {
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt) {
-        v[nt].x = 1.0f / (1.0f + expf(-v[nt].x)); v[nt].y = 1.0f / (1.0f + expf(-v[nt].y));
-        v[nt].z = 1.0f / (1.0f + expf(-v[nt].z)); v[nt].w = 1.0f / (1.0f + expf(-v[nt].w));
-      }
-    }
-    if (m < p.M && ((ONSSEN_XP_ABLATE & 16) == 0 || v[0].x == 123.456f)) {
-      float* crow = p.C + (long)(m / p.R) * p.c_s0 + (long)(m % p.R) * p.c_s1;
-#pragma unroll
-      for (int nt = 0; nt < 5; ++nt) {
-        const int n = n0 + wn * 80 + nt * 16 + 4 * fg;
-        if (p.c_vec) {
-          if (n < p.N) *reinterpret_cast<float4*>(crow + n) = v[nt];
-        } else {
-          if (n + 0 < p.N) crow[n + 0] = v[nt].x;
-          if (n + 1 < p.N) crow[n + 1] = v[nt].y;
-          if (n + 2 < p.N) crow[n + 2] = v[nt].z;
-          if (n + 3 < p.N) crow[n + 3] = v[nt].w;
-        }
-      }
-    }
-  }
-}
-
-// fp32 rows (row m at src + (m / R)*s0 + (m % R)*s1, K contiguous) -> x3 image [rows][KB][2][32]
-__global__ void x3_image_kernel(const float* __restrict__ src, long s0, long s1, int R, int rows, int K, int KB,
-                                unsigned short* __restrict__ img) {
-  const long total = (long)rows * KB * 32;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int kk = (int)(e & 31);
-    const long rb = e >> 5;                       // row * KB + kblock
-    const int m = (int)(rb / KB), k = (int)(rb % KB) * 32 + kk;
-    unsigned short h, l;
-    split_bf16(k < K ? src[(long)(m / R) * s0 + (long)(m % R) * s1 + k] : 0.0f, h, l);
-    img[rb * 64 + kk] = h;
-    img[rb * 64 + 32 + kk] = l;
-  }
-}
-
-// =================================================================================================
-// N3: training-label features from the three complex STFTs (mix, s1, s2) of a chunk
-// (onssen/data/feature_utils.py:77-95 get_cos_difference / get_one_hot, wsj0_2mix.py:130-152)
-// =================================================================================================
-__global__ void utt_max_kernel(const float* __restrict__ x, long per_utt, float* __restrict__ out) {
-  __shared__ float red[256];
-  const float* p = x + (long)blockIdx.x * per_utt;
-  float m = -INFINITY;
-  for (long i = threadIdx.x; i < per_utt; i += 256) m = fmaxf(m, p[i]);
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
-}
-
-__global__ void labels_kernel(const float* __restrict__ mix, const float* __restrict__ s1, const float* __restrict__ s2,
-                              const float* __restrict__ feat, const float* __restrict__ fmax, long per_utt, long total,
-                              float db_threshold, float* __restrict__ one_hot, float* __restrict__ mag_mix,
-                              float* __restrict__ mag_s1, float* __restrict__ mag_s2, float* __restrict__ cos_s1,
-                              float* __restrict__ cos_s2) {
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const float xr = mix[2 * e], xi = mix[2 * e + 1];
-    const float ar = s1[2 * e], ai = s1[2 * e + 1], br = s2[2 * e], bi = s2[2 * e + 1];
-    const float m1 = hypotf(ar, ai), m2 = hypotf(br, bi);
-    mag_mix[e] = hypotf(xr, xi);
-    mag_s1[e] = m1;
-    mag_s2[e] = m2;
-    // np.argmax takes the first maximum: speaker 0 on ties; bins below max(feature) - dB/20 are silent (all-zero label)
-    const bool active = !(feat[e] < fmax[e / per_utt] - db_threshold / 20.0f);
-    const int who = (m2 > m1) ? 1 : 0;
-    one_hot[2 * e] = (active && who == 0) ? 1.0f : 0.0f;
-    one_hot[2 * e + 1] = (active && who == 1) ? 1.0f : 0.0f;
-    if (cos_s1) {
-      const float am = atan2f(xi, xr);
-      cos_s1[e] = cosf(am - atan2f(ai, ar));
-      cos_s2[e] = cosf(am - atan2f(bi, br));
-    }
-  }
-}
-
-
-// =================================================================================================
-// N2: deep-clustering back end on the device -- 2-means over the embeddings of the active TF bins
-// (egs/wsj0-2mix/deep_clustering/evaluate.py:36-41: threshold at max - 40/20, KMeans(n_clusters=2), binary masks)
-// Deterministic: farthest-point initialisation, fixed iteration count, per-block partial sums reduced in a
-// fixed order (no float atomics).  Workspace per utterance: [0] feature max, [1..2D] centroids,
-// then NBLK x 2 x (D+1) partial sums.
-// =================================================================================================
-namespace km {
-constexpr int NBLK = 64, DMAX = 32;
-}
-
-// one workgroup per utterance: c0 = embedding of the loudest active bin, c1 = active embedding farthest from c0
-__global__ void kmeans2_init_kernel(const float* __restrict__ emb, const float* __restrict__ feat, long per_utt, int D,
-                                    float db, float* __restrict__ ws, long ws_stride) {
-  __shared__ float rv[256];
-  __shared__ long ri[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* f = feat + (long)b * per_utt;
-  const float* e = emb + (long)b * per_utt * D;
-  float* w = ws + (long)b * ws_stride;
-  float best = -INFINITY;
-  long bi = 0;
-  for (long i = tid; i < per_utt; i += 256)
-    if (f[i] > best) { best = f[i]; bi = i; }
-  rv[tid] = best; ri[tid] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s && (rv[tid + s] > rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid]))) {
-      rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s];
-    }
-    __syncthreads();
-  }
-  const float fmax = rv[0];
-  const long i0 = ri[0];
-  __syncthreads();
-  const float thr = fmax - db / 20.0f;
-  float worst = INFINITY;
-  long wi = i0;
-  for (long i = tid; i < per_utt; i += 256) {
-    if (f[i] >= thr) {
-      float dot = 0.0f;
-      for (int d = 0; d < D; ++d) dot += e[i * D + d] * e[i0 * D + d];
-      if (dot < worst) { worst = dot; wi = i; }
-    }
-  }
-  rv[tid] = worst; ri[tid] = wi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s && (rv[tid + s] < rv[tid] || (rv[tid + s] == rv[tid] && ri[tid + s] < ri[tid]))) {
-      rv[tid] = rv[tid + s]; ri[tid] = ri[tid + s];
-    }
-    __syncthreads();
-  }
-  const long i1 = ri[0];
-  if (tid == 0) w[0] = fmax;
-  for (int d = tid; d < D; d += 256) {
-    w[1 + d] = e[i0 * D + d];
-    w[1 + D + d] = e[i1 * D + d];
-  }
-}
-
-// assignment + per-block partial sums (MODE 0), or assignment + mask write (MODE 1)
-template <int MODE>
-__global__ void kmeans2_assign_kernel(const float* __restrict__ emb, const float* __restrict__ feat, long per_utt, int D,
-                                      float db, float* __restrict__ ws, long ws_stride, float* __restrict__ masks) {
-  using namespace km;
-  __shared__ float part[MODE == 0 ? 2 * (DMAX + 1) * 256 : 1];
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const float* f = feat + (long)b * per_utt;
-  const float* e = emb + (long)b * per_utt * D;
-  float* w = ws + (long)b * ws_stride;
-  const float thr = w[0] - db / 20.0f;
-  float c0[DMAX], c1[DMAX], s0[DMAX], s1[DMAX];
-  float n0 = 0.f, n1 = 0.f, q0 = 0.f, q1 = 0.f;
-  for (int d = 0; d < D; ++d) {
-    c0[d] = w[1 + d]; c1[d] = w[1 + D + d];
-    q0 += c0[d] * c0[d]; q1 += c1[d] * c1[d];
-    s0[d] = 0.f; s1[d] = 0.f;
-  }
-  for (long i = (long)blockIdx.x * 256 + tid; i < per_utt; i += (long)gridDim.x * 256) {
-    const bool active = f[i] >= thr;
-    float d0 = q0, d1 = q1;               // ||e - c||^2 = ||e||^2 - 2 e.c + ||c||^2 ; ||e||^2 is common
-    if (active)
-      for (int d = 0; d < D; ++d) { const float v = e[i * D + d]; d0 -= 2.f * v * c0[d]; d1 -= 2.f * v * c1[d]; }
-    const int lab = (d1 < d0) ? 1 : 0;
-    if (MODE == 1) {
-      masks[2 * ((long)b * per_utt + i)] = active ? (float)lab : 0.0f;          // mask[0] = label
-      masks[2 * ((long)b * per_utt + i) + 1] = active ? (float)(1 - lab) : 0.0f;  // mask[1] = 1 - label
-    } else if (active) {
-      if (lab) { n1 += 1.f; for (int d = 0; d < D; ++d) s1[d] += e[i * D + d]; }
-      else     { n0 += 1.f; for (int d = 0; d < D; ++d) s0[d] += e[i * D + d]; }
-    }
-  }
-  if (MODE == 0) {
-    // all 2(D+1) accumulators go to LDS at once; thread k then adds up column k (one barrier in total)
-    float* out = w + 1 + 2 * D + (long)blockIdx.x * 2 * (D + 1);
-    const int na = 2 * (D + 1);
-    for (int k = 0; k < na; ++k) {
-      const int c = k / (D + 1), d = k % (D + 1);
-      part[k * 256 + tid] = d == D ? (c ? n1 : n0) : (c ? s1[d] : s0[d]);
-    }
-    __syncthreads();
-    if (tid < na) {
-      float acc = 0.f;
-      for (int j = 0; j < 256; ++j) acc += part[tid * 256 + j];
-      out[tid] = acc;
-    }
-  }
-}
-
-__global__ void kmeans2_update_kernel(int D, int nblk, float* __restrict__ ws, long ws_stride) {
-  float* w = ws + (long)blockIdx.x * ws_stride;
-  const int k = threadIdx.x;                 // 2*D threads: (cluster, dim)
-  if (k < 2 * D) {
-    const int c = k / D, d = k % D;
-    float s = 0.f, n = 0.f;
-    for (int j = 0; j < nblk; ++j) {
-      const float* pj = w + 1 + 2 * D + (long)j * 2 * (D + 1) + c * (D + 1);
-      s += pj[d];
-      n += pj[D];
-    }
-    if (n > 0.f) w[1 + c * D + d] = s / n;   // an empty cluster keeps its centroid
-  }
-}
-
-// =================================================================================================
-// K4: one LSTM time step, both directions
-// =================================================================================================
-struct StepArgs {
-  const float* G;    // [T][B][2][NP]   input projection + biases, gate-permuted columns
-  const float* whh;  // [2][NU][KQ][NT][64][4]
-  float* y;          // [T][B][2][Hp]   layer output (h_t)
-  float* c;          // [2][B][Hp]      cell state
-  const unsigned short* whh_x3;  // split-bf16 image [2][NU][KQ2][NT][2][64][8]          (X3 kernels)
-  unsigned short* hs;            // split h hand-off in A-fragment order:
-                                 //   [2 slots][2 dirs][ceil(B/16)][KQ2][hi|lo][64 lanes][8] bf16   (X3 kernels)
-  int KQ2, Hs;                   // 32-wide k-chunks, padded row length Hs = 32*KQ2
-  int B, T, Hp, NP, KQ, NU, step;
-  long long* dbg;  // profiling only: per-step timestamps of workgroup (0,0,0), or null
-  int ablate;  // profiling only (flags >> 8): 1 = no h loads, 2 = no W loads, 4 = no MFMA, 8 = no G / c loads
-};
-
-namespace rec {
-constexpr int RLD = 72;  // LDS row stride of the per-wave partial accumulators (64 lanes + pad)
-constexpr int QB = 10;   // k-chunks (16 k each) a wave keeps in flight: 4 waves x 10 x 16 = 640 >= H
-constexpr int QB3 = 5;   // same for the split-bf16 form (32 k per chunk)
-}
-
-// Gate non-linearities on the hardware transcendental units: sigmoid(x) = rcp(1 + exp2(-x log2 e)),
-// tanh(x) = 2 sigmoid(2x) - 1.  v_exp_f32 / v_rcp_f32 are ~1 ulp, so the absolute error is ~1e-7 --
-// far inside the 1e-5 parity budget -- while libm-grade expf/tanhf/IEEE divides made this epilogue
-// (one wave per SIMD, nothing to hide latency behind) a measurable slice of every time step.
-__device__ __forceinline__ float gate_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float gate_tanh(float x) { return 2.0f * gate_sigmoid(2.0f * x) - 1.0f; }
-
-// Arguments are 14 scalar dwords in order of first use so that, with -amdgpu-kernarg-preload-count, the
-// command processor delivers them in SGPRs at dispatch.  Every launch starts with cold scalar/L2 caches, so
-// each *dependent* s_load of a kernel argument is a ~1 us round trip to memory on the critical path of a
-// time step; the struct-by-value form paid three of them.  Everything else is derived from these.
-template <int MT, int NT, bool X3, bool DBG>
-__global__ __launch_bounds__(256) void lstm_step_kernel(const void* w, char* ws, float* y, int step, int B, int NU,
-                                                        int T, unsigned g_off256, unsigned c_off256,
-                                                        unsigned hs_off256, int ablate_arg, long long* dbg_arg) {
-  using namespace rec;
-  constexpr int UG = 4 * NT;          // hidden units per workgroup
-  StepArgs p;
-  p.G = reinterpret_cast<const float*>(ws + (size_t)g_off256 * 256);
-  p.c = reinterpret_cast<float*>(ws + (size_t)c_off256 * 256);
-  p.hs = reinterpret_cast<unsigned short*>(ws + (size_t)hs_off256 * 256);
-  p.whh = static_cast<const float*>(w);
-  p.whh_x3 = static_cast<const unsigned short*>(w);
-  p.y = y; p.step = step; p.B = B; p.NU = NU; p.T = T;
-  p.Hp = NU * UG; p.NP = 4 * p.Hp; p.KQ = (p.Hp + 15) / 16; p.KQ2 = (p.Hp + 31) / 32; p.Hs = 32 * p.KQ2;
-  p.ablate = DBG ? ablate_arg : 0;
-  p.dbg = DBG ? dbg_arg : nullptr;
-  constexpr int NE = 16 * MT * UG;    // (batch row, unit) elements per workgroup
-  constexpr int EPT = (NE + 255) / 256;
-  __shared__ float red[4 * MT * NT * 4 * RLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ugi = blockIdx.x, dir = blockIdx.y, b0 = blockIdx.z * 16 * MT;
-  const int t = dir == 0 ? p.step : p.T - 1 - p.step;
-  const int tprev = dir == 0 ? t - 1 : t + 1;
-  const bool first = p.step == 0;
-  const bool stamp = p.dbg && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-  if (stamp) { p.dbg[p.step * 8 + 0] = wall_clock64(); p.dbg[p.step * 8 + 1] = clock64(); }
-
-  // ---- the epilogue's global reads (input projection, cell state) are independent of the recurrent
-  // product: they are issued right after the operand fetches so that their latency hides behind the MFMAs
-  float gpre[EPT][4], cold[EPT];
-  auto load_epilogue_inputs = [&]() {
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e / UG, ju = e % UG, b = b0 + row;
-      const bool ok = (e < NE) && (b < p.B) && !(p.ablate & 8);
-      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + ((long)(t * p.B + b) * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-      gpre[i][0] = g4.x; gpre[i][1] = g4.y; gpre[i][2] = g4.z; gpre[i][3] = g4.w;
-      cold[i] = (ok && !first) ? p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] : 0.0f;
-    }
-  };
-  if (first) load_epilogue_inputs();
-
-  if (!first) {
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int fi = lane & 15, fg = lane >> 4;
-    // All operand fetches are raw buffer loads: one SGPR descriptor per operand, ONE per-lane byte offset,
-    // compile-time deltas per fragment.  Out-of-range offsets return zeros, so rows past B and chunks past
-    // the end of K need neither a branch nor address arithmetic per load -- with a single wave per SIMD the
-    // issue cost of ~40 loads was a visible slice of every time step.  (The range check covers the per-lane
-    // offset and the immediate, not the scalar offset, so everything goes into the former.)
-    constexpr unsigned kOOB = 0x7ffffff0u;
-    if constexpr (X3) {
-      // split-bf16 form: A = (h_hi, h_lo) written by the previous step's epilogue, B = (W_hi, W_lo)
-      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.whh_x3 + (long)(dir * p.NU + ugi) * p.KQ2 * NT * 1024), 0, p.KQ2 * NT * 2048, 0x00020000);
-      // the hand-off image is stored in A-fragment order, so each of these loads is one contiguous KiB per wave
-      // (a row-major image costs 16 half-used cache lines per load and was the slowest fetch of the step)
-      const int nmt = (p.B + 15) >> 4;
-      const long hdir = (long)nmt * p.KQ2 * 1024;                     // uint16 elements per (slot, direction)
-      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.hs + ((long)((p.step - 1) & 1) * 2 + dir) * hdir), 0, (int)(hdir * 2), 0x00020000);
-      const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 2048 + lane * 16);
-      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 >> 4) * p.KQ2 + wave) * 2048) + lane * 16);
-      const unsigned h_mt = p.KQ2 * 2048, h_hl = 1024;
-      for (int qb = 0; qb < p.KQ2; qb += 4 * QB3) {
-        u32x4 a[QB3][MT][2], w[QB3][NT][2];
-#pragma unroll
-        for (int i = 0; i < QB3; ++i) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-              a[i][mt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + hl * h_hl + (qb + 4 * i) * 2048, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl)
-              w[i][nt][hl] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + (nt * 2 + hl) * 1024 + (qb + 4 * i) * NT * 2048, 0, 0);
-        }
-        if (qb == 0) load_epilogue_inputs();
-        if (stamp) p.dbg[p.step * 8 + 2] = clock64();
-#pragma unroll
-        for (int i = 0; i < QB3; ++i) {
-          if (qb + wave + 4 * i < p.KQ2 && !(p.ablate & 4)) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                const s16x8 ah = __builtin_bit_cast(s16x8, a[i][mt][0]), al = __builtin_bit_cast(s16x8, a[i][mt][1]);
-                const s16x8 wh = __builtin_bit_cast(s16x8, w[i][nt][0]), wl = __builtin_bit_cast(s16x8, w[i][nt][1]);
-                acc[mt][nt] = mfma_bf16(al, wh, acc[mt][nt]);   // small terms first
-                acc[mt][nt] = mfma_bf16(ah, wl, acc[mt][nt]);
-                acc[mt][nt] = mfma_bf16(ah, wh, acc[mt][nt]);
-              }
-          }
-        }
-      }
-    } else {
-      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.whh + (long)(dir * p.NU + ugi) * p.KQ * NT * 256), 0, p.KQ * NT * 1024, 0x00020000);
-      // fp32 hand-off image in A-fragment order (same reason as the split-bf16 form): [slot][dir][m-tile][q][lane][4]
-      const int nmt = (p.B + 15) >> 4;
-      const long hdir = (long)nmt * p.KQ * 256;                       // floats per (slot, direction)
-      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(reinterpret_cast<float*>(p.hs) + ((long)((p.step - 1) & 1) * 2 + dir) * hdir), 0, (int)(hdir * 4),
-          0x00020000);
-      const unsigned wv = (p.ablate & 2) ? kOOB : (unsigned)(wave * NT * 1024 + lane * 16);
-      const unsigned hv = (p.ablate & 1) ? kOOB : (unsigned)((((b0 >> 4) * p.KQ + wave) * 1024) + lane * 16);
-      const unsigned h_mt = p.KQ * 1024;
-      for (int qb = 0; qb < p.KQ; qb += 4 * QB) {
-        u32x4 a[QB][MT], w[QB][NT];
-#pragma unroll
-        for (int i = 0; i < QB; ++i) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            a[i][mt] = __builtin_amdgcn_raw_buffer_load_b128(rh, hv + mt * h_mt + (qb + 4 * i) * 1024, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            w[i][nt] = __builtin_amdgcn_raw_buffer_load_b128(rw, wv + nt * 1024 + (qb + 4 * i) * NT * 1024, 0, 0);
-        }
-        if (qb == 0) load_epilogue_inputs();
-#pragma unroll
-        for (int i = 0; i < QB; ++i) {
-          if (qb + wave + 4 * i < p.KQ && !(p.ablate & 4)) {  // wave-uniform: skip chunks past the end of K
-            float4 af[MT], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = __builtin_bit_cast(float4, a[i][mt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = __builtin_bit_cast(float4, w[i][nt]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(af[mt], r), f4c(wf[nt], r), acc[mt][nt], 0, 0, 0);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * MT * NT + mt * NT + nt) * 4 + r) * RLD + lane] = acc[mt][nt][r];
-    if (stamp) p.dbg[p.step * 8 + 3] = clock64();
-    __syncthreads();
-    if (stamp) p.dbg[p.step * 8 + 4] = clock64();
-  }
-
-  // ---- fused cell update: one (batch row, hidden unit) per thread
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = tid + 256 * i;
-    const int row = e / UG, ju = e % UG, b = b0 + row;
-    if (e < NE && b < p.B) {
-      float pre[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float s = 0.0f;
-        if (!first) {
-          const int pl = g * UG + ju;
-          const int tile = (row >> 4) * NT + (pl >> 4);
-          const int src = (((row & 15) >> 2) << 4) + (pl & 15), r = row & 3;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) s += red[((w * MT * NT + tile) * 4 + r) * RLD + src];
-        }
-        pre[g] = s + gpre[i][g];
-      }
-      float ig, fg2, gg, og, cn, h;
-      if (p.ablate & 16) {   // profiling: libm-grade activations
-        ig = 1.0f / (1.0f + expf(-pre[0]));
-        fg2 = 1.0f / (1.0f + expf(-pre[1]));
-        gg = tanhf(pre[2]);
-        og = 1.0f / (1.0f + expf(-pre[3]));
-        cn = fg2 * cold[i] + ig * gg;
-        h = og * tanhf(cn);
-      } else {
-        ig = gate_sigmoid(pre[0]);
-        fg2 = gate_sigmoid(pre[1]);
-        gg = gate_tanh(pre[2]);
-        og = gate_sigmoid(pre[3]);
-        cn = fg2 * cold[i] + ig * gg;
-        h = og * gate_tanh(cn);
-      }
-      if constexpr (X3) {   // hand h_t to the next step already split (3 VALU ops here vs hundreds in the consumer)
-        unsigned short hi, lo;
-        split_bf16(h, hi, lo);
-        const int k = ugi * UG + ju, nmt = (p.B + 15) >> 4;
-        unsigned short* dst = p.hs + ((((long)(p.step & 1) * 2 + dir) * nmt + (b >> 4)) * p.KQ2 + (k >> 5)) * 1024 +
-                              ((b & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
-        dst[0] = hi;
-        dst[512] = lo;
-      } else {
-        const int k = ugi * UG + ju, nmt = (p.B + 15) >> 4;
-        reinterpret_cast<float*>(p.hs)[((((long)(p.step & 1) * 2 + dir) * nmt + (b >> 4)) * p.KQ + (k >> 4)) * 256 +
-                                       ((b & 15) + 16 * ((k >> 2) & 3)) * 4 + (k & 3)] = h;
-      }
-      p.c[((long)dir * p.B + b) * p.Hp + ugi * UG + ju] = cn;
-      p.y[((long)(t * p.B + b) * 2 + dir) * p.Hp + ugi * UG + ju] = h;
-    }
-  }
-  if (stamp) { p.dbg[p.step * 8 + 5] = clock64(); p.dbg[p.step * 8 + 6] = wall_clock64(); }
-}
-
-
-
-// -------------------------------------------------------------------------------------------------
-// K4, XCD-local persistent form (split-bf16 only): ONE launch runs all T steps of a layer.
-//
-// A (direction, 16-row batch group) recurrence is an exchange group of NU <= 32 workgroups, one hidden-unit
-// group each, and the launch places every member of a group on the SAME XCD (workgroup b is observed to run
-// on XCD b % 8, so group = b % 8, member = b / 8).  W_hh never leaves the register file, the cell state stays
-// in registers, and h_t moves between the members through that XCD's own L2: plain stores (write-through L1,
-// line kept in L2), s_waitcnt vmcnt(0), one flag word per member, consumers poll the 32 flags with ONE
-// L1-bypassing load and then fetch the fragment-ordered h image with L1-bypassing (sc1) loads.  No fabric
-// round trip, no kernel boundary: the step costs two L2 hops instead of ~1.6 us + a cold fetch.
-//
-// Correctness never rests on that placement.  At start-up every member publishes its HW_REG_XCC_ID with
-// agent-scope atomics; only if all ids of a group agree does the group use the L2-local protocol, otherwise
-// it runs the same loop with write-through (sc1) stores and system-scope (sc0 sc1) loads, which is valid for any
-// placement (and slower than one launch per step -- see DESIGN.md).  Every spin is bounded; a timeout raises
-// the abort word, all workgroups leave, and the status word tells the host.
-// -------------------------------------------------------------------------------------------------
-struct XcdArgs {
-  const float* G;               // [T][B][2][NP]
-  const unsigned short* whh;    // split-bf16 image [2][NU][KQ2][NT][2][64][8]
-  float* y;                     // [T][B][2][Hp]
-  unsigned short* hx;           // per group: [2 slots][KQ2][hi|lo][64][8]
-  unsigned* sync;               // u32 words: [256 + g] arrivals, [280] abort, u64 pairs at [320 + 4g]: max(xcc+1), max(16-xcc),
-                                // [281] status (1 = some group ran the placement-independent protocol), [288 + g]
-                                // launch generation; u64 flags at byte 2048 + ((g*32 + m)*NW + wave)*8 (up to 16 KiB).  The block is zeroed ONCE
-                                // by the workspace owner: everything in it is monotonic, so no launch depends on a
-                                // per-launch memset reaching this XCD's L2 (hipGraph replays showed that it may not)
-  int B, T, Hp, NP, KQ2, NU, row0, nbg;
-  const unsigned short* wih0;   // FUSE_IN0: B-fragment image of the layer's W_ih [2][NU][KC0][NT][hi|lo][64][8], else null
-  const unsigned short* ximg;   // FUSE_IN0: x3 image of the layer's input rows [T*B][KC0][2][32]
-  const float* bias0;           // FUSE_IN0: [2*NP] packed bias (G column order)
-  int KC0;                      // FUSE_IN0: ceil(in_dim / 32) <= 5, else 0
-  int KCM;                      // FUSE_IN0: chunks multiplied on the MFMA pipe: KC0, or KC0 - 1 when in_dim = 32*KCM + 1 (129, 257:
-                                // the lone last column is a rank-1 update on the VALU in the cell update instead)
-  const float* x0;              // FUSE_IN0 tail: fp32 input, element (b, t, k) at x0 + b*xs_b + t*xs_t + k
-  long xs_b, xs_t;
-  const float* wtail;           // FUSE_IN0 tail: column in_dim-1 of the packed W_ih, [2*NP] (G column order)
-  int RG;                       // batch rows per exchange group: 16, or 8 / 4 when the batch is small enough to give
-                                // every XCD a group anyway (the MFMA tile stays 16 rows; less h to move and to update)
-  unsigned spin_limit;
-  long long* dbg;               // profiling only: per-step timestamps of workgroup 0, or null
-  int ablate;                   // profiling only: 1 = no h loads, 2 = no G prefetch, 4 = no MFMA, 16 = no y / image stores; test only: 8 = rotate groups over XCDs
-  unsigned short* yimg;         // x3 image [T*B][KBI][2][32] of the layer output (the next GEMM's A operand), or null
-  int KBI;                      // ceil(2*Hp / 32)
-};
-
-// FUSE: the first layer's input projection is computed in here (ONSSEN_BLSTM_FUSE_IN0); a compile-time switch so that
-// the plain instantiation carries none of its registers
-template <int NT, int NW, bool FUSE>
-__global__ __launch_bounds__(64 * NW) void lstm_xcd_kernel(XcdArgs p) {
-  using namespace rec;
-  constexpr int UG = 4 * NT;
-  constexpr int NE = 16 * UG;
-  constexpr int NTHR = 64 * NW;                // NW = 4 or 8 waves: two waves per SIMD issue MFMAs ~1.4x denser than one
-  constexpr int EPT = (NE + NTHR - 1) / NTHR;
-  constexpr int CPW = 20 / NW + (20 % NW != 0);   // k-chunks (32 k) per wave: NW x CPW x 32 >= 640 >= H
-  constexpr unsigned kOOB = 0x7ffffff0u;
-  __shared__ float red[2 * NW * NT * 4 * RLD];   // two step parities
-  constexpr int KCMAX = 5;                       // fused layer-0 input projection: in_dim <= 160
-  __shared__ __attribute__((aligned(16))) unsigned short wih_s[FUSE ? KCMAX * NT * 1024 : 8];   // [chunk][nt][hi|lo][64][8]
-  __shared__ unsigned s_ctl[3];                // [0] abort, [1] fast, [2] launch generation
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // group = workgroup id mod 8 (the XCD the dispatcher is observed to use); test bit 8 rotates the groups across
-  // the XCDs instead, so that the placement-independent protocol runs with real cross-XCD traffic
-  const int ugi = blockIdx.x >> 3, g = (p.ablate & 8) ? ((blockIdx.x + ugi) & 7) : (blockIdx.x & 7);
-  if (p.dbg && tid == 0)                       // profiling only: where did the dispatcher put this workgroup?
-    p.dbg[4096 + blockIdx.x] = (long long)(__builtin_amdgcn_s_getreg(6164) & 15u) |
-                               ((long long)__builtin_amdgcn_s_getreg(63492) << 8);   // hwreg(HW_REG_HW_ID)
-  if (g >= 2 * p.nbg) return;                  // whole workgroup, before any barrier
-  const int dir = g / p.nbg, bg = g % p.nbg;
-  const int b0 = p.row0 + bg * p.RG;
-  unsigned long long* flags = reinterpret_cast<unsigned long long*>(p.sync + 512) + g * (32 * NW);   // [member][wave]
-  unsigned* abort_w = p.sync + 280;
-
-  // ---- placement check: do all members of this group sit on one XCD?
-  if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 15u;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    // launch generation: bumped by member 0 at the very end of every launch, read here by everyone
-    const unsigned gen0 = __hip_atomic_fetch_add(p.sync + 288 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_ctl[2] = gen0;
-    // max(xcc+1) and max(16-xcc) of THIS launch: tagged with the generation, so older launches (the dispatcher
-    // may start a launch on another XCD) never win the max
-    unsigned long long* xw = reinterpret_cast<unsigned long long*>(p.sync + 320) + 2 * g;
-    __hip_atomic_fetch_max(xw, ((unsigned long long)gen0 << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_max(xw + 1, ((unsigned long long)gen0 << 8) | (16u - xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(p.sync + 256 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0, ab = 0;
-    // the arrival counter is never reset: NU arrivals per launch, so launch `gen0` ends at (gen0+1)*NU
-    while (__hip_atomic_fetch_add(p.sync + 256 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen0 * (unsigned)p.NU <
-           (unsigned)p.NU) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-    }
-    const unsigned hi = (unsigned)__hip_atomic_fetch_add(xw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 255u;
-    const unsigned lo = (unsigned)__hip_atomic_fetch_add(xw + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 255u;
-    s_ctl[0] = ab;
-    s_ctl[1] = (hi + lo == 17u) ? 1u : 0u;     // max(xcc)+1 + 16-min(xcc) == 17  <=>  max == min
-    if (ab) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!ab && s_ctl[1] == 0u) __hip_atomic_store(p.sync + 281, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (s_ctl[0]) return;
-  const bool fast = s_ctl[1] != 0;
-  const unsigned long long gen = (unsigned long long)s_ctl[2] << 32;   // high half of every flag of this launch
-
-  // ---- resident recurrent weights (hi and lo fragments), chunks q = wave, wave+4, ...
-  const int fi = lane & 15;
-  s16x8 w[CPW][NT][2];
-  {
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.whh + (long)(dir * p.NU + ugi) * p.KQ2 * NT * 1024), 0, p.KQ2 * NT * 2048, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < CPW; ++i)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl)
-          w[i][nt][hl] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(
-              rw, (unsigned)(((wave + NW * i) * NT + nt) * 2048 + hl * 1024 + lane * 16), 0, 0));
-  }
-  // ---- fused input projection of the first layer (in_dim <= 160): this member's W_ih slice lives in LDS, the
-  //      products x_t W_ih^T are accumulated into the same MFMA accumulators as h_{t-1} W_hh^T -- behind the latency
-  //      of the h exchange, which they do not depend on -- and G never exists in memory
-  constexpr bool fuse = FUSE;
-  if constexpr (FUSE) {
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.wih0 + (long)(dir * p.NU + ugi) * p.KC0 * NT * 1024);
-    for (int i = tid; i < p.KC0 * NT * 128; i += NTHR) reinterpret_cast<u32x4*>(wih_s)[i] = src[i];
-    __syncthreads();
-  }
-  float cst[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) cst[i] = 0.0f;
-  const long hx_group = (long)g * 2 * p.KQ2 * 1024;             // uint16 elements per group (two slots)
-  const bool stamp = p.dbg && tid == 0 && blockIdx.x == 0;
-
-  // ---- per-thread constants of the cell update: element e = (row, ju) of this member's 16 x UG tile
-  bool e_ok[EPT], e_inb[EPT];
-  long g_off[EPT], y_off[EPT], i_off[EPT];   // float / float / uint16 offsets at t = 0
-  unsigned hx_off[EPT];                 // byte offset inside a hand-off slot
-  int red_off[EPT][4];                  // LDS float offset of the wave-0 partial of each gate
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    const int e = tid + NTHR * i;
-    const int row = (e / UG) & 15, ju = e % UG, b = b0 + row, k = ugi * UG + ju;
-    e_ok[i] = e < p.RG * UG;
-    e_inb[i] = e_ok[i] && b < p.B;
-    g_off[i] = ((long)b * 2 + dir) * p.NP + ugi * 4 * UG + ju * 4;
-    y_off[i] = ((long)b * 2 + dir) * p.Hp + k;
-    i_off[i] = ((long)b * p.KBI + ((dir * p.Hp + k) >> 5)) * 64 + ((dir * p.Hp + k) & 31);
-    hx_off[i] = (unsigned)(((k >> 5) * 1024 + (row + 16 * ((k >> 3) & 3)) * 8 + (k & 7)) * 2);
-#pragma unroll
-    for (int gt = 0; gt < 4; ++gt) {
-      const int pl = gt * UG + ju;
-      red_off[i][gt] = ((pl >> 4) * 4 + (row & 3)) * RLD + ((row >> 2) << 4) + (pl & 15);
-    }
-  }
-  const long g_step = (long)p.B * 2 * p.NP, y_step = (long)p.B * 2 * p.Hp, i_step = (long)p.B * p.KBI * 64;
-  // input projection of a step: loaded one step AHEAD into a second register set.  Waiting for the h fragments
-  // (vmcnt retires in order) would otherwise also wait for these older, HBM-cold loads on the critical path.
-  auto load_g = [&](float (&gp)[EPT][4], int step) {
-    const int t = dir == 0 ? step : p.T - 1 - step;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const bool ok = e_inb[i] && (step < p.T) && !(p.ablate & 2) && !fuse;
-      const float4 g4 = ok ? *reinterpret_cast<const float4*>(p.G + g_off[i] + t * g_step) : make_float4(0.f, 0.f, 0.f, 0.f);
-      gp[i][0] = g4.x; gp[i][1] = g4.y; gp[i][2] = g4.z; gp[i][3] = g4.w;
-    }
-  };
-  float gcur[EPT][4], gnext[EPT][4];
-  if constexpr (!FUSE) load_g(gcur, 0);
-  float bgate[EPT][4];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i)
-#pragma unroll
-    for (int gt = 0; gt < 4; ++gt)
-      bgate[i][gt] = (fuse && e_ok[i]) ? p.bias0[dir * p.NP + ugi * 4 * UG + ((tid + NTHR * i) % UG) * 4 + gt] : 0.0f;
-  // input fragments of a step (A operand: batch rows x 32-wide k chunk), chunks wave, wave + NW (< KC0 <= 5);
-  // like G they are fetched one step ahead into a second register set
-  constexpr int XS = FUSE ? KCMAX / NW + (KCMAX % NW != 0) : 1;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.ximg, 0, fuse ? (int)((long)p.T * p.B * p.KC0 * 128) : 0, 0x00020000);
-  auto load_x = [&](u32x4 (&xf)[XS][2], int step) {
-    const int t = dir == 0 ? step : p.T - 1 - step;
-    const int b = b0 + (lane & 15);
-#pragma unroll
-    for (int ci = 0; ci < XS; ++ci) {
-      const int c = wave + NW * ci;
-      const bool ok = fuse && c < p.KCM && (lane & 15) < p.RG && b < p.B && step < p.T;
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl)
-        xf[ci][hl] = __builtin_amdgcn_raw_buffer_load_b128(
-            rx, ok ? (unsigned)((((long)(t * p.B + b) * p.KC0 + c) * 2 + hl) * 64 + (lane >> 4) * 16) : 0x7ffffff0u, 0, 0);
-    }
-  };
-  u32x4 xcur[XS][2], xnext[XS][2];
-  if constexpr (FUSE) load_x(xcur, 0);
-  // lone last input column (in_dim = 32*KCM + 1): w_tail per (element, gate) in registers, x_tail fetched one step ahead
-  const bool tail = fuse && p.KCM < p.KC0;
-  float wt[EPT][4];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i)
-#pragma unroll
-    for (int gt = 0; gt < 4; ++gt)
-      wt[i][gt] = (tail && e_ok[i]) ? p.wtail[dir * p.NP + ugi * 4 * UG + ((tid + NTHR * i) % UG) * 4 + gt] : 0.0f;
-  auto load_xt = [&](float (&xt)[EPT], int step) {
-    const int t = dir == 0 ? step : p.T - 1 - step;
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int b = b0 + ((tid + NTHR * i) / UG);
-      xt[i] = (tail && e_inb[i] && step < p.T) ? p.x0[(long)b * p.xs_b + (long)t * p.xs_t + 32 * p.KCM] : 0.0f;
-    }
-  };
-  float xtcur[EPT], xtnext[EPT];
-  if constexpr (FUSE) load_xt(xtcur, 0);
-
-  // One flag per WAVE of every member (128 per group, 1 KiB): a wave raises its own flag as soon as its own
-  // stores are acknowledged, and every wave polls for itself with one 16-byte load per lane -- no workgroup
-  // barrier on either side of the exchange.  The only barrier of a step is the one between the per-wave
-  // partial sums and the cell update; `red` is double-buffered so that this one barrier suffices.
-  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void*)flags, 0, 32 * NW * 8, 0x00020000);
-  bool gave_up = false;                          // after a timeout nobody waits any more: the launch drains
-                                                 // with garbage and the abort word tells the host
-  // the loop body exists twice: L2-local protocol (FAST) and placement-independent protocol
-  auto run = [&](auto fast_c) {
-    constexpr bool FAST = decltype(fast_c)::value;
-    constexpr int LD_AUX = FAST ? 16 : 17;       // sc1: bypass L1, served by this XCD's L2 | sc0 sc1: coherent anywhere
-    constexpr int ST_AUX = FAST ? 0 : 16;        // plain (line stays in L2) | sc1 write-through
-    auto wait_flags = [&](unsigned want_lo) {    // until every wave of every member has published `want_lo`
-      if (gave_up) return;
-      const unsigned long long want = gen | want_lo;
-      unsigned spins = 0;
-      for (;;) {
-        bool ready = true;
-#pragma unroll
-        for (int h = 0; h < NW / 4; ++h) {   // 32*NW flags: NW/4 16-byte loads per lane
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rf, (unsigned)(h * 1024 + lane * 16), 0, LD_AUX);
-          const unsigned long long f0 = ((unsigned long long)v[1] << 32) | v[0], f1 = ((unsigned long long)v[3] << 32) | v[2];
-          ready = ready && ((h * 128 + 2 * lane >= NW * p.NU) || (f0 >= want && f1 >= want));   // stale words carry an older generation
-        }
-        if (__all(ready)) break;
-        if (!FAST) __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 63u) == 0 &&
-            (spins > p.spin_limit || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          if (lane == 0) __hip_atomic_store(abort_w, 2u + want_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          gave_up = true;
-          break;
-        }
-      }
-      if (!FAST) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the producers' release below
-    };
-    // one time step; `guse` holds this step's input projection, `gpre` receives the next step's (the two
-    // register sets swap roles every step, so the prefetch is only waited for when it is consumed)
-    auto body = [&](int step, float (&guse)[EPT][4], float (&gpre)[EPT][4], u32x4 (&xuse)[XS][2], u32x4 (&xpre)[XS][2],
-                    float (&xtuse)[EPT], float (&xtpre)[EPT]) {
-      const int t = dir == 0 ? step : p.T - 1 - step;
-      float* redb = red + (step & 1) * (NW * NT * 4 * RLD);
-      if (stamp) p.dbg[step * 8 + 0] = clock64();
-      f32x4 acc[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (FUSE) {   // x_t W_ih^T: independent of the exchange -- issued BEFORE the flag wait, the MFMAs run under it
-#pragma unroll
-        for (int ci = 0; ci < XS; ++ci) {
-          const int c = wave + NW * ci;
-          if (c < p.KCM) {
-            const s16x8 xh = __builtin_bit_cast(s16x8, xuse[ci][0]), xl = __builtin_bit_cast(s16x8, xuse[ci][1]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const s16x8 wh = *reinterpret_cast<const s16x8*>(wih_s + ((c * NT + nt) * 2 + 0) * 512 + lane * 8);
-              const s16x8 wl = *reinterpret_cast<const s16x8*>(wih_s + ((c * NT + nt) * 2 + 1) * 512 + lane * 8);
-              acc[nt] = mfma_bf16(xl, wh, acc[nt]);
-              acc[nt] = mfma_bf16(xh, wl, acc[nt]);
-              acc[nt] = mfma_bf16(xh, wh, acc[nt]);
-            }
-          }
-        }
-      }
-      u32x4 a[CPW][2];
-      if (step > 0) {
-        wait_flags((unsigned)step);
-        if (stamp) p.dbg[step * 8 + 1] = clock64();
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.hx + hx_group + (long)((step - 1) & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < CPW; ++i)
-#pragma unroll
-          for (int hl = 0; hl < 2; ++hl)    // chunks past KQ2 are out of range -> zeros
-            a[i][hl] = __builtin_amdgcn_raw_buffer_load_b128(
-                rh, ((p.ablate & 1) || (lane & 15) >= p.RG) ? 0x7ffffff0u : (unsigned)((wave + NW * i) * 2048 + hl * 1024 + lane * 16), 0, LD_AUX);
-      }
-      if (stamp) p.dbg[step * 8 + 6] = clock64();
-      if constexpr (FUSE) {
-        load_x(xpre, step + 1);
-        load_xt(xtpre, step + 1);
-      } else {
-        load_g(gpre, step + 1);
-      }
-      if (stamp) p.dbg[step * 8 + 7] = clock64();
-      if (step > 0 && !(p.ablate & 4)) {
-#pragma unroll
-        for (int i = 0; i < CPW; ++i) {
-          if (wave + NW * i < p.KQ2) {
-            const s16x8 ah = __builtin_bit_cast(s16x8, a[i][0]), al = __builtin_bit_cast(s16x8, a[i][1]);
-            // term-major: NT independent accumulators between two MFMAs on the same one
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(al, w[i][nt][0], acc[nt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][1], acc[nt]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(ah, w[i][nt][0], acc[nt]);
-          }
-        }
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) redb[((wave * NT + nt) * 4 + r) * RLD + lane] = acc[nt][r];
-      if (stamp) p.dbg[step * 8 + 2] = clock64();
-      __syncthreads();
-      if (stamp) p.dbg[step * 8 + 3] = clock64();
-
-      // ---- fused cell update; publish h_t (fp32 row for the next layer, split-bf16 fragment image for the group)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(p.hx + hx_group + (long)(step & 1) * p.KQ2 * 1024), 0, p.KQ2 * 2048, 0x00020000);
-      float keep_h[EPT];
-      unsigned keep_hl[EPT];
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        keep_h[i] = 0.0f;
-        keep_hl[i] = 0u;
-        if (e_ok[i]) {
-          // 4 gates x NW wave partials: independent LDS reads issued together, then summed pairwise
-          float part[4][NW], pre[4];
-#pragma unroll
-          for (int gt = 0; gt < 4; ++gt) {
-            const float* src = redb + red_off[i][gt];
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) part[gt][wv] = src[wv * NT * 4 * RLD];
-          }
-#pragma unroll
-          for (int gt = 0; gt < 4; ++gt) {
-            float sum = (part[gt][0] + part[gt][1]) + (part[gt][2] + part[gt][3]);
-            if constexpr (NW == 8) sum += (part[gt][4] + part[gt][5]) + (part[gt][6] + part[gt][7]);
-            if constexpr (FUSE) pre[gt] = sum + bgate[i][gt] + xtuse[i] * wt[i][gt];
-            else pre[gt] = sum + guse[i][gt];
-          }
-          const float ig = gate_sigmoid(pre[0]), fg2 = gate_sigmoid(pre[1]), gg = gate_tanh(pre[2]), og = gate_sigmoid(pre[3]);
-          const float cn = fg2 * cst[i] + ig * gg;
-          cst[i] = cn;
-          const float h = e_inb[i] ? og * gate_tanh(cn) : 0.0f;   // rows past B carry zeros through the exchange
-          unsigned short hi, lo;
-          split_bf16(h, hi, lo);
-          __builtin_amdgcn_raw_buffer_store_b16((short)hi, rs, hx_off[i], 0, ST_AUX);
-          __builtin_amdgcn_raw_buffer_store_b16((short)lo, rs, hx_off[i] + 1024, 0, ST_AUX);
-          keep_h[i] = h;
-          keep_hl[i] = (unsigned)hi | ((unsigned)lo << 16);
-        }
-      }
-      // this wave's stores are acknowledged (by L2 / by memory) -> raise this wave's flag
-      if (stamp) p.dbg[step * 8 + 4] = clock64();
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // s_waitcnt vmcnt(0)
-      if (stamp) p.dbg[step * 8 + 5] = clock64();
-      if (lane == 0) {
-        if (FAST) {
-          __hip_atomic_store(flags + ugi * NW + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {   // write this XCD's L2 back, then raise the flag
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          __hip_atomic_store(flags + ugi * NW + wave, gen | ((unsigned)step + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      // the layer's OUTPUT (fp32 rows for the caller, x3 image for the next GEMM) is nobody's business inside this
-      // launch: it leaves after the flag, off the exchange's critical path
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        if (e_inb[i] && !(p.ablate & 16)) {
-          if (p.y) p.y[y_off[i] + t * y_step] = keep_h[i];
-          if (p.yimg) {   // the same split pair, in the layout the next layer's / the head's GEMM reads
-            unsigned short* d = p.yimg + i_off[i] + t * i_step;
-            d[0] = (unsigned short)(keep_hl[i] & 0xffffu);
-            d[32] = (unsigned short)(keep_hl[i] >> 16);
-          }
-        }
-      }
-    };
-    for (int step = 0; step < p.T; step += 2) {
-      body(step, gcur, gnext, xcur, xnext, xtcur, xtnext);
-      if (step + 1 < p.T) body(step + 1, gnext, gcur, xnext, xcur, xtnext, xtcur);
-    }
-    // member 0 closes the launch: once every wave of the group has published its last step (so nobody can
-    // still be comparing against this generation), bump it
-    if (ugi == 0 && wave == 0) {
-      wait_flags((unsigned)p.T);
-      if (lane == 0) __hip_atomic_fetch_add(p.sync + 288 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  if (fast) run(std::true_type{}); else run(std::false_type{});
-}
-
-// =================================================================================================
-// K1+K2 / K10: fp64 FFT helpers.  One wavefront transforms one frame in its own LDS buffer: radix-4
-// decimation-in-time stages (N = 4^k, or two half-size transforms + one radix-2 stage for N = 2*4^k), twiddles and
-// the Hann window from a constant table, and NO workgroup barrier: a wave's LDS operations execute in order, so
-// the stages of a frame only need the compiler to keep them in order.
-// =================================================================================================
-#include "fft_tables.inc"
-
-template <int N>
-struct FftPlan {
-  static constexpr bool kOdd = (N == 512 || N == 128 || N == 2048);   // N = 2 * 4^k
-  static constexpr int M = kOdd ? N / 2 : N;                           // radix-4 transform length
-  static constexpr int DIG = M == 64 ? 3 : M == 256 ? 4 : M == 1024 ? 5 : 0;
-  static_assert(DIG != 0, "FFT length must be 4^k or 2*4^k with 64 <= 4^k <= 1024");
-};
-
-// LDS position of input sample n so that the in-place stages below end in natural order
-template <int N>
-__device__ __forceinline__ int fft_perm(int n) {
-  using P = FftPlan<N>;
-  const int m = P::kOdd ? (n >> 1) : n;
-  int r = 0;
-#pragma unroll
-  for (int d = 0; d < P::DIG; ++d) r |= ((m >> (2 * d)) & 3) << (2 * (P::DIG - 1 - d));
-  return (P::kOdd ? (n & 1) * P::M : 0) + r;
-}
-
-// LDS position of logical element i: two doubles of padding per 16, so that the strided accesses of the first
-// radix-4 stages (4 consecutive doubles every 16 / one double every 4) spread over all banks instead of 8
-__device__ __forceinline__ int fft_idx(int i) { return i + ((i >> 4) << 1); }
-template <int N>
-constexpr int fft_buf_len() { return N + N / 8; }
-
-template <int N>
-__device__ __forceinline__ double fft_win(int i) { return 0.5 - 0.5 * kCos1024[i * (1024 / N)]; }   // periodic Hann
-
-// In-place FFT of the wave's frame (input at fft_perm positions, output in natural order).  inverse = conjugated
-// twiddles, unscaled.  Every lane of the wave calls this.
-template <int N>
-__device__ __forceinline__ void fft_wave(double* re, double* im, int lane, bool inverse) {
-  using P = FftPlan<N>;
-  constexpr int M = P::M;
-  const double sg = inverse ? 1.0 : -1.0;   // sign of the imaginary part of the twiddles / of the +-i rotations
-#pragma unroll
-  for (int d = 0; d < P::DIG; ++d) {
-    const int Ls = 1 << (2 * d);            // length of the four sub-transforms being combined
-    __builtin_amdgcn_wave_barrier();
-    for (int u = lane; u < N / 4; u += 64) {
-      const int sub = u / (M / 4), v = u % (M / 4);
-      const int j = v & (Ls - 1), base = sub * M + ((v >> (2 * d)) << (2 * d + 2)) + j;
-      const int tk = j * (1024 / (4 * Ls));            // W_{4Ls}^j = table[tk]
-      double xr[4], xi[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double ar = re[fft_idx(base + q * Ls)], ai = im[fft_idx(base + q * Ls)];
-        if (q == 0 || d == 0) {
-          xr[q] = ar;
-          xi[q] = ai;
-        } else {
-          const double wr = kCos1024[q * tk], wi = sg * kSin1024[q * tk];
-          xr[q] = ar * wr - ai * wi;
-          xi[q] = ar * wi + ai * wr;
-        }
-      }
-      // y0 = x0+x1+x2+x3, y1 = x0 + s*i*x1 - x2 - s*i*x3 (s = sg: -i forward), y2 = x0-x1+x2-x3, y3 = x0 - s*i*x1 - x2 + s*i*x3
-      const double ar = xr[0] + xr[2], ai = xi[0] + xi[2], br = xr[0] - xr[2], bi = xi[0] - xi[2];
-      const double cr = xr[1] + xr[3], ci = xi[1] + xi[3], dr = xr[1] - xr[3], di = xi[1] - xi[3];
-      const int p0 = fft_idx(base), p1 = fft_idx(base + Ls), p2 = fft_idx(base + 2 * Ls), p3 = fft_idx(base + 3 * Ls);
-      re[p0] = ar + cr;  im[p0] = ai + ci;
-      re[p2] = ar - cr;  im[p2] = ai - ci;
-      // s*i*(dr + i di) = s*(-di + i dr)
-      re[p1] = br - sg * di;  im[p1] = bi + sg * dr;
-      re[p3] = br + sg * di;  im[p3] = bi - sg * dr;
-    }
-  }
-  if (P::kOdd) {   // X[k] = E[k] + W_N^k O[k], X[k + N/2] = E[k] - W_N^k O[k]
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < N / 2; k += 64) {
-      const double wr = kCos1024[k * (1024 / N)], wi = sg * kSin1024[k * (1024 / N)];
-      const int pe = fft_idx(k), po = fft_idx(k + N / 2);
-      const double er = re[pe], ei = im[pe], orr = re[po], oi = im[po];
-      const double tr = orr * wr - oi * wi, ti = orr * wi + oi * wr;
-      re[pe] = er + tr;  im[pe] = ei + ti;
-      re[po] = er - tr;  im[po] = ei - ti;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int N>
-__global__ __launch_bounds__(256) void stft_logmag_kernel(const float* __restrict__ wav, int B, int n_samples,
-                                                          long wav_stride, int hop, int T, float eps,
-                                                          float* __restrict__ logmag, float* __restrict__ stft_ri) {
-  __shared__ double buf_re[4][fft_buf_len<N>()], buf_im[4][fft_buf_len<N>()];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int F = N / 2 + 1;
-  const long total = (long)B * T;
-  double* re = buf_re[wave];
-  double* im = buf_im[wave];
-  // grid-stride over frames, one frame per wave at a time; no workgroup-wide synchronisation anywhere
-  for (long frame = (long)blockIdx.x * 4 + wave; frame < total; frame += (long)gridDim.x * 4) {
-    const int b = (int)(frame / T), t = (int)(frame % T);
-    const float* sig = wav + (long)b * wav_stride;
-    for (int i = lane; i < N; i += 64) {
-      int pidx = t * hop + i - N / 2;  // centred frame, reflect padding (edge sample not repeated)
-      if (pidx < 0) pidx = -pidx;
-      if (pidx >= n_samples) pidx = 2 * (n_samples - 1) - pidx;
-      const int j = fft_idx(fft_perm<N>(i));
-      re[j] = (double)sig[pidx] * fft_win<N>(i);
-      im[j] = 0.0;
-    }
-    fft_wave<N>(re, im, lane, false);
-    for (int f = lane; f < F; f += 64) {
-      const float xr = (float)re[fft_idx(f)], xi = (float)im[fft_idx(f)];  // complex128 -> complex64 like the reference
-      const long o = (frame * F + f);
-      logmag[o] = log10f(hypotf(xr, xi) + eps);
-      if (stft_ri) {
-        stft_ri[2 * o] = xr;
-        stft_ri[2 * o + 1] = xi;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();   // the next frame overwrites the buffer
-  }
-}
-
-// FB = frames transformed per workgroup (FB/4 rounds of 4 waves); sized so that the LDS image
-// (tables + 4 FFT buffers + FB windowed frames, all fp64) stays under 160 KiB.
-// PAIR: two speakers per workgroup through ONE complex inverse FFT per frame: with Z = S_a + i S_b (both Hermitian),
-// ifft(Z) = s_a + i s_b because s_a and s_b are real -- half the butterflies of two real transforms.  blockIdx.y then
-// counts speaker pairs (the last pair of an odd C repeats its only speaker and drops the copy).
-template <int N, int FB, bool PAIR>
-__global__ __launch_bounds__(256) void mask_istft_kernel(const float* __restrict__ stft_ri,
-                                                         const float* __restrict__ mask, long m_sb, long m_sc,
-                                                         long m_st, long m_sf, int C, int T, int hop, int length,
-                                                         int FR, float* __restrict__ out) {
-  constexpr int NS = PAIR ? 2 : 1;
-  __shared__ double buf_re[4][fft_buf_len<N>()], buf_im[4][fft_buf_len<N>()];
-  __shared__ float fr[NS][FB][N];   // windowed time-domain frames of this chunk (the reference's istft keeps them in
-                                    // float32 too); 50 KB per workgroup with the FFT buffers: three workgroups per CU
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int F = N / 2 + 1;
-  const int chunk = blockIdx.x, b = blockIdx.z;
-  const int c0 = PAIR ? 2 * (int)blockIdx.y : (int)blockIdx.y, c1 = (PAIR && c0 + 1 < C) ? c0 + 1 : c0;
-  // output samples n in [chunk*FR*hop, +FR*hop); padded position p = n + N/2 is covered by frames
-  // t with t*hop <= p < t*hop + N
-  const int p0 = chunk * FR * hop + N / 2;
-  int tfirst = (p0 - N + hop) / hop;  // ceil((p0 - N + 1) / hop) for p0 >= N/2 >= 1 ... clamp below
-  if (p0 - N + 1 <= 0) tfirst = 0;
-  const double inv_n = 1.0 / (double)N;
-  for (int round = 0; round < FB / 4; ++round) {
-    const int fidx = round * 4 + wave, t = tfirst + fidx;
-    const bool active = t < T;
-    double* re = buf_re[wave];
-    double* im = buf_im[wave];
-    const float* xs = stft_ri + ((long)(b * T + (active ? t : 0)) * F) * 2;
-    const float* ms0 = mask ? mask + (long)b * m_sb + (long)c0 * m_sc + (long)(active ? t : 0) * m_st : nullptr;
-    const float* ms1 = mask ? mask + (long)b * m_sb + (long)c1 * m_sc + (long)(active ? t : 0) * m_st : nullptr;
-    for (int f = lane; f < F; f += 64) {
-      // S_a = X * m_a (and S_b = X * m_b); c2r transforms ignore the imaginary part of DC / Nyquist
-      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-      if (active) {
-        const double xr = (double)xs[2 * f], xi = (f == 0 || f == N / 2) ? 0.0 : (double)xs[2 * f + 1];
-        const double ma = ms0 ? (double)ms0[(long)f * m_sf] : 1.0;
-        ar = xr * ma;
-        ai = xi * ma;
-        if (PAIR) {
-          const double mb = ms1 ? (double)ms1[(long)f * m_sf] : 1.0;
-          br = xr * mb;
-          bi = xi * mb;
-        }
-      }
-      const int j = fft_idx(fft_perm<N>(f));
-      re[j] = ar - bi;           // Z[f] = S_a[f] + i S_b[f]
-      im[j] = ai + br;
-      if (f > 0 && f < N / 2) {  // Hermitian mirrors: Z[N-f] = conj(S_a[f]) + i conj(S_b[f])
-        const int jm = fft_idx(fft_perm<N>(N - f));
-        re[jm] = ar + bi;
-        im[jm] = -ai + br;
-      }
-    }
-    fft_wave<N>(re, im, lane, true);
-    for (int i = lane; i < N; i += 64) {
-      const double w = active ? fft_win<N>(i) * inv_n : 0.0;
-      fr[0][fidx][i] = (float)(w * re[fft_idx(i)]);
-      if (PAIR) fr[1][fidx][i] = (float)(w * im[fft_idx(i)]);
-    }
-    __builtin_amdgcn_wave_barrier();   // the wave's next round overwrites its buffer
-  }
-  __syncthreads();
-  const int exp_len = N + hop * (T - 1);
-  for (int idx = tid; idx < FR * hop; idx += 256) {
-    const int n = chunk * FR * hop + idx;
-    if (n >= length) continue;
-    const int pp = n + N / 2;
-    double y0 = 0.0, y1 = 0.0;
-    if (pp < exp_len) {
-      int tlo = (pp - N + hop) / hop;
-      if (pp - N + 1 <= 0) tlo = 0;
-      int thi = pp / hop;
-      if (thi > T - 1) thi = T - 1;
-      double s0 = 0.0, s1 = 0.0, wss = 0.0;
-      for (int t = tlo; t <= thi && t - tfirst < FB; ++t) {
-        const int i = pp - t * hop;
-        s0 += (double)fr[0][t - tfirst][i];
-        if (PAIR) s1 += (double)fr[1][t - tfirst][i];
-        const double w = fft_win<N>(i);
-        wss += w * w;
-      }
-      const bool norm = wss > 2.2250738585072014e-308;
-      y0 = norm ? s0 / wss : s0;
-      y1 = norm ? s1 / wss : s1;
-    }
-    out[((long)b * C + c0) * length + n] = (float)y0;
-    if (PAIR && c1 != c0) out[((long)b * C + c1) * length + n] = (float)y1;
-  }
-}
-
-
-
-template <int NT>
-static int launch_xcd(XcdArgs xa, int nw, hipStream_t st) {
-  // <= 4 batch groups of 16 rows per launch (2 directions x 4 = the chip's 8 XCDs)
-  // rows per group: the smallest of 4 / 8 / 16 that still covers the batch with the chip's 8 groups per launch
-  xa.RG = xa.B <= 16 ? 4 : xa.B <= 32 ? 8 : 16;
-  static const int rg_env = getenv("ONSSEN_XCD_RG") ? atoi(getenv("ONSSEN_XCD_RG")) : 0;   // profiling: force 4 / 8 / 16
-  if (rg_env == 4 || rg_env == 8 || rg_env == 16) xa.RG = rg_env;
-  for (int r0 = 0; r0 < xa.B; r0 += 4 * xa.RG) {
-    const int rows = xa.B - r0 < 4 * xa.RG ? xa.B - r0 : 4 * xa.RG;
-    xa.row0 = r0;
-    xa.nbg = ceil_div(rows, xa.RG);
-    const bool fz = xa.KC0 > 0;
-    if (nw == 8) {
-      if (fz) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8, true>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
-      else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 8, false>), dim3((unsigned)(8 * xa.NU)), dim3(512), 0, st, xa);
-    } else {
-      if (fz) hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4, true>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
-      else hipLaunchKernelGGL((lstm_xcd_kernel<NT, 4, false>), dim3((unsigned)(8 * xa.NU)), dim3(256), 0, st, xa);
-    }
-  }
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ONSSEN_OK : (int)e;
-}
-
-template <int MT, int NT>
-static int launch_steps(StepArgs sp, char* ws, int T, bool x3, hipStream_t st) {
-  const dim3 grid((unsigned)sp.NU, 2, (unsigned)ceil_div(sp.B, 16 * MT)), block(256);
-  const unsigned g_off = (unsigned)(((const char*)sp.G - ws) / 256), c_off = (unsigned)(((char*)sp.c - ws) / 256),
-                 hs_off = (unsigned)(((char*)sp.hs - ws) / 256);
-  ONSSEN_CLEAR_ERROR();
-  for (int s = 0; s < T; ++s) {
-    sp.step = s;
-    const void* w = x3 ? (const void*)sp.whh_x3 : (const void*)sp.whh;
-#define ONSSEN_STEP_LAUNCH(X3_, DBG_)                                                                             \
-  hipLaunchKernelGGL((lstm_step_kernel<MT, NT, X3_, DBG_>), grid, block, 0, st, w, ws, sp.y, s, sp.B, sp.NU, T, g_off, \
-                     c_off, hs_off, sp.ablate, sp.dbg)
-    if (sp.ablate || sp.dbg) {
-      if (x3) ONSSEN_STEP_LAUNCH(true, true); else ONSSEN_STEP_LAUNCH(false, true);
-    } else {
-      if (x3) ONSSEN_STEP_LAUNCH(true, false); else ONSSEN_STEP_LAUNCH(false, false);
-    }
-#undef ONSSEN_STEP_LAUNCH
-  }
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ONSSEN_OK : (int)e;
-}
-
-// calibration probe: a chain of n dependent near-empty launches (measures the launch-boundary floor)
-__global__ void probe_kernel(float* p) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1.0f;
-}
-
-// =================================================================================================
-// N1 (forward half): deep-clustering loss value, onssen/loss/loss_dc.py:6-44 with loss_util.py:4-11.
-// Per utterance b: z_r = [ s_r * V_r (D) | Y_r (C) ], s_r = sum_c Y_r[c] (0 on silent bins), weight w_r^2 =
-// mag_r / sum_r mag_r.  Everything the loss needs is the (D+C) x (D+C) Gram matrix G = sum_r mag_r z_r z_r^T:
-// V^T V, V^T Y and Y^T Y are its blocks, and the 1/sum(mag) scale is applied at the end (the weights are
-// linear in the Gram), so the embedding is streamed from HBM exactly once.
-// =================================================================================================
-namespace lossdc {
-constexpr int NBLK = 64;        // row blocks per utterance (partials reduced in a fixed order: deterministic)
-constexpr int RT = 64;          // rows per LDS tile
-constexpr int ZMAX = 34;        // D + C <= 34
-}  // namespace lossdc
-
-__global__ __launch_bounds__(256) void loss_dc_partial_kernel(const float* __restrict__ emb, const float* __restrict__ one_hot,
-                                                              const float* __restrict__ mag, int TF, int D, int C,
-                                                              float* __restrict__ partial) {
-  using namespace lossdc;
-  __shared__ float q[RT][ZMAX + 1];      // sqrt(mag_r) * z_r
-  __shared__ float msum[256];
-  const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
-  const int Z = D + C, nout = Z * Z;
-  const int rows_per = (TF + NBLK - 1) / NBLK, r0 = blk * rows_per, r1 = r0 + rows_per < TF ? r0 + rows_per : TF;
-  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // outputs tid, tid+256, ... (Z*Z <= 1156)
-  float mtot = 0.f;
-  const long base = (long)b * TF;
-  for (int t0 = r0; t0 < r1; t0 += RT) {
-    const int nr = r1 - t0 < RT ? r1 - t0 : RT;
-    __syncthreads();
-    for (int e = tid; e < nr * Z; e += 256) {
-      const int r = e / Z, a = e % Z;
-      const long row = base + t0 + r;
-      const float m = mag[row];
-      float v;
-      if (a < D) {
-        float sact = 0.f;
-        for (int c = 0; c < C; ++c) sact += one_hot[row * C + c];
-        v = sact * emb[row * D + a];
-      } else {
-        v = one_hot[row * C + (a - D)];
-      }
-      q[r][a] = sqrtf(m) * v;
-    }
-    for (int r = tid; r < nr; r += 256) mtot += mag[base + t0 + r];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int o = tid + 256 * k;
-      if (o < nout) {
-        const int i = o / Z, j = o % Z;
-        float sum = acc[k];
-        for (int r = 0; r < nr; ++r) sum += q[r][i] * q[r][j];
-        acc[k] = sum;
-      }
-    }
-  }
-  float* dst = partial + ((long)b * NBLK + blk) * (ZMAX * ZMAX + 1);
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int o = tid + 256 * k;
-    if (o < nout) dst[o] = acc[k];
-  }
-  msum[tid] = mtot;
-  __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
-    if (tid < sft) msum[tid] += msum[tid + sft];
-    __syncthreads();
-  }
-  if (tid == 0) dst[ZMAX * ZMAX] = msum[0];
-}
-
-// one workgroup per utterance: reduce the partial Grams, then ||V^T V||_F - 2 ||V^T Y||_F + ||Y^T Y||_F
-__global__ __launch_bounds__(256) void loss_dc_final_kernel(const float* __restrict__ partial, int D, int C,
-                                                            float* __restrict__ per_utt, float* __restrict__ total_mag) {
-  using namespace lossdc;
-  __shared__ double red[3][256];
-  __shared__ float tot;
-  const int tid = threadIdx.x, b = blockIdx.x, Z = D + C, nout = Z * Z;
-  const float* src = partial + (long)b * NBLK * (ZMAX * ZMAX + 1);
-  if (tid == 0) {
-    float t = 0.f;
-    for (int k = 0; k < NBLK; ++k) t += src[(long)k * (ZMAX * ZMAX + 1) + ZMAX * ZMAX];
-    tot = t;
-  }
-  __syncthreads();
-  double s_vv = 0.0, s_vy = 0.0, s_yy = 0.0;
-  for (int o = tid; o < nout; o += 256) {
-    float g = 0.f;
-    for (int k = 0; k < NBLK; ++k) g += src[(long)k * (ZMAX * ZMAX + 1) + o];
-    g /= tot;                                  // w_r^2 = mag_r / sum(mag)
-    const int i = o / Z, j = o % Z;
-    const double g2 = (double)g * (double)g;
-    if (i < D && j < D) s_vv += g2;
-    else if (i < D && j >= D) s_vy += g2;
-    else if (i >= D && j >= D) s_yy += g2;
-  }
-  red[0][tid] = s_vv; red[1][tid] = s_vy; red[2][tid] = s_yy;
-  __syncthreads();
-  for (int sft = 128; sft > 0; sft >>= 1) {
-    if (tid < sft) {
-      red[0][tid] += red[0][tid + sft]; red[1][tid] += red[1][tid + sft]; red[2][tid] += red[2][tid + sft];
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    per_utt[b] = (float)(sqrt(red[0][0]) - 2.0 * sqrt(red[1][0]) + sqrt(red[2][0]));
-    total_mag[b] = tot;
-  }
-}
-
-// =================================================================================================
-// N4: batch SI-SDR with best permutation, onssen/evaluate/sdr.py:11-87 (calc_sdr_torch + batch_SDR_torch).
-// Everything the metric needs per utterance is the Gram matrix of the 2C zero-mean (optionally masked) signals
-// [est_0..est_{C-1}, org_0..org_{C-1}]: pass 1 sums the signals (means), pass 2 the centred products, a last
-// workgroup per utterance forms the C x C SDR table and scans the C! permutations in the reference's
-// (lexicographic) order.  The separated waveforms never leave the device.
-// =================================================================================================
-namespace sdr {
-constexpr int NBLK = 32, CMAX = 4, SMAX = 2 * CMAX, TS = 256;
-constexpr int PSTRIDE = SMAX * SMAX + SMAX;     // per (b, block): Gram then sums
-}  // namespace sdr
-
-template <int PASS>
-__global__ __launch_bounds__(256) void sdr_partial_kernel(const float* __restrict__ est, const float* __restrict__ org,
-                                                          const float* __restrict__ mask, int C, int n,
-                                                          const float* __restrict__ means, float* __restrict__ partial) {
-  using namespace sdr;
-  __shared__ float tile[SMAX][TS + 1];
-  const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y, S = 2 * C;
-  const int per = (n + NBLK - 1) / NBLK, s0 = blk * per, s1 = s0 + per < n ? s0 + per : n;
-  float mu[SMAX];
-#pragma unroll
-  for (int k = 0; k < SMAX; ++k) mu[k] = (PASS == 1 && k < S) ? means[b * SMAX + k] : 0.0f;
-  float acc = 0.0f;                               // PASS 0: thread k < S sums signal k; PASS 1: thread o < S*S -> G[o/S][o%S]
-  for (int t0 = s0; t0 < s1; t0 += TS) {
-    const int nt = s1 - t0 < TS ? s1 - t0 : TS;
-    __syncthreads();
-    for (int e = tid; e < S * TS; e += 256) {
-      const int k = e / TS, i = e % TS;
-      float v = 0.0f;
-      if (i < nt) {
-        const float* src = (k < C ? est + ((long)b * C + k) * n : org + ((long)b * C + (k - C)) * n);
-        v = src[t0 + i];
-        if (PASS == 1) {
-          v -= mu[k];
-          if (mask) v *= mask[(long)b * n + t0 + i];
-        }
-      }
-      tile[k][i] = v;
-    }
-    __syncthreads();
-    if (PASS == 0) {
-      if (tid < S) for (int i = 0; i < nt; ++i) acc += tile[tid][i];
-    } else if (tid < S * S) {
-      const int k = tid / S, l = tid % S;
-      for (int i = 0; i < nt; ++i) acc += tile[k][i] * tile[l][i];
-    }
-  }
-  float* dst = partial + ((long)b * NBLK + blk) * PSTRIDE;
-  if (PASS == 0) {
-    if (tid < S) dst[SMAX * SMAX + tid] = acc;
-  } else if (tid < S * S) {
-    dst[tid] = acc;
-  }
-}
-
-__global__ void sdr_means_kernel(const float* __restrict__ partial, int C, int n, float* __restrict__ means) {
-  using namespace sdr;
-  const int b = blockIdx.x, k = threadIdx.x;
-  if (k < 2 * C) {
-    double s = 0.0;
-    for (int blk = 0; blk < NBLK; ++blk) s += partial[((long)b * NBLK + blk) * PSTRIDE + SMAX * SMAX + k];
-    means[b * SMAX + k] = (float)(s / n);
-  }
-}
-
-__global__ void sdr_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ sdr_out, int* __restrict__ perm_out) {
-  using namespace sdr;
-  __shared__ float G[SMAX][SMAX];
-  __shared__ float tab[CMAX][CMAX];
-  const int b = blockIdx.x, tid = threadIdx.x, S = 2 * C;
-  if (tid < S * S) {
-    double s = 0.0;
-    for (int blk = 0; blk < NBLK; ++blk) s += partial[((long)b * NBLK + blk) * PSTRIDE + tid];
-    G[tid / S][tid % S] = (float)s;
-  }
-  __syncthreads();
-  if (tid < C * C) {       // SDR[i][j] of estimate i against source j (sdr.py:23-33)
-    const int i = tid / C, j = tid % C;
-    const float oo = G[C + j][C + j], ee = G[i][i], eo = G[i][C + j];
-    const float scale = eo / (oo + 1e-8f);
-    const float true_p = scale * scale * oo + 1e-8f;
-    const float res_p = ee - 2.0f * scale * eo + scale * scale * oo + 1e-8f;
-    tab[i][j] = 10.0f * log10f(true_p) - 10.0f * log10f(res_p);
-  }
-  __syncthreads();
-  if (tid == 0) {          // permutations in lexicographic order (sorted(set(permutations(range(C)))), sdr.py:74)
-    int perm[CMAX], best_idx = 0, idx = 0;
-    for (int k = 0; k < C; ++k) perm[k] = k;
-    float best = -3.0e38f;
-    for (;;) {
-      float v = 0.0f;
-      for (int k = 0; k < C; ++k) v += tab[k][perm[k]];
-      if (v > best) { best = v; best_idx = idx; }      // torch.max keeps the first maximum
-      ++idx;
-      int a = C - 2;                                   // next lexicographic permutation
-      while (a >= 0 && perm[a] > perm[a + 1]) --a;
-      if (a < 0) break;
-      int c = C - 1;
-      while (perm[c] < perm[a]) --c;
-      int t = perm[a]; perm[a] = perm[c]; perm[c] = t;
-      for (int l = a + 1, r = C - 1; l < r; ++l, --r) { t = perm[l]; perm[l] = perm[r]; perm[r] = t; }
-    }
-    sdr_out[b] = best / (float)C;
-    if (perm_out) perm_out[b] = best_idx;
-  }
-}
+// ---- device code, one translation unit (the host-side emulation compiles exactly this file too)
+#include "pack.inc"
+#include "gemm.inc"
+#include "labels_cluster.inc"
+#include "lstm.inc"
+#include "fft.inc"
+#include "loss_sdr.inc"
 
 // =================================================================================================
 // C ABI

@@ -11,7 +11,9 @@ OUT = os.path.join(ROOT, "tests", "emu", "libonssen_emu.so")
 
 
 def build_emu():
-    newest = max(os.path.getmtime(f) for f in [SRC] + HDRS)
+    csrc = os.path.dirname(SRC)
+    parts = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]   # one TU, several files
+    newest = max(os.path.getmtime(f) for f in parts + HDRS)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-I",
                                os.path.join(ROOT, "tests", "emu", "include"), "-pthread", "-shared", "-fPIC",
