@@ -77,11 +77,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     import torch.distributed as dist
+    # ONSSEN_BENCH_ONE_DEVICE=1 (harness self-test on a 1-GPU box): every rank uses cuda:0 and the gloo backend
+    one_dev = os.environ.get("ONSSEN_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from onssen_amd import nn as onn
     from onssen_amd.features import mask_istft, stft_logmag
@@ -154,7 +161,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            te = torch.tensor([elapsed], device="cpu" if one_dev else dev, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
