@@ -367,6 +367,19 @@ int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, 
   return ONSSEN_OK;
 }
 
+
+int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
+                         const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
+                         float* out, void* stream) {
+  if (!mask_a || !mask_b || !mag_mix || !mag_s1 || !mag_s2 || !out || B <= 0 || TF <= 0 || ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
+    return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(loss_mask_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, mask_a, mask_b, (long)m_sb,
+                     (long)m_se, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, TF, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // workspace layout: header | G | ybuf (L > 1) | c | h hand-off image | x3 images: layer-0 input, output A (the

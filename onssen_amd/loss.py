@@ -54,3 +54,64 @@ def _loss_dc_hip(emb, one_hot, mag, B, TF, D, C):
     lib.loss_dc(emb.data_ptr(), one_hot.data_ptr(), mag.data_ptr(), B, TF, D, C, per_utt.data_ptr(), total.data_ptr(),
                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     return per_utt * total.unsqueeze(1)                  # (B,) * (B,1) -> (B,B), as upstream
+
+
+# ----------------------------------------------------------------------------- chimera / chimera++ losses
+def _l1(x):
+    return x.reshape(x.shape[0], -1).abs().sum(dim=1)
+
+
+def _mask_term(mask_A, mask_B, mag_mix, t1, t2):
+    l_ab = _l1(mask_A * mag_mix - t1) + _l1(mask_B * mag_mix - t2)
+    l_ba = _l1(mask_B * mag_mix - t1) + _l1(mask_A * mag_mix - t2)
+    return torch.min(l_ab, l_ba)
+
+
+def _mask_term_hip(mask_A, mask_B, mag_mix, s1, s2, c1=None, c2=None):
+    """The mask-inference term on the device (no autograd): one pass over the maps, onssen_loss_mask_f32."""
+    from .hip import get_lib
+    B = mag_mix.shape[0]
+    TF = mag_mix[0].numel()
+    base = getattr(mask_A, "_base", None)
+    if (base is None or getattr(mask_B, "_base", None) is not base or mask_A.stride() != mask_B.stride()
+            or mask_A.stride(2) * mask_A.shape[2] != mask_A.stride(1)):
+        mask_A, mask_B = mask_A.contiguous(), mask_B.contiguous()   # not the strided views of one (B,T,F,2) buffer
+    f32 = lambda t: None if t is None else t.float().contiguous()
+    mag, s1, s2, c1, c2 = f32(mag_mix), f32(s1), f32(s2), f32(c1), f32(c2)
+    out = torch.empty(B, device=mag.device, dtype=torch.float32)
+    # element (b, e = t*F + f) of a mask view sits at b*stride(0) + e*stride(2) when stride(1) = F*stride(2)
+    get_lib().loss_mask(mask_A.data_ptr(), mask_B.data_ptr(), mask_A.stride(0), mask_A.stride(2), mag.data_ptr(), s1.data_ptr(),
+                        s2.data_ptr(), c1.data_ptr() if c1 is not None else None, c2.data_ptr() if c2 is not None else None,
+                        B, TF, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def _no_grad_needed(*ts):
+    return not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
+
+
+def loss_chimera_msa(output, label):
+    """onssen/loss/loss_chimera.py:6-31: 0.975 * loss_dc + 0.025 * magnitude-spectrum-approximation mask loss with the
+    better of the two speaker assignments ((B,B) like loss_dc, as upstream)."""
+    embedding, mask_A, mask_B = output
+    one_hot, mag_mix, mag_s1, mag_s2 = label
+    le = loss_dc([embedding], [one_hot, mag_mix])
+    if mask_A.is_cuda and _no_grad_needed(mask_A, mask_B):
+        lm = _mask_term_hip(mask_A, mask_B, mag_mix, mag_s1, mag_s2)
+    else:
+        lm = _mask_term(mask_A, mask_B, mag_mix, mag_s1, mag_s2)
+    return le * 0.975 + lm * 0.025
+
+
+def loss_chimera_psa(output, label):
+    """onssen/loss/loss_chimera.py:33-59: as MSA with the phase-sensitive targets min(|x|, relu(|s| cos(theta)))."""
+    embedding, mask_A, mask_B = output
+    one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2 = label
+    le = loss_dc([embedding], [one_hot, mag_mix])
+    if mask_A.is_cuda and _no_grad_needed(mask_A, mask_B):
+        lm = _mask_term_hip(mask_A, mask_B, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2)
+    else:
+        t1 = torch.min(mag_mix, torch.relu(mag_s1 * cos_s1))
+        t2 = torch.min(mag_mix, torch.relu(mag_s2 * cos_s2))
+        lm = _mask_term(mask_A, mask_B, mag_mix, t1, t2)
+    return le * 0.975 + lm * 0.025

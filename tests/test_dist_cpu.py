@@ -118,3 +118,16 @@ def test_loss_dc_and_gradient_match_reference_fixture(golden_dir):
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
     np.testing.assert_allclose(gn.item(), float(z["grad_norm"]), rtol=1e-4)
     np.testing.assert_allclose(m.fc_dc.bias.grad.numpy(), z["grad_fc_dc_bias"], rtol=1e-3, atol=1e-6)
+
+
+def test_chimera_losses_match_reference_fixture(golden_dir):
+    """N1: loss_chimera_msa / loss_chimera_psa (autograd path on CPU) against the reference's values
+    (tools/gen_golden_loss_chimera.py), including the (B, B) shape inherited from loss_dc."""
+    from onssen_amd.loss import loss_chimera_msa, loss_chimera_psa
+    z = np.load(f"{golden_dir}/g7_loss_chimera.npz")
+    tt = torch.from_numpy
+    out = [tt(z["emb"]), tt(z["masks"])[..., 0], tt(z["masks"])[..., 1]]
+    msa = loss_chimera_msa(out, [tt(z["one_hot"]), tt(z["mag"]), tt(z["s1"]), tt(z["s2"])])
+    psa = loss_chimera_psa(out, [tt(z["one_hot"]), tt(z["mag"]), tt(z["s1"]), tt(z["s2"]), tt(z["c1"]), tt(z["c2"])])
+    np.testing.assert_allclose(msa.numpy(), z["msa"], rtol=1e-5)
+    np.testing.assert_allclose(psa.numpy(), z["psa"], rtol=1e-5)

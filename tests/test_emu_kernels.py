@@ -432,3 +432,22 @@ def test_batch_sdr(lib, B, C, n, use_mask):
     ref_sdr, ref_perm = O.batch_sdr(est, org, mask)
     np.testing.assert_allclose(sdr, ref_sdr, rtol=1e-4, atol=1e-4)
     np.testing.assert_array_equal(perm, ref_perm)
+
+
+@pytest.mark.parametrize("psa", [False, True])
+def test_loss_mask_term(lib, psa):
+    """onssen_loss_mask_f32 against NumPy: both speaker assignments, MSA and PSA targets, strided mask views."""
+    rng = np.random.default_rng(12)
+    B, TF = 2, 700
+    masks = rng.random((B, TF, 2)).astype(np.float32)            # interleaved like fc_mi's output
+    mag = (np.abs(rand(rng, B, TF)) + 1e-3).astype(np.float32)
+    s1, s2 = (mag * rng.random((B, TF))).astype(np.float32), (mag * rng.random((B, TF))).astype(np.float32)
+    c1, c2 = rand(rng, B, TF).clip(-1, 1), rand(rng, B, TF).clip(-1, 1)
+    out = np.full(B, np.nan, np.float32)
+    ma, mb = masks[..., 0], masks[..., 1]
+    lib.loss_mask(P(masks), masks.ctypes.data + 4, 2 * TF, 2, P(mag), P(s1), P(s2), P(c1) if psa else None, P(c2) if psa else None,
+                  B, TF, P(out), None)
+    t1, t2 = (np.minimum(mag, np.maximum(s1 * c1, 0)), np.minimum(mag, np.maximum(s2 * c2, 0))) if psa else (s1, s2)
+    l1 = lambda a: np.abs(a.astype(np.float64)).sum(1)
+    ref = np.minimum(l1(ma * mag - t1) + l1(mb * mag - t2), l1(mb * mag - t1) + l1(ma * mag - t2))
+    np.testing.assert_allclose(out, ref, rtol=1e-5)

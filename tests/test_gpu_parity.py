@@ -493,3 +493,18 @@ def test_batch_sdr_on_device_matches_reference_fixture(dev, golden_dir):
     est = (org[:, ::-1] + 0.5 * rng.standard_normal(org.shape)).astype(np.float32)
     got = batch_SDR_torch(torch.from_numpy(est.copy()).to(dev), torch.from_numpy(org).to(dev))
     np.testing.assert_allclose(got.cpu().numpy(), O.batch_sdr(est, org)[0], rtol=1e-4, atol=1e-4)
+
+
+def test_chimera_losses_on_device_match_reference_fixture(dev, golden_dir):
+    """N1: loss_chimera_msa / psa under no_grad (HIP loss_dc + HIP mask term on the strided mask views) against the
+    reference's values."""
+    from onssen_amd.loss import loss_chimera_msa, loss_chimera_psa
+    z = np.load(f"{golden_dir}/g7_loss_chimera.npz")
+    d = lambda k: torch.from_numpy(z[k]).to(dev)
+    masks = d("masks")
+    out = [d("emb"), masks[..., 0], masks[..., 1]]
+    with torch.no_grad():
+        msa = loss_chimera_msa(out, [d("one_hot"), d("mag"), d("s1"), d("s2")])
+        psa = loss_chimera_psa(out, [d("one_hot"), d("mag"), d("s1"), d("s2"), d("c1"), d("c2")])
+    np.testing.assert_allclose(msa.cpu().numpy(), z["msa"], rtol=1e-4)
+    np.testing.assert_allclose(psa.cpu().numpy(), z["psa"], rtol=1e-4)
