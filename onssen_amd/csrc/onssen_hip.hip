@@ -584,7 +584,7 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
 
 size_t onssen_dc_cluster_workspace_bytes(int B, int D) {
   if (B <= 0 || D <= 0 || D > km::DMAX) return 0;
-  return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1)) * sizeof(float);
+  return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1) + 1) * sizeof(float);   // fmax, centroids, partial sums, done flag
 }
 
 int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
@@ -594,17 +594,23 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, D)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)stream;
-  const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1);
+  const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1) + 1;
   float* w = (float*)ws;
   hipLaunchKernelGGL(kmeans2_init_kernel, dim3((unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w,
                      stride);
+#define ONSSEN_KM_ASSIGN(MODE_, OUT_)                                                                                      \
+  do {                                                                                                                   \
+    if (D == 20) hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 20>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, \
+                                    feature, per_utt, D, db_threshold, w, stride, OUT_);                                    \
+    else hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 0>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature,  \
+                            per_utt, D, db_threshold, w, stride, OUT_);                                                      \
+  } while (0)
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL((kmeans2_assign_kernel<0>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D,
-                       db_threshold, w, stride, (float*)nullptr);
+    ONSSEN_KM_ASSIGN(0, (float*)nullptr);
     hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(128), 0, st, D, km::NBLK, w, stride);
   }
-  hipLaunchKernelGGL((kmeans2_assign_kernel<1>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D,
-                     db_threshold, w, stride, masks);
+  ONSSEN_KM_ASSIGN(1, masks);
+#undef ONSSEN_KM_ASSIGN
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
