@@ -165,6 +165,29 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
+        # ---- the same step with the REAL deep-clustering back end (threshold + 2-means on the device)
+        #      instead of resident masks: reported next to the headline, outside the timed region, rank 0 only
+        dc_e2e = None
+        if kind == "deep_clustering" and rank == 0:
+            from onssen_amd.separation import dc_masks
+
+            def step_km():
+                logmag, ri = stft_logmag(wav, NFFT, HOP)
+                emb, = model([logmag])
+                return mask_istft(ri, dc_masks(emb, logmag), HOP, N_SAMPLES)
+            step_km()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                step_km()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_km = e0.elapsed_time(e1) / 5
+            dc_e2e = {"ms_per_step": ms_km, "x_real_time": B * (T_FRAMES * HOP / SR) / ms_km * 1e3, "launch": "eager",
+                      "what": "waveform -> STFT -> BLSTM -> embedding -> threshold + 2-means (20 Lloyd iterations, on the "
+                              "device) -> binary masks -> mask-apply + iSTFT"}
+
         # ---- per-kernel timing leg (HIP events on the launch stream), outside the timed region
         roof = (kernel_roofline(model.chimera if kind == "phase_net" else model, wav, dev,
                                 "chimera" if kind == "phase_net" else kind, F, H, L, B, D) if rank == 0 else None)
@@ -205,6 +228,8 @@ def main():
     result["config"]["xcd_placement_independent_protocol_used"] = _XcdStatus.safe_protocol_seen
     if rank == 0:
         result["roofline"] = roof
+        if dc_e2e is not None:
+            result["separate_dc_with_device_kmeans"] = dc_e2e
         if world == 1 and not args.no_cpu_baseline and kind != "phase_net":
             result["cpu_baseline"] = cpu_baseline(sd, kind, wav_np, bin_masks.cpu().numpy())
         print(json.dumps(result))
