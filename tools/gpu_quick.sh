@@ -1,6 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2> gpurun_out/b.err | python -c "
-import json,sys
-r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['value'], r.get('separate_dc_with_device_kmeans'))"
-tail -2 gpurun_out/b.err
+timeout 600 python -m pytest tests -m gpu -x -q -k "cluster or separate or dc_" 2>&1 | tail -2
+timeout 300 python tools/separate_probe.py 2>&1 | grep -v amdgpu.ids | tail -2
