@@ -596,8 +596,11 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   hipStream_t st = (hipStream_t)stream;
   const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1) + 1;
   float* w = (float*)ws;
-  hipLaunchKernelGGL(kmeans2_init_kernel, dim3((unsigned)B), dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w,
-                     stride);
+  const dim3 sgrid(km::NBLK, (unsigned)B);
+  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride);
+  hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride);
 #define ONSSEN_KM_ASSIGN(MODE_, OUT_)                                                                                      \
   do {                                                                                                                   \
     if (D == 20) hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 20>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, \
@@ -607,7 +610,7 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   } while (0)
   for (int it = 0; it < iters; ++it) {
     ONSSEN_KM_ASSIGN(0, (float*)nullptr);
-    hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(128), 0, st, D, km::NBLK, w, stride);
+    hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(256), 0, st, D, km::NBLK, w, stride);
   }
   ONSSEN_KM_ASSIGN(1, masks);
 #undef ONSSEN_KM_ASSIGN
