@@ -241,9 +241,10 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
  *   sum |mask_x * mag_mix - t_1| + sum |mask_y * mag_mix - t_2|,  t_s = mag_s (MSA: cos_* = NULL) or
  *   min(mag_mix, relu(mag_s * cos_s)) (PSA).  Replaces onssen/loss/loss_chimera.py:25-29 and :53-57.
  *   mask element (b, e) at mask_* + b*m_sb + e*m_se (the strided views of the (B,T,F,2) mask buffer); maps (B, TF). */
+size_t onssen_loss_mask_workspace_bytes(int B);
 int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
                          const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
-                         float* out, void* stream);
+                         float* out, void* ws, size_t ws_bytes, void* stream);
 size_t onssen_loss_dc_workspace_bytes(int B);
 int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
                        float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream);

@@ -42,7 +42,8 @@ SIGNATURES = {
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
-    "onssen_loss_mask_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "onssen_loss_mask_workspace_bytes": (_sz, [_i]),
+    "onssen_loss_mask_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_workspace_bytes": (_sz, [_i]),
     "onssen_batch_sdr_workspace_bytes": (_sz, [_i]),
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -97,8 +98,12 @@ class Lib:
         self.check(self.dll.onssen_batch_sdr_f32(est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream),
                    "onssen_batch_sdr_f32")
 
-    def loss_mask(self, ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, stream):
-        self.check(self.dll.onssen_loss_mask_f32(ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, stream), "onssen_loss_mask_f32")
+    def loss_mask_workspace_bytes(self, B):
+        return int(self.dll.onssen_loss_mask_workspace_bytes(B))
+
+    def loss_mask(self, ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_loss_mask_f32(ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, ws, ws_bytes, stream),
+                   "onssen_loss_mask_f32")
 
     def loss_dc_workspace_bytes(self, B):
         return int(self.dll.onssen_loss_dc_workspace_bytes(B))

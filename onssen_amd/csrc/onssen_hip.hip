@@ -368,14 +368,20 @@ int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, 
 }
 
 
+size_t onssen_loss_mask_workspace_bytes(int B) { return B > 0 ? (size_t)B * 32 * 4 * sizeof(float) : 0; }
+
 int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
                          const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
-                         float* out, void* stream) {
-  if (!mask_a || !mask_b || !mag_mix || !mag_s1 || !mag_s2 || !out || B <= 0 || TF <= 0 || ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
+                         float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!mask_a || !mask_b || !mag_mix || !mag_s1 || !mag_s2 || !out || !ws || B <= 0 || TF <= 0 ||
+      ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
     return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_loss_mask_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
-  hipLaunchKernelGGL(loss_mask_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, mask_a, mask_b, (long)m_sb,
-                     (long)m_se, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, TF, out);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_mask_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, mask_a, mask_b, (long)m_sb, (long)m_se, mag_mix,
+                     mag_s1, mag_s2, cos_s1, cos_s2, TF, (float*)ws);
+  hipLaunchKernelGGL(loss_mask_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)ws, 32, out);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

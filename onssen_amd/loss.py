@@ -79,10 +79,12 @@ def _mask_term_hip(mask_A, mask_B, mag_mix, s1, s2, c1=None, c2=None):
     f32 = lambda t: None if t is None else t.float().contiguous()
     mag, s1, s2, c1, c2 = f32(mag_mix), f32(s1), f32(s2), f32(c1), f32(c2)
     out = torch.empty(B, device=mag.device, dtype=torch.float32)
+    lib = get_lib()
+    ws = torch.empty(lib.loss_mask_workspace_bytes(B), dtype=torch.uint8, device=mag.device)
     # element (b, e = t*F + f) of a mask view sits at b*stride(0) + e*stride(2) when stride(1) = F*stride(2)
-    get_lib().loss_mask(mask_A.data_ptr(), mask_B.data_ptr(), mask_A.stride(0), mask_A.stride(2), mag.data_ptr(), s1.data_ptr(),
-                        s2.data_ptr(), c1.data_ptr() if c1 is not None else None, c2.data_ptr() if c2 is not None else None,
-                        B, TF, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    lib.loss_mask(mask_A.data_ptr(), mask_B.data_ptr(), mask_A.stride(0), mask_A.stride(2), mag.data_ptr(), s1.data_ptr(),
+                  s2.data_ptr(), c1.data_ptr() if c1 is not None else None, c2.data_ptr() if c2 is not None else None,
+                  B, TF, out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     return out
 
 

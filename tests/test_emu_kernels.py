@@ -445,8 +445,9 @@ def test_loss_mask_term(lib, psa):
     c1, c2 = rand(rng, B, TF).clip(-1, 1), rand(rng, B, TF).clip(-1, 1)
     out = np.full(B, np.nan, np.float32)
     ma, mb = masks[..., 0], masks[..., 1]
+    ws = aligned_f32(lib.loss_mask_workspace_bytes(B) // 4 + 64)
     lib.loss_mask(P(masks), masks.ctypes.data + 4, 2 * TF, 2, P(mag), P(s1), P(s2), P(c1) if psa else None, P(c2) if psa else None,
-                  B, TF, P(out), None)
+                  B, TF, P(out), P(ws), ws.nbytes, None)
     t1, t2 = (np.minimum(mag, np.maximum(s1 * c1, 0)), np.minimum(mag, np.maximum(s2 * c2, 0))) if psa else (s1, s2)
     l1 = lambda a: np.abs(a.astype(np.float64)).sum(1)
     ref = np.minimum(l1(ma * mag - t1) + l1(mb * mag - t2), l1(mb * mag - t1) + l1(ma * mag - t2))
