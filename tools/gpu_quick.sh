@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-timeout 300 python tools/separate_probe.py 2>&1 | grep -v amdgpu.ids | tail -1
+ONSSEN_X3P_WDIRECT=1 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "x3_image" 2>&1 | tail -2
+timeout 200 python tools/gemm_probe2.py 2>&1 | grep -v amdgpu.ids | tail -5
+ONSSEN_X3P_WDIRECT=1 timeout 200 python tools/gemm_probe2.py 2>&1 | grep -v amdgpu.ids | tail -5
