@@ -64,8 +64,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override chunks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "bf16x3"), choices=["f32", "bf16x3"],
-                    help="f32 = exact-fp32 MFMA; bf16x3 = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate)")
+    ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
+                    help="f32 = exact-fp32 MFMA; bf16x3 = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate); "
+                         "bf16 = opt-in plain bf16 products (fp32 accumulate), outside the 1e-4 parity contract")
     args = ap.parse_args()
 
     os.environ["ONSSEN_PRECISION"] = args.precision
@@ -203,7 +204,8 @@ def main():
         "sep_hours_per_s": audio_s / elapsed / 3600.0,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate)",
+        "dtype": {"f32": "f32", "bf16": "bf16 products, fp32 accumulate / gates / state (opt-in, below the 1e-4 parity contract)",
+                  "bf16x3": "f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, {SR // 1000} kHz STFT "
                                f"{NFFT}/{HOP}, {B} x {T_FRAMES}-frame chunks per GPU; step = STFT+log-mag -> BLSTM "
@@ -257,6 +259,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     pk = model._packed.get(ug)
     Hp, NP = pk.Hp, pk.NP
     x3 = bool(flags & 2)
+    bf16_only = bool(flags & _abi.BLSTM_BF16)          # opt-in plain bf16 products
+    ebf = _abi.EPI_BF16 if bf16_only else 0
     wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if x3 else pk.wih
     whh = pk.whh_x3 if x3 else pk.whh
 
@@ -305,18 +309,18 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
 
         def gemm0():       # layer 0 as the stack runs it: split the features, then the GEMM
             lib.x3_image(xin.data_ptr(), xin.stride(1), xin.stride(0), B, T * B, F, img_x.data_ptr(), st())
-            lib.linear_x3p(img_x.data_ptr(), T * B, F, pk.wih_img[0].data_ptr(), pk.bias[0].data_ptr(), 2 * NP, 0, 0, 1e-12,
+            lib.linear_x3p(img_x.data_ptr(), T * B, F, pk.wih_img[0].data_ptr(), pk.bias[0].data_ptr(), 2 * NP, ebf, 0, 1e-12,
                            gbuf.data_ptr(), B, B * 2 * NP, 2 * NP, st())
 
         def gemm_in():
             if lyr == 0:
                 gemm0()
             else:
-                lib.linear_x3p(img_y.data_ptr(), T * B, K1, pk.wih_img[1].data_ptr(), pk.bias[1].data_ptr(), 2 * NP, 0, 0,
+                lib.linear_x3p(img_y.data_ptr(), T * B, K1, pk.wih_img[1].data_ptr(), pk.bias[1].data_ptr(), 2 * NP, ebf, 0,
                                1e-12, gbuf.data_ptr(), B, B * 2 * NP, 2 * NP, st())
 
         def head():
-            lib.linear_x3p(img_y.data_ptr(), T * B, K1, hp.img.data_ptr(), hp.b.data_ptr(), hp.N, 1, D, 1e-12,
+            lib.linear_x3p(img_y.data_ptr(), T * B, K1, hp.img.data_ptr(), hp.b.data_ptr(), hp.N, 1 | ebf, D, 1e-12,
                            out.data_ptr(), B, hp.N, T * hp.N, st())
     else:
         def image_in():
@@ -373,11 +377,11 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     launches = -(-B // 64) if xcd else T
     # ceiling for ALGORITHMIC (fp32-equivalent) FLOPs: the exact-fp32 MFMA rate, or a third of the dense bf16
     # MFMA rate when every product is three bf16 MFMAs
-    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS if bf16_only else BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
     rec = {"kernel": "lstm_xcd_kernel" if xcd else "lstm_step_kernel", "bound": "mfma",
            "achieved": flop_rec / t_rec / 1e12, "peak": peak, "unit": "TFLOP/s",
            "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
-           "peak_note": "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
+           "peak_note": "dense bf16 MFMA 2500 TF" if bf16_only else "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
            "bound_note": "a serial chain of T dependent time steps: the kernel is bound by the per-step exchange latency "
                          "(two L2 round trips + barrier), not by MFMA issue or HBM -- see DESIGN.md",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,

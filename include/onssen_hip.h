@@ -65,6 +65,10 @@ extern "C" {
 #define ONSSEN_BLSTM_FUSE_TAIL 32   /* (with FUSE_IN0, in_dim = 32k + 1, e.g. F = 129) the lone last input column is a rank-1
                                      update on the VALU instead of a whole MFMA k-chunk: bias_p_host[0] then holds 4*NP
                                      floats -- the bias, then column in_dim-1 of the packed W_ih ([2*NP]). */
+#define ONSSEN_BLSTM_BF16 64        /* (with BF16X3 | XCD) OPT-IN reduced precision: every product of the stack (input
+                                     projections, h W_hh^T) uses the bf16 hi halves only -- one MFMA instead of
+                                     three, bf16-grade results (~1e-2 relative), outside the 1e-4 parity contract.
+                                     Same images, same workspace; accumulation, gates and cell state stay fp32. */
 /* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
  * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
  * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
@@ -73,6 +77,8 @@ extern "C" {
 #define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
 #define ONSSEN_EPI_L2NORM 1   /* ... then x / max(||x||_2, eps) over `group` consecutive outputs        */
 #define ONSSEN_EPI_SIGMOID 2  /* ... then logistic                                                      */
+#define ONSSEN_EPI_BF16 0x100 /* OR-ed into `mode` of onssen_linear_x3p: plain bf16 products (the hi halves of the x3 images only,
+                                 fp32 accumulate; ~2^-9 relative per product) instead of split-bf16                       */
 #define ONSSEN_EPI_RELU 3     /* ... then max(x, 0), times `resid` (laid out like C) if given -- onssen_linear_f32 only
                                  (enhance: fc_pre / fc_post, onssen/nn/enhancement.py:49-51)           */
 

@@ -8,12 +8,14 @@ imports torch, so the same binding drives the product library
 import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
+EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
 ABI_VERSION = 3
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
 BLSTM_FUSE_IN0 = 16
 BLSTM_FUSE_TAIL = 32
+BLSTM_BF16 = 64
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t

@@ -297,6 +297,8 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   if (!aligned16(a_img) || !aligned16(w_img)) return ONSSEN_E_ALIGN;
   const int KB = ceil_div(K, 32);
   if ((long)lxp::BM * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
+  const bool bf16_only = (mode & ONSSEN_EPI_BF16) != 0;   // plain bf16 products: hi halves only
+  mode &= ~ONSSEN_EPI_BF16;
   if (mode == ONSSEN_EPI_L2NORM) {
     if (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4 || (N % group) != 0) return ONSSEN_E_ARG;
   } else if (mode != ONSSEN_EPI_BIAS && mode != ONSSEN_EPI_SIGMOID) {
@@ -312,10 +314,12 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   static const int xp_wms = getenv("ONSSEN_X3P_WAVES") && atoi(getenv("ONSSEN_X3P_WAVES")) == 4 ? 2 : 4;   // 8 waves unless =4
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(128 * xp_wms);
   hipStream_t st = (hipStream_t)stream;
-#define ONSSEN_XP(MODE_)                                                                           \
-  do {                                                                                             \
-    if (xp_wms == 4) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 4>), grid, block, 0, st, p);     \
-    else hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 2>), grid, block, 0, st, p);                 \
+#define ONSSEN_XP(MODE_)                                                                                       \
+  do {                                                                                                         \
+    if (xp_wms == 4 && bf16_only) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 4, 1>), grid, block, 0, st, p);    \
+    else if (xp_wms == 4) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 4, 3>), grid, block, 0, st, p);           \
+    else if (bf16_only) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 2, 1>), grid, block, 0, st, p);             \
+    else hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 2, 3>), grid, block, 0, st, p);                            \
   } while (0)
   if (mode == ONSSEN_EPI_BIAS) ONSSEN_XP(ONSSEN_EPI_BIAS);
   else if (mode == ONSSEN_EPI_L2NORM) ONSSEN_XP(ONSSEN_EPI_L2NORM);
@@ -468,6 +472,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
   // XCD form: activations travel between the layers (and on to the heads) as x3 images written by the recurrence
   // epilogue; wih_p_host[l] is then the x3 image of the [2*NP][K_l] input-projection matrix
   const bool images = x3 && (flags & ONSSEN_BLSTM_XCD);
+  const bool bf16_only = images && (flags & ONSSEN_BLSTM_BF16);   // plain bf16 products instead of the three-term split
   uint16_t* img_x = (uint16_t*)((char*)ws + wl.off_imgx);
   uint16_t* img_ab[2] = {(uint16_t*)((char*)ws + wl.off_imga), (uint16_t*)((char*)ws + wl.off_imgb)};
   for (int l = 0; l < L; ++l) {
@@ -485,7 +490,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       }
       if (fuse0) rc = ONSSEN_OK;   // x_t W_ih^T is computed inside the recurrence launch: no G, no GEMM
       else rc = onssen_linear_x3p(a_img, T * B, l == 0 ? in_dim : 2 * Hp, (const uint16_t*)wih_p_host[l], bias_p_host[l],
-                             2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G, B, (int64_t)B * 2 * NP, 2 * NP, stream);
+                             2 * NP, ONSSEN_EPI_BIAS | (bf16_only ? ONSSEN_EPI_BF16 : 0), 0, 0.f, G, B, (int64_t)B * 2 * NP, 2 * NP, stream);
     } else if (x3) {   // wih_p_host[l]: split-bf16 planes [2][2*NP][ld], ld = K rounded up to 32
       const int K = l == 0 ? in_dim : 2 * Hp, ld = ceil_div(K, 32) * 32;
       rc = onssen_linear_bf16x3(l == 0 ? x : yin, l == 0 ? xs_t : (int64_t)B * 2 * Hp, l == 0 ? xs_b : 2 * Hp, B, T * B,
@@ -517,6 +522,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       xa.KCM = vtail ? xa.KC0 - 1 : xa.KC0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
       xa.wtail = vtail ? bias_p_host[0] + 2 * NP : nullptr;
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
+      xa.terms = bf16_only ? 1 : 3;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
       // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase

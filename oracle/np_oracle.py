@@ -145,20 +145,31 @@ def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
-def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
+def bf16_round(a):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: what the opt-in ONSSEN_PRECISION=bf16 mode
+    feeds the matrix cores (not a reference function; used to restate that mode's arithmetic for its tests)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse, rnd=None):
     """One direction of one nn.LSTM layer (batch_first, zero initial state).
     Gate row order in the 4H axis is i, f, g, o; the two bias vectors add.
-    x: (B, T, In) -> (B, T, H).  (onssen/nn/deep_clustering.py:15-22,35.)"""
+    x: (B, T, In) -> (B, T, H).  (onssen/nn/deep_clustering.py:15-22,35.)
+    ``rnd`` (default None = the reference's arithmetic) rounds the operands of the two matrix products."""
     B, T, _ = x.shape
     H = w_hh.shape[1]
     dt = x.dtype
+    if rnd is not None:
+        x, w_ih, w_hh = rnd(x), rnd(w_ih), rnd(w_hh)
     gx = x @ w_ih.T + (b_ih + b_hh)
     h = np.zeros((B, H), dtype=dt)
     c = np.zeros((B, H), dtype=dt)
     out = np.empty((B, T, H), dtype=dt)
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        g = gx[:, t] + h @ w_hh.T
+        g = gx[:, t] + (h if rnd is None else rnd(h)) @ w_hh.T
         i = _sigmoid(g[:, 0:H])
         f = _sigmoid(g[:, H:2 * H])
         gg = np.tanh(g[:, 2 * H:3 * H])
@@ -169,7 +180,7 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
     return out
 
 
-def blstm_stack(x, sd, prefix, num_layers, collect=None):
+def blstm_stack(x, sd, prefix, num_layers, collect=None, rnd=None):
     """nn.LSTM(bidirectional=True, batch_first=True) in eval mode (inter-layer
     dropout inactive): layer output = [forward | reverse] on the last axis,
     which feeds the next layer.  ``sd`` is a reference-layout state_dict of
@@ -180,7 +191,7 @@ def blstm_stack(x, sd, prefix, num_layers, collect=None):
             outs.append(lstm_direction(
                 x,
                 sd[f"{prefix}weight_ih_l{k}{sfx}"], sd[f"{prefix}weight_hh_l{k}{sfx}"],
-                sd[f"{prefix}bias_ih_l{k}{sfx}"], sd[f"{prefix}bias_hh_l{k}{sfx}"], rev))
+                sd[f"{prefix}bias_ih_l{k}{sfx}"], sd[f"{prefix}bias_hh_l{k}{sfx}"], rev, rnd))
         x = np.concatenate(outs, axis=-1)
         if collect is not None:
             collect.append(x)

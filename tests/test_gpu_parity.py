@@ -142,6 +142,29 @@ def test_linear_x3_image_kernel(dev, M, K, N, mode, group):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-5, rtol=1e-4)
 
 
+def test_linear_x3_image_kernel_plain_bf16_products(dev):
+    """ONSSEN_EPI_BF16: only the hi halves of the images are multiplied -- exactly the GEMM of the bf16-rounded operands
+    with fp32 accumulation."""
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    M, K, N = 700, 1200, 480
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / K ** 0.5; bias = torch.randn(N, generator=g)
+    Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
+    KB = (K + 31) // 32
+    a_img = torch.empty(M, KB, 2, 32, device=dev, dtype=torch.int16); w_img = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.x3_image(Ad.data_ptr(), K, 0, 1, M, K, a_img.data_ptr(), st)
+    lib.x3_image(Wd.data_ptr(), K, 0, 1, N, K, w_img.data_ptr(), st)
+    out = torch.full((M, N), float("nan"), device=dev)
+    lib.linear_x3p(a_img.data_ptr(), M, K, w_img.data_ptr(), bd.data_ptr(), N, _abi.EPI_BIAS | _abi.EPI_BF16, 0, 0.0,
+                   out.data_ptr(), 1, N, 0, st)
+    ref = A.bfloat16().double() @ W.bfloat16().double().T + bias.double()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+    full = A.double() @ W.double().T + bias.double()
+    assert (out.cpu().double() - full).abs().max() < 0.05       # ... and ~2^-9 per product away from the fp32 result
+
+
 # ---------------------------------------------------------------- golden vectors of the reference
 @pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
 def test_dc_tiny_golden(dev, golden_dir, prec, name):
@@ -197,6 +220,43 @@ def test_full_size_golden_subsample(dev, golden_dir, prec, tag, kind):
     if kind == "chimera":
         np.testing.assert_allclose(outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], atol=1e-5, rtol=1e-4)
         np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg3_chimera_L4", "chimera")])
+def test_optin_bf16_mode_full_size(dev, golden_dir, monkeypatch, tag, kind):
+    """ONSSEN_PRECISION=bf16 (opt-in; BASELINE cfg2's literal dtype): plain bf16 products, fp32 accumulate / gates / state.
+    OUTSIDE the 1e-4 contract -- its own tolerance: per-vector rel-L2 <= 1.5e-2 against the fp32 reference
+    (the reference itself run in bf16 shows 3.7e-3 mean / 9.8e-3 max); masks within 1e-2 abs."""
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    z = np.load(f"{golden_dir}/g2_{tag}.npz")
+    m, _ = build(kind, z, dev)
+    x = logmag_input(int(z["x_seed"]), int(z["B"]), int(z["T"]))
+    with torch.no_grad():
+        outs = m([torch.from_numpy(x).to(dev)])
+    emb = outs[0].cpu().numpy()
+    rl2 = rel_l2(emb[:, ::40, ::16, :], z["emb_sub"])
+    print(f"[bf16] {tag}: per-vector rel-L2 mean {rl2.mean():.3e} max {rl2.max():.3e}")
+    assert 1e-4 < rl2.max() < 1.5e-2        # engaged (not the split-bf16 path), and inside the mode's own budget
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=-1), 1.0, atol=1e-5)   # normalisation stays fp32
+    if kind == "chimera":
+        np.testing.assert_allclose(outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], atol=1e-2)
+        np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-2)
+
+
+def test_optin_bf16_mode_ragged_fused(dev, monkeypatch):
+    """The same mode on a ragged batch > 32 rows (first layer's input projection fused into the recurrence launch)."""
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    cfg = dict(F=129, H=128, L=2, D=20, C=2, seed=3, gain=1.5)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = logmag_input(11, 70, 9)
+    ref = TC.deep_clustering_forward(sd, x).numpy()
+    with torch.no_grad():
+        emb, = m([torch.from_numpy(x).to(dev)])
+    rl2 = rel_l2(emb.cpu().numpy(), ref)
+    print(f"[bf16] ragged fused: per-vector rel-L2 mean {rl2.mean():.3e} max {rl2.max():.3e}")
+    assert 1e-4 < rl2.max() < 1.5e-2
 
 
 # ---------------------------------------------------------------- oracle at other shapes / edge cases
