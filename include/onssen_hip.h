@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 3
+#define ONSSEN_ABI_VERSION 4
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -200,6 +200,29 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
                              void* stream);
+
+/* ---- Training: nn.LSTM forward with saved state and its backward recurrence ------------------
+ * What `loss.backward()` does for `self.rnn` (onssen/utils/train.py:80-84; nn.LSTM autograd), one layer at a time so that
+ * the caller can apply the inter-layer dropout (nn.LSTM(dropout=0.3), onssen/nn/deep_clustering.py:15-22) in between.
+ *
+ * onssen_lstm_train_forward_f32: one bidirectional layer in the ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3 form (same
+ *   operands as onssen_blstm_forward_f32 with L = 1: wih_img = x3 image of the packed [2*NP][in_dim] projection,
+ *   whh_x3 = the two directions' onssen_lstm_pack_whh_bf16x3 images, bias_p [2*NP]; ws as for L = 1).  Besides
+ *   y [T][B][2][Hp] it leaves gates [T][B][2][NP] = the activations (i, f, g, o) of every unit in the packed column
+ *   layout of G (column = ugi*4*ug + ju*4 + gate) and cs [T][B][2][Hp] = the cell states c_t.
+ * onssen_lstm_train_backward_f32: given dy [T][B][2][Hp] = dL/dy (padded units 0), overwrites `gates_dp` in place with
+ *   dL/d(pre-activation) (same layout) -- the operand of the weight / input gradient GEMMs:
+ *     dW_ih(packed) = dP^T x,  dW_hh(packed, per direction) = dP_d^T h_prev,  db = sum_rows dP,  dx = dP W_ih(packed).
+ *   whhT: the two directions' onssen_lstm_pack_whhT_bf16x3 images (onssen_lstm_whhT_elems uint16 each), back to back.
+ *   One launch per time step (T launches on `stream`); split-bf16 products, fp32 accumulation and state. */
+int onssen_lstm_train_forward_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
+                                  int ug, const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,
+                                  float* gates, float* cs, void* ws, size_t ws_bytes, void* stream);
+int64_t onssen_lstm_whhT_elems(int H, int ug);
+int onssen_lstm_pack_whhT_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream);
+size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug);
+int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whhT, const float* dy, float* gates_dp,
+                                   const float* cs, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 glue  recurrent input of the phase network for all C speakers at once:

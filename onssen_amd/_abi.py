@@ -9,7 +9,7 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 3
+ABI_VERSION = 4
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -40,6 +40,11 @@ SIGNATURES = {
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
+    "onssen_lstm_pack_whhT_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
+    "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -163,6 +168,24 @@ class Lib:
                                                      arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, flags, stream),
                    "onssen_blstm_forward_f32")
 
+
+    # ---- training (row N1)
+    def lstm_train_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates, cs, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_lstm_train_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates,
+                                                          cs, ws, ws_bytes, stream), "onssen_lstm_train_forward_f32")
+
+    def lstm_whhT_elems(self, H, ug):
+        return int(self.dll.onssen_lstm_whhT_elems(H, ug))
+
+    def lstm_pack_whhT_bf16x3(self, w_hh, H, ug, out, stream):
+        self.check(self.dll.onssen_lstm_pack_whhT_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whhT_bf16x3")
+
+    def lstm_train_backward_workspace_bytes(self, B, H, ug):
+        return int(self.dll.onssen_lstm_train_backward_workspace_bytes(B, H, ug))
+
+    def lstm_train_backward(self, B, T, H, ug, whhT, dy, gates_dp, cs, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whhT, dy, gates_dp, cs, ws, ws_bytes, stream),
+                   "onssen_lstm_train_backward_f32")
 
     def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
         self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,

@@ -58,6 +58,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #include "gemm.inc"
 #include "labels_cluster.inc"
 #include "lstm.inc"
+#include "lstm_bwd.inc"
 #include "fft.inc"
 #include "loss_sdr.inc"
 
@@ -428,10 +429,10 @@ int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t*
   return ONSSEN_OK;
 }
 
-int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
-                             int ug, const float* const* wih_p_host, const float* const* whh_p_host,
-                             const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
-                             void* stream) {
+static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
+                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
+                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
+                              void* stream, float* save_g, float* save_c) {
   int Hp, NP, KQ;
   int64_t we;
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
@@ -523,6 +524,7 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
       xa.wtail = vtail ? bias_p_host[0] + 2 * NP : nullptr;
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
       xa.terms = bf16_only ? 1 : 3;
+      xa.save_g = save_g; xa.save_c = save_c;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
       // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase
@@ -562,6 +564,80 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
 #undef ONSSEN_STEPS
     if (rc != ONSSEN_OK) return rc;
   }
+  return ONSSEN_OK;
+}
+
+int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
+                             int ug, const float* const* wih_p_host, const float* const* whh_p_host,
+                             const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
+                             void* stream) {
+  return blstm_forward_impl(x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_p_host, whh_p_host, bias_p_host, y, ws, ws_bytes,
+                            flags, stream, nullptr, nullptr);
+}
+
+// ---- training: one layer forward with saved state, and its backward recurrence ----------------
+int onssen_lstm_train_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
+                                  const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,
+                                  float* gates, float* cs, void* ws, size_t ws_bytes, void* stream) {
+  if (!y || !gates || !cs || !aligned16(gates)) return ONSSEN_E_ARG;
+  const float* wih[1] = {(const float*)wih_img};
+  const float* whh[1] = {(const float*)whh_x3};
+  const float* bias[1] = {bias_p};
+  return blstm_forward_impl(x, xs_b, xs_t, B, T, in_dim, H, 1, ug, wih, whh, bias, y, ws, ws_bytes,
+                            ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD, stream, gates, cs);
+}
+
+static bool lstm_bwd_geometry(int H, int ug, int* Hp, int* NP, int* KQB, int* NUB) {
+  if (onssen_lstm_geometry(H, ug, Hp, NP, nullptr, nullptr) != ONSSEN_OK) return false;
+  *KQB = ceil_div(*NP, 32);
+  *NUB = ceil_div(*Hp, 16);
+  return true;
+}
+
+int64_t onssen_lstm_whhT_elems(int H, int ug) {
+  int Hp, NP, KQB, NUB;
+  if (!lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return 0;
+  return (int64_t)NUB * KQB * 1024;
+}
+
+int onssen_lstm_pack_whhT_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream) {
+  int Hp, NP, KQB, NUB;
+  if (!w_hh || !out || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const long n = (long)NUB * KQB * 512;
+  hipLaunchKernelGGL(pack_whhT_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_hh, H, Hp, ug, KQB, NUB, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug) {
+  int Hp, NP, KQB, NUB;
+  if (B <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return 0;
+  return align256((size_t)2 * 2 * ceil_div(B, 16) * KQB * 2048) + align256((size_t)2 * B * Hp * sizeof(float));
+}
+
+int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whhT, const float* dy, float* gates_dp,
+                                   const float* cs, void* ws, size_t ws_bytes, void* stream) {
+  int Hp, NP, KQB, NUB;
+  if (!whhT || !dy || !gates_dp || !cs || !ws || B <= 0 || T <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB))
+    return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_lstm_train_backward_workspace_bytes(B, H, ug)) return ONSSEN_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(gates_dp)) return ONSSEN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t img_bytes = align256((size_t)2 * 2 * ceil_div(B, 16) * KQB * 2048);
+  hipError_t e = hipMemsetAsync(ws, 0, img_bytes, st);   // rows past B and the K tail of the images stay zero
+  if (e != hipSuccess) return (int)e;
+  BwdArgs p;
+  p.gd = gates_dp; p.cs = cs; p.dy = dy; p.wT = whhT; p.ds = (unsigned short*)ws; p.dc = (float*)((char*)ws + img_bytes);
+  p.B = B; p.T = T; p.Hp = Hp; p.NP = NP; p.UG = ug; p.KQB = KQB; p.NUB = NUB;
+  ONSSEN_CLEAR_ERROR();
+  const dim3 grid((unsigned)NUB, 2, (unsigned)ceil_div(B, 16));
+  for (int s = 0; s < T; ++s) {
+    p.step = s;
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, st, p);
+  }
+  ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
 

@@ -133,8 +133,15 @@ class BLSTMParams(nn.Module):
         return out
 
     def autograd_forward(self, x, training):
-        """Training path (needs autograd): the stock ATen LSTM op on the ROCm
-        device.  NOT the product's inference path -- see DESIGN.md 'scope'."""
+        """Training path (needs autograd).  On a ROCm device with H <= 640: the HIP forward with saved state and the
+        HIP backward recurrence (nn/_train.py); ONSSEN_TRAIN_HIP=0, a CPU tensor or a wider layer
+        take the stock ATen LSTM op instead."""
+        if x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+            from ._train import BLSTMTrainFunction
+            if getattr(self, "_train_packed", None) is None:
+                object.__setattr__(self, "_train_packed", PackedBLSTM(self))
+            p_drop = float(self.dropout) if training and self.num_layers > 1 else 0.0
+            return BLSTMTrainFunction.apply(x, self._train_packed, p_drop, *self.flat_weights())
         B = x.shape[0]
         z = x.new_zeros(2 * self.num_layers, B, self.hidden_size)
         out, _, _ = torch._VF.lstm(x, (z, z), self.flat_weights(), True, self.num_layers,
@@ -165,6 +172,7 @@ class _PackedImages:
     def __init__(self, params, ug):
         self.p, self.ug = params, ug
         self.key = None
+        self._whhT = None
 
     def get(self):
         p, lib = self.p, get_lib()
@@ -214,7 +222,24 @@ class _PackedImages:
                 # FUSE_TAIL (in_dim = 32k + 1): the bias followed by the last column of the packed W_ih
                 self.bias0_tail = torch.cat([c.reshape(-1), a[:, :, in_l - 1].reshape(-1)]).contiguous() if in_l % 32 == 1 and in_l > 1 else None
         self.key = key
+        self._whhT = None
         return self
+
+    def whhT(self):
+        """Per layer, both directions' B-fragment images of W_hh for the backward recurrence (training only; lazily)."""
+        if self._whhT is None:
+            p, lib = self.p, get_lib()
+            flat = p.flat_weights()
+            n = lib.lstm_whhT_elems(p.hidden_size, self.ug)
+            out = []
+            for l in range(p.num_layers):
+                img = torch.empty(2, n, device=flat[0].device, dtype=torch.int16)
+                for d in range(2):
+                    w_hh = flat[(2 * l + d) * 4 + 1].detach().contiguous()
+                    lib.lstm_pack_whhT_bf16x3(w_hh.data_ptr(), p.hidden_size, self.ug, img[d].data_ptr(), _stream())
+                out.append(img)
+            self._whhT = out
+        return self._whhT
 
 
 class PackedHead:

@@ -461,3 +461,69 @@ def test_loss_mask_term(lib, psa):
     l1 = lambda a: np.abs(a.astype(np.float64)).sum(1)
     ref = np.minimum(l1(ma * mag - t1) + l1(mb * mag - t2), l1(mb * mag - t1) + l1(ma * mag - t2))
     np.testing.assert_allclose(out, ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 5), (24, 8, 18, 3)])
+def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T):
+    """Row N1: training forward (saved gates / cell states) + backward recurrence of one bidirectional layer against
+    nn.LSTM autograd on the CPU (the reference's `loss.backward()`, onssen/utils/train.py:80-84).  Split-bf16 products:
+    gradients within 2e-4 of their largest entry."""
+    import torch
+    from onssen_amd.nn._train import layer_gradients
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
+    monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")
+    F = 9
+    sd = make_state_dict("chimera", F, H, 1, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(5)
+    x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    Kp = (F + 3) // 4 * 4
+    a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
+    nT = lib.lstm_whhT_elems(H, ug)
+    wT = _shm((2, nT), dtype=np.uint16)
+    scratch = _shm((we,))
+    for d, sfx in enumerate(("", "_reverse")):
+        srcs = []
+        for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            v = sd[f"rnn.{n}_l0{sfx}"]
+            sv = _shm(v.shape); sv[...] = v
+            srcs.append(sv)
+        lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), F, 0, H, ug, P(a[d]), P(scratch), P(c[d]), None)
+        lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
+        lib.lstm_pack_whhT_bf16x3(P(srcs[1]), H, ug, P(wT[d]), None)
+    pl = _shm((2 * NP, (F + 31) // 32, 2, 32), dtype=np.uint16)
+    lib.x3_image(P(a), Kp, 0, 1, 2 * NP, F, P(pl), None)
+    ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, 1, ug) // 4 + 64,))
+    y, gates, cs = _shm((T, B, 2, Hp), fill=np.nan), _shm((T, B, 2, NP), fill=np.nan), _shm((T, B, 2, Hp), fill=np.nan)
+    lib.lstm_train_forward(P(x), T * F, F, B, T, F, H, ug, P(pl), P(b3), P(c), P(y), P(gates), P(cs), P(ws), ws.nbytes, None)
+    assert ws.view(np.uint32)[280] == 0
+
+    # the reference: nn.LSTM on the CPU, a random linear functional of its output as the loss
+    lstm = torch.nn.LSTM(F, H, 1, batch_first=True, bidirectional=True)
+    lstm.load_state_dict({k[4:]: torch.from_numpy(np.asarray(v)) for k, v in sd.items() if k.startswith("rnn.")})
+    xt = torch.from_numpy(np.array(x)).requires_grad_(True)
+    yr, _ = lstm(xt)
+    R = torch.from_numpy(rand(rng, B, T, 2 * H))
+    (yr * R).sum().backward()
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    assert np.abs(got - yr.detach().numpy()).max() < 2e-5
+
+    dy = _shm((T, B, 2, Hp))
+    dy[:, :, :, :H] = R.numpy().transpose(1, 0, 2).reshape(T, B, 2, H)
+    wsb = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug) // 4 + 64,))
+    lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, None)
+    w_ih = (lstm.weight_ih_l0.detach(), lstm.weight_ih_l0_reverse.detach())
+    x_rows = torch.from_numpy(np.array(x)).transpose(0, 1).reshape(T * B, F)
+    dx_rows, g = layer_gradients(torch.from_numpy(np.array(gates)), x_rows, torch.from_numpy(np.array(y)), w_ih, H, ug)
+
+    def close(a_, b_, what):
+        a_, b_ = a_.numpy(), b_.numpy()
+        assert np.abs(a_ - b_).max() <= 2e-4 * max(np.abs(b_).max(), 1e-3), (what, np.abs(a_ - b_).max(), np.abs(b_).max())
+    close(dx_rows.view(T, B, F).transpose(0, 1), xt.grad, "dx")
+    for d, sfx in enumerate(("", "_reverse")):
+        close(g[d][0], getattr(lstm, f"weight_ih_l0{sfx}").grad, f"dW_ih{sfx}")
+        close(g[d][1], getattr(lstm, f"weight_hh_l0{sfx}").grad, f"dW_hh{sfx}")
+        close(g[d][2], getattr(lstm, f"bias_ih_l0{sfx}").grad, f"db{sfx}")
+    assert np.all(np.array(gates).reshape(T, B, 2, NP // 4, 4)[:, :, :, H:, :] == 0) if ug * (Hp // ug) == Hp and H % ug == 0 else True

@@ -568,3 +568,78 @@ def test_chimera_losses_on_device_match_reference_fixture(dev, golden_dir):
         psa = loss_chimera_psa(out, [d("one_hot"), d("mag"), d("s1"), d("s2"), d("c1"), d("c2")])
     np.testing.assert_allclose(msa.cpu().numpy(), z["msa"], rtol=1e-4)
     np.testing.assert_allclose(psa.cpu().numpy(), z["psa"], rtol=1e-4)
+
+
+# ---------------------------------------------------------------- training path (row N1): HIP forward + backward
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,F,H,L", [(4, 50, 129, 600, 2), (3, 17, 129, 30, 3), (18, 9, 33, 128, 1)])
+def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L):
+    """What `loss.backward()` computes for self.rnn (onssen/utils/train.py:80-84): the HIP training path (saved-state
+    XCD forward, backward recurrence kernel, rocBLAS weight-gradient GEMMs) against nn.LSTM autograd in float64 on the
+    CPU, dropout off.  Split-bf16 products: every gradient tensor within 3e-4 of its largest entry."""
+    from onssen_amd.nn._core import BLSTMParams
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    torch.manual_seed(H + L)
+    ref = torch.nn.LSTM(F, H, L, batch_first=True, bidirectional=True).double()
+    rnn = BLSTMParams(F, H, L, dropout=0.0)
+    rnn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    rnn = rnn.to(dev)
+    x = torch.randn(B, T, F, dtype=torch.float64)
+    R = torch.randn(B, T, 2 * H, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    (yr * R).sum().backward()
+    xg = x.float().to(dev).requires_grad_(True)
+    yg = rnn.autograd_forward(xg, True)
+    (yg * R.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert (yg.detach().cpu().double() - yr.detach()).abs().max() < 2e-5
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        assert err <= 3e-4 * max(scale, 1e-6), f"{what}: max err {err:.3e} vs max |ref| {scale:.3e}"
+    close(xg.grad, xr.grad, "dx")
+    for name, p in rnn.named_parameters():
+        close(p.grad, getattr(ref, name).grad, name)
+
+
+@pytest.mark.gpu
+def test_dc_training_step_hip_vs_aten(dev, monkeypatch):
+    """One deep-clustering training forward + loss_dc + backward (dropout off so both paths see the same network): the
+    HIP BLSTM path and the stock ATen LSTM give the same loss and gradients (2e-3 of each tensor's largest entry: two
+    fp32 implementations of a T-step recurrence); with dropout on, the HIP path still trains (finite, loss decreases)."""
+    from onssen_amd import nn as onn
+    from onssen_amd.loss import loss_dc
+    torch.manual_seed(1)
+    B, T, Fq = 4, 60, 129
+    x = torch.randn(B, T, Fq, device=dev)
+    lab = torch.nn.functional.one_hot(torch.randint(0, 2, (B, T, Fq), device=dev), 2).float()
+    wt = torch.rand(B, T, Fq, device=dev)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ONSSEN_TRAIN_HIP", mode)
+        torch.manual_seed(2)
+        m = onn.deep_clustering(Fq, 600, 2, 20, dropout=0.0).to(dev).train()
+        out = m([x])
+        loss = torch.mean(loss_dc(out, [lab, wt]))      # as trainer.train does (onssen/utils/train.py:78)
+        loss.backward()
+        results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert abs(results["1"][0] - results["0"][0]) <= 1e-4 * abs(results["0"][0])
+    for k, g0 in results["0"][1].items():
+        g1 = results["1"][1][k]
+        assert (g1 - g0).abs().max().item() <= 2e-3 * max(g0.abs().max().item(), 1e-8), k
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    torch.manual_seed(3)
+    m = onn.deep_clustering(Fq, 600, 2, 20, dropout=0.3).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        loss = torch.mean(loss_dc(m([x]), [lab, wt]))
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]

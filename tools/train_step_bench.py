@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """BASELINE config 4: one deep-clustering TRAINING step -- forward, loss_dc, backward, RCCL
 all-reduce of the gradients, clip, Adam -- on synthetic wsj0-2mix batches whose features and labels come from the HIP
-front end (STFT + label kernels).  The forward/backward of the network run on stock ATen ops (autograd); this is a
-harness measurement, not the product's hot path.  One JSON line like bench.py.
+front end (STFT + label kernels).  The BLSTM stack runs on the HIP training path (saved-state forward + backward
+recurrence, onssen_amd/nn/_train.py; ONSSEN_TRAIN_HIP=0 selects the stock ATen LSTM for comparison); BatchNorm, the
+embedding head and loss_dc run on ATen autograd.  One JSON line like bench.py.
 
     python tools/train_step_bench.py [--steps K --warmup W]            # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py --gpus N
@@ -64,7 +65,9 @@ def main():
         print(json.dumps({"metric": "training real_time_factor (forward + loss_dc + backward + all-reduce + clip + Adam)",
                           "value": frames * 64 / 8000 / dt, "unit": "audio-seconds trained per wall-second, whole job",
                           "frames_per_s": frames / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32 (ATen / MIOpen autograd path)",
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": ("f32 as split-bf16 in the HIP BLSTM forward/backward recurrence, fp32 rocBLAS weight-gradient GEMMs"
+                                    if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "f32 (ATen / MIOpen autograd path)"),
+                          "blstm_path": "hip" if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "aten",
                           "data": "synthetic", "last_loss": loss,
                           "config": {"workload": f"deep_clustering {args.layers}xBLSTM-600 training, 16 x 400-frame chunks per GPU, features + labels from the HIP front end",
                                      "parallelism": f"data parallel x{world}, RCCL all-reduce of per-layer gradient buckets before clipping"}}))
