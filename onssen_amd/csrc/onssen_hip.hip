@@ -635,7 +635,7 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
   const dim3 grid((unsigned)NUB, 2, (unsigned)ceil_div(B, 16));
   for (int s = 0; s < T; ++s) {
     p.step = s;
-    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(64 * recb::NW), 0, st, p);
   }
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
