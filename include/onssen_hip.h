@@ -213,16 +213,27 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
  * onssen_lstm_train_backward_f32: given dy [T][B][2][Hp] = dL/dy (padded units 0), overwrites `gates_dp` in place with
  *   dL/d(pre-activation) (same layout) -- the operand of the weight / input gradient GEMMs:
  *     dW_ih(packed) = dP^T x,  dW_hh(packed, per direction) = dP_d^T h_prev,  db = sum_rows dP,  dx = dP W_ih(packed).
- *   whhT: the two directions' onssen_lstm_pack_whhT_bf16x3 images (onssen_lstm_whhT_elems uint16 each), back to back.
- *   One launch per time step (T launches on `stream`); split-bf16 products, fp32 accumulation and state. */
+ *   form ONSSEN_LSTM_BWD_XCD (default of the Python layer): ONE persistent launch per layer, every (direction, row
+ *     group) inside one XCD like the forward; each member keeps the rows of W_hh of its own gate columns in registers,
+ *     multiplies them with the dP it has just produced and the members reduce-scatter fp32 partial sums of dh through
+ *     the XCD's L2.  whh_img = the two directions' onssen_lstm_pack_whhR_bf16x3 images (onssen_lstm_whhR_elems uint16
+ *     each).  ws: zeroed ONCE by its owner (header words [280] / [281] report aborts / the placement-independent
+ *     protocol exactly as in onssen_blstm_forward_f32).
+ *   form ONSSEN_LSTM_BWD_STEPS: one launch per time step (T launches); whh_img = onssen_lstm_pack_whhT_bf16x3 images
+ *     (onssen_lstm_whhT_elems).  No requirements on ws contents.
+ *   Split-bf16 products, fp32 accumulation and state in both forms. */
+#define ONSSEN_LSTM_BWD_STEPS 0
+#define ONSSEN_LSTM_BWD_XCD 1
 int onssen_lstm_train_forward_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
                                   int ug, const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,
                                   float* gates, float* cs, void* ws, size_t ws_bytes, void* stream);
 int64_t onssen_lstm_whhT_elems(int H, int ug);
 int onssen_lstm_pack_whhT_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream);
-size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug);
-int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whhT, const float* dy, float* gates_dp,
-                                   const float* cs, void* ws, size_t ws_bytes, void* stream);
+int64_t onssen_lstm_whhR_elems(int H, int ug);
+int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream);
+size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form);
+int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
+                                   const float* cs, void* ws, size_t ws_bytes, int form, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 glue  recurrent input of the phase network for all C speakers at once:

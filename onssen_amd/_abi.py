@@ -16,6 +16,7 @@ BLSTM_XCD = 4
 BLSTM_FUSE_IN0 = 16
 BLSTM_FUSE_TAIL = 32
 BLSTM_BF16 = 64
+LSTM_BWD_STEPS, LSTM_BWD_XCD = 0, 1
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -43,8 +44,10 @@ SIGNATURES = {
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
     "onssen_lstm_pack_whhT_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
-    "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i]),
-    "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_lstm_whhR_elems": (_i64, [_i, _i]),
+    "onssen_lstm_pack_whhR_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
+    "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -180,11 +183,17 @@ class Lib:
     def lstm_pack_whhT_bf16x3(self, w_hh, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_whhT_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whhT_bf16x3")
 
-    def lstm_train_backward_workspace_bytes(self, B, H, ug):
-        return int(self.dll.onssen_lstm_train_backward_workspace_bytes(B, H, ug))
+    def lstm_whhR_elems(self, H, ug):
+        return int(self.dll.onssen_lstm_whhR_elems(H, ug))
 
-    def lstm_train_backward(self, B, T, H, ug, whhT, dy, gates_dp, cs, ws, ws_bytes, stream):
-        self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whhT, dy, gates_dp, cs, ws, ws_bytes, stream),
+    def lstm_pack_whhR_bf16x3(self, w_hh, H, ug, out, stream):
+        self.check(self.dll.onssen_lstm_pack_whhR_bf16x3(w_hh, H, ug, out, stream), "onssen_lstm_pack_whhR_bf16x3")
+
+    def lstm_train_backward_workspace_bytes(self, B, H, ug, form):
+        return int(self.dll.onssen_lstm_train_backward_workspace_bytes(B, H, ug, form))
+
+    def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream):
+        self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream),
                    "onssen_lstm_train_backward_f32")
 
     def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):

@@ -611,25 +611,81 @@ int onssen_lstm_pack_whhT_bf16x3(const float* w_hh, int H, int ug, uint16_t* out
   return ONSSEN_OK;
 }
 
-size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug) {
+int64_t onssen_lstm_whhR_elems(int H, int ug) {
+  int Hp, NP, KQB, NUB;
+  if (!lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return 0;
+  return (int64_t)(Hp / ug) * ceil_div(4 * ug, 32) * NUB * 1024;
+}
+
+int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream) {
+  int Hp, NP, KQB, NUB;
+  if (!w_hh || !out || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const int KC = ceil_div(4 * ug, 32);
+  const long n = (long)(Hp / ug) * KC * NUB * 512;
+  hipLaunchKernelGGL(pack_whhR_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_hh, H, Hp, ug, KC, NUB, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+static int bwd_rows_per_group(int B) {
+  int rg = B <= 16 ? 4 : B <= 32 ? 8 : 16;
+  static const int rg_env = getenv("ONSSEN_XCD_RG") ? atoi(getenv("ONSSEN_XCD_RG")) : 0;
+  if (rg_env == 4 || rg_env == 8 || rg_env == 16) rg = rg_env;
+  return rg;
+}
+
+size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form) {
   int Hp, NP, KQB, NUB;
   if (B <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return 0;
+  if (form == ONSSEN_LSTM_BWD_XCD) {
+    const int NU = Hp / ug, RG = bwd_rows_per_group(B);
+    return ONSSEN_BLSTM_WS_HEADER_BYTES + align256((size_t)8 * 2 * NU * NU * RG * ug * sizeof(float));
+  }
   return align256((size_t)2 * 2 * ceil_div(B, 16) * KQB * 2048) + align256((size_t)2 * B * Hp * sizeof(float));
 }
 
-int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whhT, const float* dy, float* gates_dp,
-                                   const float* cs, void* ws, size_t ws_bytes, void* stream) {
+int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
+                                   const float* cs, void* ws, size_t ws_bytes, int form, void* stream) {
   int Hp, NP, KQB, NUB;
-  if (!whhT || !dy || !gates_dp || !cs || !ws || B <= 0 || T <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB))
+  if (!whh_img || !dy || !gates_dp || !cs || !ws || B <= 0 || T <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB) ||
+      (form != ONSSEN_LSTM_BWD_STEPS && form != ONSSEN_LSTM_BWD_XCD))
     return ONSSEN_E_ARG;
-  if (ws_bytes < onssen_lstm_train_backward_workspace_bytes(B, H, ug)) return ONSSEN_E_WORKSPACE;
+  if (ws_bytes < onssen_lstm_train_backward_workspace_bytes(B, H, ug, form)) return ONSSEN_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(gates_dp)) return ONSSEN_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
+  if (form == ONSSEN_LSTM_BWD_XCD) {
+    if (Hp / ug > 32 || NUB > 40) return ONSSEN_E_ARG;
+    static const unsigned xcd_spin = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
+    static const int ablate_env = getenv("ONSSEN_BWD_ABLATE") ? atoi(getenv("ONSSEN_BWD_ABLATE")) : 0;
+    XcdBwdArgs xa;
+    xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
+    xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
+    xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
+    xa.spin_limit = xcd_spin; xa.ablate = ablate_env;
+    ONSSEN_CLEAR_ERROR();
+    const dim3 grid((unsigned)(8 * xa.NU));
+    for (int r0 = 0; r0 < B; r0 += 4 * xa.RG) {
+      const int rows = B - r0 < 4 * xa.RG ? B - r0 : 4 * xa.RG;
+      xa.row0 = r0;
+      xa.nbg = ceil_div(rows, xa.RG);
+      switch (ug) {
+        case 4: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<4>), grid, dim3(512), 0, st, xa); break;
+        case 8: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<8>), grid, dim3(512), 0, st, xa); break;
+        case 12: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<12>), grid, dim3(512), 0, st, xa); break;
+        case 16: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<16>), grid, dim3(512), 0, st, xa); break;
+        default: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<20>), grid, dim3(512), 0, st, xa); break;
+      }
+    }
+    ONSSEN_LAUNCH_CHECK();
+    return ONSSEN_OK;
+  }
   const size_t img_bytes = align256((size_t)2 * 2 * ceil_div(B, 16) * KQB * 2048);
   hipError_t e = hipMemsetAsync(ws, 0, img_bytes, st);   // rows past B and the K tail of the images stay zero
   if (e != hipSuccess) return (int)e;
   BwdArgs p;
-  p.gd = gates_dp; p.cs = cs; p.dy = dy; p.wT = whhT; p.ds = (unsigned short*)ws; p.dc = (float*)((char*)ws + img_bytes);
+  p.gd = gates_dp; p.cs = cs; p.dy = dy; p.wT = whh_img; p.ds = (unsigned short*)ws; p.dc = (float*)((char*)ws + img_bytes);
   p.B = B; p.T = T; p.Hp = Hp; p.NP = NP; p.UG = ug; p.KQB = KQB; p.NUB = NUB;
   ONSSEN_CLEAR_ERROR();
   const dim3 grid((unsigned)NUB, 2, (unsigned)ceil_div(B, 16));

@@ -225,21 +225,26 @@ class _PackedImages:
         self._whhT = None
         return self
 
-    def whhT(self):
-        """Per layer, both directions' B-fragment images of W_hh for the backward recurrence (training only; lazily)."""
+    def whh_bwd(self, form):
+        """Per layer, both directions' images of W_hh for the backward recurrence (training only; built lazily):
+        form LSTM_BWD_XCD -> row slices (onssen_lstm_pack_whhR_bf16x3), LSTM_BWD_STEPS -> column slices (whhT)."""
         if self._whhT is None:
+            self._whhT = {}
+        if form not in self._whhT:
             p, lib = self.p, get_lib()
             flat = p.flat_weights()
-            n = lib.lstm_whhT_elems(p.hidden_size, self.ug)
+            xcd = form == _abi.LSTM_BWD_XCD
+            n = (lib.lstm_whhR_elems if xcd else lib.lstm_whhT_elems)(p.hidden_size, self.ug)
+            pack = lib.lstm_pack_whhR_bf16x3 if xcd else lib.lstm_pack_whhT_bf16x3
             out = []
             for l in range(p.num_layers):
                 img = torch.empty(2, n, device=flat[0].device, dtype=torch.int16)
                 for d in range(2):
                     w_hh = flat[(2 * l + d) * 4 + 1].detach().contiguous()
-                    lib.lstm_pack_whhT_bf16x3(w_hh.data_ptr(), p.hidden_size, self.ug, img[d].data_ptr(), _stream())
+                    pack(w_hh.data_ptr(), p.hidden_size, self.ug, img[d].data_ptr(), _stream())
                 out.append(img)
-            self._whhT = out
-        return self._whhT
+            self._whhT[form] = out
+        return self._whhT[form]
 
 
 class PackedHead:

@@ -3,13 +3,16 @@
 What autograd does for ``self.rnn(x)`` in the reference's training loop (onssen/utils/train.py:70-84 calling
 onssen/nn/deep_clustering.py:32-35): here the forward of every layer is the XCD-local persistent recurrence with saved
 gate activations / cell states (``onssen_lstm_train_forward_f32``), the backward recurrence is
-``onssen_lstm_train_backward_f32`` (one launch per time step), and the weight / input gradient contractions -- plain
+``onssen_lstm_train_backward_f32`` (XCD-local persistent launch; one launch per time step with ONSSEN_BWD_XCD=0), and the weight / input gradient contractions -- plain
 dense GEMMs over T*B rows -- are library GEMMs (rocBLAS through ``torch.mm``) on the pre-activation gradient the
 kernel leaves.  The inter-layer dropout of ``nn.LSTM(dropout=0.3)`` (deep_clustering.py:15-22) is applied between the
 layers with torch's own generator, as ATen does."""
+import os
+
 import torch
 import torch.nn.functional as Fn
 
+from .. import _abi
 from ..hip import get_lib
 from ._core import _XcdStatus
 
@@ -120,14 +123,18 @@ class BLSTMTrainFunction(torch.autograd.Function):
         # (B,T,2H) -> time-major (T,B,2,Hp), padded units zero
         dy = dy_bt.transpose(0, 1).reshape(T, B, 2, H)
         dy = Fn.pad(dy, (0, Hp - H)).contiguous() if Hp != H else dy.contiguous()
-        wsb = _Workspace.get(("bwd", B, H), lib.lstm_train_backward_workspace_bytes(B, H, ug), dev, zero=False)
-        whhT = pk.whhT()
+        # ONSSEN_BWD_XCD=0: one launch per time step instead of the XCD-local persistent launch
+        form = _abi.LSTM_BWD_XCD if os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
+        wsb = _Workspace.get(("bwd", B, H, form), lib.lstm_train_backward_workspace_bytes(B, H, ug, form), dev, zero=True)
+        whh_img = pk.whh_bwd(form)
         grads = [None] * (8 * L)
         dx_rows = None
         for l in range(L - 1, -1, -1):
             x_rows, y, gates, cs, mask = ctx.saved_layers[l]
-            lib.lstm_train_backward(B, T, H, ug, whhT[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
-                                    wsb.data_ptr(), wsb.numel(), st)
+            lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
+                                    wsb.data_ptr(), wsb.numel(), form, st)
+            if form == _abi.LSTM_BWD_XCD:
+                _XcdStatus.post(wsb)
             w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
             dx_rows, g = layer_gradients(gates, x_rows, y, w_ih, H, ug)
             for d in range(2):

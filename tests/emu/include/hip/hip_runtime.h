@@ -274,6 +274,16 @@ static inline void __builtin_amdgcn_raw_buffer_store_b16(short v, __amdgpu_buffe
     __atomic_store_n(reinterpret_cast<short*>(r.base + voff + soff), v, __ATOMIC_SEQ_CST);
   }
 }
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  unsigned v = 0;
+  if ((unsigned long)(unsigned)voff + 4 <= (unsigned long)r.bytes)
+    v = __atomic_load_n(reinterpret_cast<unsigned*>(r.base + voff + soff), __ATOMIC_SEQ_CST);
+  return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  if ((unsigned long)(unsigned)voff + 4 <= (unsigned long)r.bytes)
+    __atomic_store_n(reinterpret_cast<unsigned*>(r.base + voff + soff), v, __ATOMIC_SEQ_CST);
+}
 static inline bool __all(bool p) {
   auto& w = emu::ctx->wbuf[emu::wave];
   w.a[emu::lane] = p ? 1.0f : 0.0f;

@@ -463,8 +463,9 @@ def test_loss_mask_term(lib, psa):
     np.testing.assert_allclose(out, ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 5), (24, 8, 18, 3)])
-def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T):
+@pytest.mark.parametrize("form,scramble", [(_abi.LSTM_BWD_XCD, "0"), (_abi.LSTM_BWD_XCD, "1"), (_abi.LSTM_BWD_STEPS, "0")])
+@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17)])
+def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T, form, scramble):
     """Row N1: training forward (saved gates / cell states) + backward recurrence of one bidirectional layer against
     nn.LSTM autograd on the CPU (the reference's `loss.backward()`, onssen/utils/train.py:80-84).  Split-bf16 products:
     gradients within 2e-4 of their largest entry."""
@@ -474,6 +475,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
     monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")
     F = 9
+    xcd = form == _abi.LSTM_BWD_XCD
     sd = make_state_dict("chimera", F, H, 1, 4, 2, seed=H + ug, gain=2.0)
     rng = np.random.default_rng(5)
     x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
@@ -481,7 +483,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     _, _, we3 = lib.lstm_geometry_x3(H, ug)
     Kp = (F + 3) // 4 * 4
     a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
-    nT = lib.lstm_whhT_elems(H, ug)
+    nT = (lib.lstm_whhR_elems if xcd else lib.lstm_whhT_elems)(H, ug)
     wT = _shm((2, nT), dtype=np.uint16)
     scratch = _shm((we,))
     for d, sfx in enumerate(("", "_reverse")):
@@ -492,7 +494,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
             srcs.append(sv)
         lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), F, 0, H, ug, P(a[d]), P(scratch), P(c[d]), None)
         lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
-        lib.lstm_pack_whhT_bf16x3(P(srcs[1]), H, ug, P(wT[d]), None)
+        (lib.lstm_pack_whhR_bf16x3 if xcd else lib.lstm_pack_whhT_bf16x3)(P(srcs[1]), H, ug, P(wT[d]), None)
     pl = _shm((2 * NP, (F + 31) // 32, 2, 32), dtype=np.uint16)
     lib.x3_image(P(a), Kp, 0, 1, 2 * NP, F, P(pl), None)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, 1, ug) // 4 + 64,))
@@ -512,8 +514,11 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
 
     dy = _shm((T, B, 2, Hp))
     dy[:, :, :, :H] = R.numpy().transpose(1, 0, 2).reshape(T, B, 2, H)
-    wsb = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug) // 4 + 64,))
-    lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, None)
+    wsb = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug, form) // 4 + 64,))
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)     # scramble=1: the placement-independent protocol
+    lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, form, None)
+    if xcd:
+        assert wsb.view(np.uint32)[280] == 0 and wsb.view(np.uint32)[281] == (1 if scramble == "1" else 0)
     w_ih = (lstm.weight_ih_l0.detach(), lstm.weight_ih_l0_reverse.detach())
     x_rows = torch.from_numpy(np.array(x)).transpose(0, 1).reshape(T * B, F)
     dx_rows, g = layer_gradients(torch.from_numpy(np.array(gates)), x_rows, torch.from_numpy(np.array(y)), w_ih, H, ug)
