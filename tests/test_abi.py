@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "onssen_hip.h")).read()
-    return sorted(set(re.findall(r"\b(onssen_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(onssen_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_and_binding_agree():
