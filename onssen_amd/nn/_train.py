@@ -51,6 +51,61 @@ def layer_gradients(dP, x_rows, y, w_ih, H, ug):
     return dx, grads
 
 
+def _x3_image(lib, st, m):
+    """Split-bf16 x3 image (onssen_x3_image_f32) of a row-major fp32 matrix (M, K)."""
+    M, K = m.shape
+    img = torch.empty(M, (K + 31) // 32, 2, 32, device=m.device, dtype=torch.int16)
+    lib.x3_image(m.data_ptr(), K, 0, 1, M, K, img.data_ptr(), st)
+    return img
+
+
+def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
+    """The same contractions as layer_gradients on the split-bf16 MFMA GEMM (onssen_linear_x3p), in the packed layouts
+    the kernels use, so that no gather of dP is needed:
+
+        [dW_ih(packed) | dW_hh(packed, both directions)] = dP^T [x | h_prev]        one GEMM, K = T*B
+        dx(padded layout of the layer below)              = dP W_ih(packed)          one GEMM, K = 2*NP
+
+    dP (T,B,2,NP); xp (T*B, Kx) the layer's input rows as its projection GEMM saw them (layer 0: the F features, deeper
+    layers: the padded [fwd(Hp) | rev(Hp)] rows); y (T,B,2,Hp); wih_p (2, NP, Kp) packed fp32 projection matrix.
+    Returns dx (T*B, Kp) or None, and per direction (dW_ih (4H, in_features), dW_hh (4H, H), db (4H))."""
+    T, B, _, NP = dP.shape
+    Hp, TB, Kx = y.shape[3], T * B, xp.shape[1]
+    dev = dP.device
+    ysh = torch.zeros_like(y)                       # h of the step before, per direction
+    if T > 1:
+        ysh[1:, :, 0] = y[:-1, :, 0]
+        ysh[:-1, :, 1] = y[1:, :, 1]
+    N1 = Kx + 2 * Hp
+    wall_t = torch.cat([xp, ysh.view(TB, 2 * Hp)], 1).t().contiguous()          # (N1, TB)
+    dp2 = dP.view(TB, 2 * NP)
+    a_t = _x3_image(lib, st, dp2.t().contiguous())                              # (2NP, TB)
+    w1 = _x3_image(lib, st, wall_t)
+    zero_bias = torch.zeros(max(N1, wih_p.shape[2]), device=dev, dtype=torch.float32)
+    out1 = torch.empty(2 * NP, N1, device=dev, dtype=torch.float32)
+    lib.linear_x3p(a_t.data_ptr(), 2 * NP, TB, w1.data_ptr(), zero_bias.data_ptr(), N1, 0, 0, 0.0, out1.data_ptr(), 1, N1, 0, st)
+    dx = None
+    if need_dx:
+        Kp = wih_p.shape[2]
+        a = _x3_image(lib, st, dp2)
+        w2 = _x3_image(lib, st, wih_p.view(2 * NP, Kp).t().contiguous())        # (Kp, 2NP)
+        dx = torch.empty(TB, Kp, device=dev, dtype=torch.float32)
+        lib.linear_x3p(a.data_ptr(), TB, 2 * NP, w2.data_ptr(), zero_bias.data_ptr(), Kp, 0, 0, 0.0, dx.data_ptr(), 1, Kp, 0, st)
+    db2 = dp2.sum(0)
+    cols = packed_columns(H, Hp, ug, dev)
+    if Kx == in_features:
+        feat = None
+    else:      # padded [fwd(Hp) | rev(Hp)] -> the reference's [fwd(H) | rev(H)]
+        feat = torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)])
+    grads = []
+    for d in range(2):
+        rows = out1.index_select(0, d * NP + cols)                               # (4H, N1) in nn.LSTM row order
+        dW_ih = rows[:, :Kx] if feat is None else rows[:, :Kx].index_select(1, feat)
+        dW_hh = rows[:, Kx + d * Hp: Kx + d * Hp + H]
+        grads.append((dW_ih.contiguous(), dW_hh.contiguous(), db2[d * NP + cols]))
+    return dx, grads
+
+
 class _Workspace:
     """Recurrence workspaces keyed by shape (their header must start out zero and is never zeroed again)."""
     cache = {}
@@ -84,7 +139,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
         x = x.contiguous()
         saved = []
         xin, xs_b, xs_t, in_l = x, T * In, In, In
-        x_rows = x.transpose(0, 1).reshape(T * B, In)                    # time-major rows for the weight gradients
+        xp = x.transpose(0, 1).reshape(T * B, In)                        # time-major rows for the weight gradients
         for l in range(L):
             nbytes = lib.blstm_workspace_bytes(B, T, in_l, H, 1, ug)
             ws = _Workspace.get(("fwd", B, T, in_l, H), nbytes, dev, zero=True)
@@ -101,12 +156,11 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 if p_drop > 0.0:
                     mask = (torch.rand_like(nxt) >= p_drop).to(torch.float32) * (1.0 / (1.0 - p_drop))
                     nxt = nxt * mask
-                saved.append((x_rows, y, gates, cs, mask))
+                saved.append((xp, y, gates, cs, mask))
                 xin, xs_b, xs_t, in_l = nxt, 2 * Hp, B * 2 * Hp, 2 * Hp
-                # the reference's feature order [fwd(H) | rev(H)] of the same rows
-                x_rows = nxt.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H) if Hp != H else nxt.view(T * B, 2 * H)
+                xp = nxt.view(T * B, 2 * Hp)                             # padded [fwd(Hp) | rev(Hp)] rows
             else:
-                saved.append((x_rows, y, gates, cs, None))
+                saved.append((xp, y, gates, cs, None))
         ctx.saved_layers = saved
         ctx.packed, ctx.ug, ctx.dims = packed, ug, (B, T, In, H, L, Hp, NP)
         ctx.flat = flat
@@ -129,23 +183,34 @@ class BLSTMTrainFunction(torch.autograd.Function):
         whh_img = pk.whh_bwd(form)
         grads = [None] * (8 * L)
         dx_rows = None
+        # weight / input gradient contractions: the split-bf16 MFMA GEMM of this package on packed layouts, or
+        # (ONSSEN_TRAIN_GEMM=blas) fp32 library GEMMs on the reference's layouts
+        use_x3 = os.environ.get("ONSSEN_TRAIN_GEMM", "x3") == "x3"
         for l in range(L - 1, -1, -1):
-            x_rows, y, gates, cs, mask = ctx.saved_layers[l]
+            xp, y, gates, cs, mask = ctx.saved_layers[l]
             lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
                                     wsb.data_ptr(), wsb.numel(), form, st)
             if form == _abi.LSTM_BWD_XCD:
                 _XcdStatus.post(wsb)
-            w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
-            dx_rows, g = layer_gradients(gates, x_rows, y, w_ih, H, ug)
+            need_dx = l > 0 or ctx.needs_input_grad[0]
+            if use_x3:
+                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx)
+            else:
+                w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
+                x_rows = xp if l == 0 or Hp == H else xp.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H)
+                dx_rows, g = layer_gradients(gates, x_rows, y, w_ih, H, ug)
             for d in range(2):
                 o = (2 * l + d) * 4
                 grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = g[d][0], g[d][1], g[d][2], g[d][2]
             if l > 0:
-                dyl = dx_rows.view(T, B, 2, H)
-                dyl = Fn.pad(dyl, (0, Hp - H)) if Hp != H else dyl
+                if use_x3:
+                    dyl = dx_rows.view(T, B, 2, Hp)              # already the padded layout of the layer below
+                else:
+                    dyl = dx_rows.view(T, B, 2, H)
+                    dyl = Fn.pad(dyl, (0, Hp - H)) if Hp != H else dyl
                 mprev = ctx.saved_layers[l - 1][4]
                 dy = (dyl.reshape(T, B, 2 * Hp) * mprev).view(T, B, 2, Hp) if mprev is not None else dyl
                 dy = dy.contiguous()
-        dx = dx_rows.view(T, B, In).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
+        dx = dx_rows[:, :In].reshape(T, B, In).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
         ctx.saved_layers = None
         return (dx, None, None) + tuple(grads)

@@ -532,3 +532,49 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
         close(g[d][1], getattr(lstm, f"weight_hh_l0{sfx}").grad, f"dW_hh{sfx}")
         close(g[d][2], getattr(lstm, f"bias_ih_l0{sfx}").grad, f"db{sfx}")
     assert np.all(np.array(gates).reshape(T, B, 2, NP // 4, 4)[:, :, :, H:, :] == 0) if ug * (Hp // ug) == Hp and H % ug == 0 else True
+
+
+@pytest.mark.parametrize("H,ug,Kx,first", [(10, 4, 9, True), (10, 4, 24, False), (8, 8, 16, False)])
+def test_layer_gradient_gemms_on_the_split_bf16_kernel(lib, H, ug, Kx, first):
+    """nn/_train.py: the weight / input gradient contractions in the packed layouts on onssen_linear_x3p agree with
+    the plain torch contractions in the reference's layouts (fp32), within the split-bf16 product error."""
+    import torch
+    from onssen_amd.nn._train import layer_gradients, layer_gradients_x3, packed_columns
+    torch.manual_seed(H + Kx)
+    T, B = 5, 3
+    Hp = -(-H // ug) * ug
+    NP = 4 * Hp
+    in_features = Kx if first else 2 * H
+    assert first or Kx == 2 * Hp
+    w_ih = [torch.randn(4 * H, in_features) for _ in range(2)]
+    cols = packed_columns(H, Hp, ug)
+    dP = torch.zeros(T, B, 2, NP)
+    dP[..., cols] = torch.randn(T, B, 2, 4 * H)                      # padded units carry zero gradient
+    y = torch.zeros(T, B, 2, Hp); y[..., :H] = torch.randn(T, B, 2, H)
+    Kp = (Kx + 3) // 4 * 4 if first else 2 * Hp
+    wih_p = torch.zeros(2, NP, Kp)
+    if first:
+        xp = torch.randn(T * B, Kx)
+        x_rows = xp
+        for d in range(2):
+            wih_p[d, cols, :Kx] = w_ih[d]
+    else:
+        xin = torch.zeros(T, B, 2, Hp); xin[..., :H] = torch.randn(T, B, 2, H)
+        xp = xin.view(T * B, 2 * Hp)
+        x_rows = xin[..., :H].reshape(T * B, 2 * H)
+        for d in range(2):
+            for dd in range(2):
+                wih_p[d, cols, dd * Hp: dd * Hp + H] = w_ih[d][:, dd * H:(dd + 1) * H]
+    dx_ref, g_ref = layer_gradients(dP, x_rows, y, w_ih, H, ug)
+    dx, g = layer_gradients_x3(lib, None, dP, xp, y, wih_p, H, ug, in_features, True)
+
+    def close(a_, b_, what):
+        assert (a_ - b_).abs().max() <= 1e-4 * max(b_.abs().max().item(), 1e-3), what
+    if first:
+        close(dx[:, :Kx], dx_ref, "dx")
+    else:
+        close(dx.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H), dx_ref, "dx")
+        assert Hp == H or dx.view(T, B, 2, Hp)[..., H:].abs().max() == 0
+    for d in range(2):
+        for k, nm in enumerate(("dW_ih", "dW_hh", "db")):
+            close(g[d][k], g_ref[d][k], f"{nm}[{d}]")

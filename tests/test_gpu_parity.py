@@ -572,15 +572,17 @@ def test_chimera_losses_on_device_match_reference_fixture(dev, golden_dir):
 
 # ---------------------------------------------------------------- training path (row N1): HIP forward + backward
 @pytest.mark.gpu
-@pytest.mark.parametrize("bwd_xcd", ["1", "0"])      # XCD-local persistent backward launch | one launch per time step
+# XCD-local persistent backward launch + split-bf16 MFMA gradient GEMMs (default) | launch per step + fp32 library GEMMs
+@pytest.mark.parametrize("bwd_xcd,gemm", [("1", "x3"), ("0", "blas")])
 @pytest.mark.parametrize("B,T,F,H,L", [(4, 50, 129, 600, 2), (3, 17, 129, 30, 3), (18, 9, 33, 128, 1), (40, 12, 20, 64, 2)])
-def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L, bwd_xcd):
+def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L, bwd_xcd, gemm):
     """What `loss.backward()` computes for self.rnn (onssen/utils/train.py:80-84): the HIP training path (saved-state
     XCD forward, backward recurrence kernel, rocBLAS weight-gradient GEMMs) against nn.LSTM autograd in float64 on the
     CPU, dropout off.  Split-bf16 products: every gradient tensor within 3e-4 of its largest entry."""
     from onssen_amd.nn._core import BLSTMParams
     monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
     monkeypatch.setenv("ONSSEN_BWD_XCD", bwd_xcd)
+    monkeypatch.setenv("ONSSEN_TRAIN_GEMM", gemm)
     monkeypatch.setenv("ONSSEN_CHECK", "1")
     torch.manual_seed(H + L)
     ref = torch.nn.LSTM(F, H, L, batch_first=True, bidirectional=True).double()
