@@ -157,6 +157,12 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
                          int ldw, const float* bias, int N, int mode, int group, float eps, const float* resid,
                          float* C, int64_t c_s0, int64_t c_s1, void* stream);
 
+/* x3 image of the TRANSPOSE of a row-major fp32 matrix src [K][ld >= M], optionally shifted along k: image row m
+ * (0 <= m < M), element k (0 <= k < K) = src[(k + k_shift) * ld + m], 0 where k + k_shift is outside [0, K).  Operands of
+ * the training path's weight-gradient GEMMs (contraction over the T*B rows of row-major activations; k_shift = -+B turns
+ * the layer output into "h of the step before" for the forward / reverse direction). */
+int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shift, uint16_t* img, void* stream);
+
 /* Split-bf16 GEMM over PRE-SPLIT operands.  An "x3 image" of a row-major [rows][K] fp32 matrix is
  * [rows][KB][2][32] bf16, KB = ceil(K/32): per row and 32-wide k block, 32 x hi = bf16(x) then 32 x lo =
  * bf16(x - hi), zeros beyond K (16-byte aligned).  onssen_x3_image_f32 builds one from fp32 rows (row m at

@@ -41,6 +41,7 @@ SIGNATURES = {
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
     "onssen_lstm_pack_whhT_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -173,6 +174,9 @@ class Lib:
 
 
     # ---- training (row N1)
+    def x3_image_t(self, src, ld, M, K, k_shift, img, stream):
+        self.check(self.dll.onssen_x3_image_t_f32(src, ld, M, K, k_shift, img, stream), "onssen_x3_image_t_f32")
+
     def lstm_train_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates, cs, ws, ws_bytes, stream):
         self.check(self.dll.onssen_lstm_train_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates,
                                                           cs, ws, ws_bytes, stream), "onssen_lstm_train_forward_f32")

@@ -292,6 +292,17 @@ int onssen_x3_image_f32(const float* src, int64_t s0, int64_t s1, int R, int row
   return ONSSEN_OK;
 }
 
+int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shift, uint16_t* img, void* stream) {
+  if (!src || !img || M <= 0 || K <= 0 || ld < M) return ONSSEN_E_ARG;
+  if (!aligned16(img)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  const int KB = ceil_div(K, 32);
+  hipLaunchKernelGGL(x3_image_t_kernel, dim3((unsigned)ceil_div(M, 64), (unsigned)KB), dim3(256), 0, (hipStream_t)stream, src,
+                     (long)ld, M, K, KB, k_shift, img);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
                       int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream) {
   if (!a_img || !w_img || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0) return ONSSEN_E_ARG;

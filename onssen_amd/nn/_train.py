@@ -72,15 +72,18 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
     T, B, _, NP = dP.shape
     Hp, TB, Kx = y.shape[3], T * B, xp.shape[1]
     dev = dP.device
-    ysh = torch.zeros_like(y)                       # h of the step before, per direction
-    if T > 1:
-        ysh[1:, :, 0] = y[:-1, :, 0]
-        ysh[:-1, :, 1] = y[1:, :, 1]
+    KB = (TB + 31) // 32
     N1 = Kx + 2 * Hp
-    wall_t = torch.cat([xp, ysh.view(TB, 2 * Hp)], 1).t().contiguous()          # (N1, TB)
     dp2 = dP.view(TB, 2 * NP)
-    a_t = _x3_image(lib, st, dp2.t().contiguous())                              # (2NP, TB)
-    w1 = _x3_image(lib, st, wall_t)
+    # operands contracted over the T*B rows: transposed images straight from the row-major activations
+    a_t = torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
+    lib.x3_image_t(dp2.data_ptr(), 2 * NP, 2 * NP, TB, 0, a_t.data_ptr(), st)
+    w1 = torch.empty(N1, KB, 2, 32, device=dev, dtype=torch.int16)
+    lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1.data_ptr(), st)
+    y2 = y.view(TB, 2 * Hp)
+    # h of the step before: the forward direction looks B rows back, the reverse direction B rows ahead
+    lib.x3_image_t(y2.data_ptr(), 2 * Hp, Hp, TB, -B, w1[Kx:].data_ptr(), st)
+    lib.x3_image_t(y2[:, Hp:].data_ptr(), 2 * Hp, Hp, TB, B, w1[Kx + Hp:].data_ptr(), st)
     zero_bias = torch.zeros(max(N1, wih_p.shape[2]), device=dev, dtype=torch.float32)
     out1 = torch.empty(2 * NP, N1, device=dev, dtype=torch.float32)
     lib.linear_x3p(a_t.data_ptr(), 2 * NP, TB, w1.data_ptr(), zero_bias.data_ptr(), N1, 0, 0, 0.0, out1.data_ptr(), 1, N1, 0, st)
@@ -88,7 +91,8 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
     if need_dx:
         Kp = wih_p.shape[2]
         a = _x3_image(lib, st, dp2)
-        w2 = _x3_image(lib, st, wih_p.view(2 * NP, Kp).t().contiguous())        # (Kp, 2NP)
+        w2 = torch.empty(Kp, (2 * NP + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_t(wih_p.data_ptr(), Kp, Kp, 2 * NP, 0, w2.data_ptr(), st)     # image of W_ih(packed)^T
         dx = torch.empty(TB, Kp, device=dev, dtype=torch.float32)
         lib.linear_x3p(a.data_ptr(), TB, 2 * NP, w2.data_ptr(), zero_bias.data_ptr(), Kp, 0, 0, 0.0, dx.data_ptr(), 1, Kp, 0, st)
     db2 = dp2.sum(0)

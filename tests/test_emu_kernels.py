@@ -578,3 +578,20 @@ def test_layer_gradient_gemms_on_the_split_bf16_kernel(lib, H, ug, Kx, first):
     for d in range(2):
         for k, nm in enumerate(("dW_ih", "dW_hh", "db")):
             close(g[d][k], g_ref[d][k], f"{nm}[{d}]")
+
+
+@pytest.mark.parametrize("M,K,shift", [(70, 45, 0), (33, 64, -3), (64, 100, 7)])
+def test_x3_image_of_the_transpose(lib, M, K, shift):
+    """onssen_x3_image_t_f32 == onssen_x3_image_f32 of the explicitly transposed (and k-shifted) matrix, bit for bit."""
+    rng = np.random.default_rng(M + K)
+    src = rand(rng, K, M + 5)                                  # [K][ld], ld > M
+    explicit = np.zeros((M, K), dtype=np.float32)
+    for k in range(K):
+        if 0 <= k + shift < K:
+            explicit[:, k] = src[k + shift, :M]
+    KB = (K + 31) // 32
+    want = np.zeros((M, KB, 2, 32), dtype=np.uint16)
+    got = np.full((M, KB, 2, 32), 0xFFFF, dtype=np.uint16)
+    lib.x3_image(P(explicit), K, 0, 1, M, K, P(want), None)
+    lib.x3_image_t(P(src), M + 5, M, K, shift, P(got), None)
+    assert np.array_equal(got, want)
