@@ -653,3 +653,28 @@ def test_dc_training_step_hip_vs_aten(dev, monkeypatch):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_chimera_training_step_hip_vs_aten(dev, monkeypatch):
+    """chimera++ (4 x BLSTM-600, no BatchNorm) + loss_chimera_msa: the HIP training path against the stock ATen LSTM,
+    dropout off.  Same bound as the deep-clustering test: 2e-3 of each gradient tensor's largest entry."""
+    from onssen_amd import nn as onn
+    from onssen_amd.loss import loss_chimera_msa
+    torch.manual_seed(5)
+    B, T, Fq = 3, 40, 129
+    x = torch.randn(B, T, Fq, device=dev)
+    lab = [torch.nn.functional.one_hot(torch.randint(0, 2, (B, T, Fq), device=dev), 2).float(),
+           torch.rand(B, T, Fq, device=dev) + 0.1, torch.rand(B, T, Fq, device=dev), torch.rand(B, T, Fq, device=dev)]
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ONSSEN_TRAIN_HIP", mode)
+        torch.manual_seed(6)
+        m = onn.chimera(Fq, 600, 4, 20, dropout=0.0).to(dev).train()
+        loss = torch.mean(loss_chimera_msa(m([x]), lab))
+        loss.backward()
+        results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert abs(results["1"][0] - results["0"][0]) <= 1e-4 * abs(results["0"][0])
+    for k, g0 in results["0"][1].items():
+        g1 = results["1"][1][k]
+        assert (g1 - g0).abs().max().item() <= 2e-3 * max(g0.abs().max().item(), 1e-8), k
