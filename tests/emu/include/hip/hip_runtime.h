@@ -284,6 +284,12 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_bu
   if ((unsigned long)(unsigned)voff + 4 <= (unsigned long)r.bytes)
     __atomic_store_n(reinterpret_cast<unsigned*>(r.base + voff + soff), v, __ATOMIC_SEQ_CST);
 }
+static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  if ((unsigned long)(unsigned)voff + 16 <= (unsigned long)r.bytes) {
+    memcpy(r.base + voff + soff, &v, 16);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  }
+}
 static inline bool __all(bool p) {
   auto& w = emu::ctx->wbuf[emu::wave];
   w.a[emu::lane] = p ? 1.0f : 0.0f;

@@ -463,8 +463,12 @@ def test_loss_mask_term(lib, psa):
     np.testing.assert_allclose(out, ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize("form,scramble", [(_abi.LSTM_BWD_XCD, "0"), (_abi.LSTM_BWD_XCD, "1"), (_abi.LSTM_BWD_STEPS, "0")])
-@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17)])
+_TRAIN_CASES = [(H, ug, B, T, _abi.LSTM_BWD_XCD, "0") for H, ug, B, T in
+                [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17), (8, 4, 1, 1)]] + \
+               [(24, 8, 18, 3, _abi.LSTM_BWD_XCD, "1"), (8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0")]
+
+
+@pytest.mark.parametrize("H,ug,B,T,form,scramble", _TRAIN_CASES)
 def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T, form, scramble):
     """Row N1: training forward (saved gates / cell states) + backward recurrence of one bidirectional layer against
     nn.LSTM autograd on the CPU (the reference's `loss.backward()`, onssen/utils/train.py:80-84).  Split-bf16 products:
