@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--dropout", type=float, default=0.3, help="nn.LSTM inter-layer dropout (0 makes the HIP and ATen paths comparable step for step)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     import torch.distributed as dist
@@ -34,7 +35,7 @@ def main():
     from onssen_amd.loss import loss_dc
     fo = dict(batch_size=16, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
     torch.manual_seed(0)
-    model = onn.deep_clustering(129, 600, args.layers, 20, dropout=0.3).to(dev).train()
+    model = onn.deep_clustering(129, 600, args.layers, 20, dropout=args.dropout).to(dev).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     loader = wsj0_2mix_dataloader("dc", fo, "tr", device=str(dev))
     batches = []
