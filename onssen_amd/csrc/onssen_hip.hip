@@ -25,6 +25,14 @@ typedef unsigned int u32x4 __attribute__((vector_size(16)));
 typedef short s16x8 __attribute__((vector_size(16)));       // 8 bf16 bit patterns = one MFMA A/B fragment
 typedef __bf16 bf16x8_t __attribute__((vector_size(16)));
 
+// Opaque to the optimiser: the first use of `x` cannot be scheduled (or folded into another block) before `after` exists.
+// (The host-side emulation of tests/emu defines ONSSEN_HOST_EMULATION: no such reordering there, and no VGPR constraints.)
+#ifdef ONSSEN_HOST_EMULATION
+#define ONSSEN_USE_AFTER(x, after) ((void)0)
+#else
+#define ONSSEN_USE_AFTER(x, after) asm volatile("" : "+v"(x) : "v"(after))
+#endif
+
 // ---- split-bf16 ("bf16x3") arithmetic ---------------------------------------------------------------
 // An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|).  A product
 // a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA pipe (each bf16 x bf16 product
@@ -675,6 +683,10 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
     xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
     xa.spin_limit = xcd_spin; xa.ablate = ablate_env;
+    // profiling only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
+    static const bool dbg_env = getenv("ONSSEN_BWD_DBG") != nullptr;
+    xa.dbg = dbg_env && ws_bytes >= onssen_lstm_train_backward_workspace_bytes(B, H, ug, form) + (size_t)T * 64
+                 ? (long long*)((char*)ws + onssen_lstm_train_backward_workspace_bytes(B, H, ug, form)) : nullptr;
     ONSSEN_CLEAR_ERROR();
     const dim3 grid((unsigned)(8 * xa.NU));
     for (int r0 = 0; r0 < B; r0 += 4 * xa.RG) {

@@ -11,6 +11,7 @@
 // documented in cdna_hip_programming.md section 3.  Slow by design; sizes in
 // tests/test_emu_*.py are tiny.  Never shipped, never timed.
 #pragma once
+#define ONSSEN_HOST_EMULATION 1
 #include <pthread.h>
 #include <sched.h>
 #include <sys/wait.h>
