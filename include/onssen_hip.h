@@ -157,6 +157,12 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
                          int ldw, const float* bias, int N, int mode, int group, float eps, const float* resid,
                          float* C, int64_t c_s0, int64_t c_s1, void* stream);
 
+/* `batch` independent problems C_z = A_z W_z^T + bias of one shape in ONE launch (gridDim.z): A_z = a_img + z*a_bs,
+ * W_z = w_img + z*w_bs (uint16 elements, multiples of 8), C_z = C + z*c_bs with row stride ldc; the bias is shared.
+ * Used by the training path: the two directions' weight-gradient GEMMs fill the chip only together. */
+int onssen_linear_x3p_batched(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                              const float* bias, int N, float* C, int64_t c_bs, int64_t ldc, int batch, void* stream);
+
 /* x3 image of the TRANSPOSE of a row-major fp32 matrix src [K][ld >= M], optionally shifted along k: image row m
  * (0 <= m < M), element k (0 <= k < K) = src[(k + k_shift) * ld + m], 0 where k + k_shift is outside [0, K).  Operands of
  * the training path's weight-gradient GEMMs (contraction over the T*B rows of row-major activations; k_shift = -+B turns

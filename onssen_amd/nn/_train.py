@@ -63,7 +63,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
     """The same contractions as layer_gradients on the split-bf16 MFMA GEMM (onssen_linear_x3p), in the packed layouts
     the kernels use, so that no gather of dP is needed:
 
-        [dW_ih(packed) | dW_hh(packed, both directions)] = dP^T [x | h_prev]        one GEMM, K = T*B
+        [dW_ih(packed) | dW_hh(packed)] = dP_d^T [x | h_prev_d]  per direction, both in ONE batched launch, K = T*B
         dx(padded layout of the layer below)              = dP W_ih(packed)          one GEMM, K = 2*NP
 
     dP (T,B,2,NP); xp (T*B, Kx) the layer's input rows as its projection GEMM saw them (layer 0: the F features, deeper
@@ -73,20 +73,22 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
     Hp, TB, Kx = y.shape[3], T * B, xp.shape[1]
     dev = dP.device
     KB = (TB + 31) // 32
-    N1 = Kx + 2 * Hp
+    N1 = Kx + Hp                                   # per direction: [dW_ih | dW_hh] columns
     dp2 = dP.view(TB, 2 * NP)
     # operands contracted over the T*B rows: transposed images straight from the row-major activations
     a_t = torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
     lib.x3_image_t(dp2.data_ptr(), 2 * NP, 2 * NP, TB, 0, a_t.data_ptr(), st)
-    w1 = torch.empty(N1, KB, 2, 32, device=dev, dtype=torch.int16)
-    lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1.data_ptr(), st)
+    w1 = torch.empty(2, N1, KB, 2, 32, device=dev, dtype=torch.int16)           # per direction: [x | h of the step before]
     y2 = y.view(TB, 2 * Hp)
-    # h of the step before: the forward direction looks B rows back, the reverse direction B rows ahead
-    lib.x3_image_t(y2.data_ptr(), 2 * Hp, Hp, TB, -B, w1[Kx:].data_ptr(), st)
-    lib.x3_image_t(y2[:, Hp:].data_ptr(), 2 * Hp, Hp, TB, B, w1[Kx + Hp:].data_ptr(), st)
+    for d in range(2):
+        lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1[d].data_ptr(), st)
+        # the forward direction looks B rows back, the reverse direction B rows ahead
+        lib.x3_image_t(y2[:, d * Hp:].data_ptr(), 2 * Hp, Hp, TB, -B if d == 0 else B, w1[d, Kx:].data_ptr(), st)
     zero_bias = torch.zeros(max(N1, wih_p.shape[2]), device=dev, dtype=torch.float32)
-    out1 = torch.empty(2 * NP, N1, device=dev, dtype=torch.float32)
-    lib.linear_x3p(a_t.data_ptr(), 2 * NP, TB, w1.data_ptr(), zero_bias.data_ptr(), N1, 0, 0, 0.0, out1.data_ptr(), 1, N1, 0, st)
+    out1 = torch.empty(2, NP, N1, device=dev, dtype=torch.float32)
+    # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
+    lib.linear_x3p_batched(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1,
+                           out1.data_ptr(), NP * N1, N1, 2, st)
     dx = None
     if need_dx:
         Kp = wih_p.shape[2]
@@ -103,9 +105,9 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
         feat = torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)])
     grads = []
     for d in range(2):
-        rows = out1.index_select(0, d * NP + cols)                               # (4H, N1) in nn.LSTM row order
+        rows = out1[d].index_select(0, cols)                                     # (4H, N1) in nn.LSTM row order
         dW_ih = rows[:, :Kx] if feat is None else rows[:, :Kx].index_select(1, feat)
-        dW_hh = rows[:, Kx + d * Hp: Kx + d * Hp + H]
+        dW_hh = rows[:, Kx:Kx + H]
         grads.append((dW_ih.contiguous(), dW_hh.contiguous(), db2[d * NP + cols]))
     return dx, grads
 
