@@ -220,3 +220,65 @@ class BLSTMTrainFunction(torch.autograd.Function):
         dx = dx_rows[:, :In].reshape(T, B, In).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
         ctx.saved_layers = None
         return (dx, None, None) + tuple(grads)
+
+
+# ----------------------------------------------------------------------------- nn.Linear on the same GEMM (training)
+def linear_x3_forward(lib, st, x2d, weight, bias):
+    """x2d (M,K) @ weight (N,K)^T + bias on onssen_linear_x3p (fc_dc / fc_mi, onssen/nn/deep_clustering.py:39)."""
+    M, K = x2d.shape
+    N = weight.shape[0]
+    out = torch.empty(M, N, device=x2d.device, dtype=torch.float32)
+    a, w = _x3_image(lib, st, x2d), _x3_image(lib, st, weight)      # (named: the images must outlive the launch's argument list)
+    lib.linear_x3p(a.data_ptr(), M, K, w.data_ptr(), bias.data_ptr(), N, 0, 0, 0.0, out.data_ptr(), 1, N, 0, st)
+    return out
+
+
+def linear_x3_backward(lib, st, dy, x2d, weight, need_dx=True):
+    """dx = dy W, dW = dy^T x, db = column sums of dy; the operands contracted over rows come from onssen_x3_image_t_f32."""
+    M, N = dy.shape
+    K = x2d.shape[1]
+    dev = dy.device
+    zero = torch.zeros(max(N, K), device=dev, dtype=torch.float32)
+    dx = None
+    if need_dx:
+        wt = torch.empty(K, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_t(weight.data_ptr(), K, K, N, 0, wt.data_ptr(), st)                     # image of W^T: rows k, contraction over n
+        dx = torch.empty(M, K, device=dev, dtype=torch.float32)
+        a = _x3_image(lib, st, dy)
+        lib.linear_x3p(a.data_ptr(), M, N, wt.data_ptr(), zero.data_ptr(), K, 0, 0, 0.0, dx.data_ptr(), 1, K, 0, st)
+    KB = (M + 31) // 32
+    dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
+    lib.x3_image_t(dy.data_ptr(), N, N, M, 0, dyt.data_ptr(), st)
+    xt = torch.empty(K, KB, 2, 32, device=dev, dtype=torch.int16)
+    lib.x3_image_t(x2d.data_ptr(), K, K, M, 0, xt.data_ptr(), st)
+    dW = torch.empty(N, K, device=dev, dtype=torch.float32)
+    lib.linear_x3p(dyt.data_ptr(), N, M, xt.data_ptr(), zero.data_ptr(), K, 0, 0, 0.0, dW.data_ptr(), 1, K, 0, st)
+    return dx, dW, dy.sum(0)
+
+
+class LinearX3Function(torch.autograd.Function):
+    """F.linear for the heads of the training forward, on the package's split-bf16 MFMA GEMM in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x2d = x.reshape(-1, x.shape[-1]).contiguous()
+        w = weight.detach().contiguous()
+        ctx.save_for_backward(x2d, w)
+        ctx.xshape = x.shape
+        return linear_x3_forward(lib, st, x2d, w, bias.detach().contiguous()).view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x2d, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx, dW, db = linear_x3_backward(lib, st, dy2, x2d, w, ctx.needs_input_grad[0])
+        return (dx.view(ctx.xshape) if dx is not None else None), dW, db
+
+
+def head_linear(lin, x):
+    """nn.Linear `lin` applied to x in a training forward: the HIP GEMM on a ROCm device (ONSSEN_TRAIN_HIP=1), else ATen."""
+    if x.is_cuda and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+        return LinearX3Function.apply(x, lin.weight, lin.bias)
+    return Fn.linear(x, lin.weight, lin.bias)

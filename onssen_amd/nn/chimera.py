@@ -2,6 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._train import head_linear
 from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
@@ -49,6 +50,6 @@ class chimera(nn.Module):
     def _autograd_forward(self, x):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
-        e = F.normalize(self.fc_dc(r).reshape(B, T * Fq, -1), p=2, dim=-1).reshape(B, T, Fq, -1)
-        m = torch.sigmoid(self.fc_mi(r)).reshape(B, T, Fq, -1)
+        e = F.normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1), p=2, dim=-1).reshape(B, T, Fq, -1)
+        m = torch.sigmoid(head_linear(self.fc_mi, r)).reshape(B, T, Fq, -1)
         return [e, m[:, :, :, 0], m[:, :, :, 1]]

@@ -2,6 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ._train import head_linear
 from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
@@ -43,5 +44,5 @@ class deep_clustering(nn.Module):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
         r = self.bn(r.permute(0, 2, 1)).permute(0, 2, 1)
-        e = F.normalize(self.fc_dc(r).view(B, T * Fq, -1), p=2, dim=-1)
+        e = F.normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1), p=2, dim=-1)
         return e.reshape(B, T, Fq, -1)

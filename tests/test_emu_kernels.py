@@ -599,3 +599,16 @@ def test_x3_image_of_the_transpose(lib, M, K, shift):
     lib.x3_image(P(explicit), K, 0, 1, M, K, P(want), None)
     lib.x3_image_t(P(src), M + 5, M, K, shift, P(got), None)
     assert np.array_equal(got, want)
+
+
+def test_head_linear_on_the_split_bf16_kernel(lib):
+    """nn/_train.py: nn.Linear forward / backward (fc_dc, fc_mi of a training forward) on onssen_linear_x3p."""
+    import torch
+    from onssen_amd.nn._train import linear_x3_forward, linear_x3_backward
+    torch.manual_seed(3)
+    M, K, N = 37, 24, 45
+    x, w, b, dy = torch.randn(M, K), torch.randn(N, K), torch.randn(N), torch.randn(M, N)
+    out = linear_x3_forward(lib, None, x, w, b)
+    dx, dW, db = linear_x3_backward(lib, None, dy, x, w)
+    for got, ref in ((out, x @ w.t() + b), (dx, dy @ w), (dW, dy.t() @ x), (db, dy.sum(0))):
+        assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()
