@@ -1,12 +1,13 @@
 """Training path of the stacked BLSTM on the HIP kernels (second half).
 
 What autograd does for ``self.rnn(x)`` in the reference's training loop (onssen/utils/train.py:70-84 calling
-onssen/nn/deep_clustering.py:32-35): here the forward of every layer is the XCD-local persistent recurrence with saved
-gate activations / cell states (``onssen_lstm_train_forward_f32``), the backward recurrence is
-``onssen_lstm_train_backward_f32`` (XCD-local persistent launch; one launch per time step with ONSSEN_BWD_XCD=0), and the weight / input gradient contractions -- plain
-dense GEMMs over T*B rows -- are library GEMMs (rocBLAS through ``torch.mm``) on the pre-activation gradient the
-kernel leaves.  The inter-layer dropout of ``nn.LSTM(dropout=0.3)`` (deep_clustering.py:15-22) is applied between the
-layers with torch's own generator, as ATen does."""
+onssen/nn/deep_clustering.py:32-35): the forward of every layer is the XCD-local persistent recurrence with saved gate
+activations / cell states (``onssen_lstm_train_forward_f32``), the backward recurrence is ``onssen_lstm_train_backward_f32``
+(XCD-local persistent launch; one launch per time step with ONSSEN_BWD_XCD=0), and the weight / input gradient
+contractions run on the package's split-bf16 MFMA GEMM (``onssen_linear_x3p`` / ``_batched``) over operand images written by
+``onssen_x3_image_t_f32`` (ONSSEN_TRAIN_GEMM=blas: fp32 library GEMMs through ``torch.mm`` instead).  The inter-layer
+dropout of ``nn.LSTM(dropout=0.3)`` (deep_clustering.py:15-22) is applied between the layers with torch's generator.
+``head_linear`` puts the heads' nn.Linear (fc_dc, fc_mi) on the same GEMM for a training forward / backward."""
 import os
 
 import torch
