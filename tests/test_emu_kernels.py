@@ -464,7 +464,7 @@ def test_loss_mask_term(lib, psa):
 
 
 _TRAIN_CASES = [(H, ug, B, T, _abi.LSTM_BWD_XCD, "0") for H, ug, B, T in
-                [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17), (8, 4, 1, 1)]] + \
+                [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17), (8, 4, 1, 1), (8, 4, 70, 2)]] + \
                [(24, 8, 18, 3, _abi.LSTM_BWD_XCD, "1"), (8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0")]
 
 
