@@ -563,8 +563,8 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
       xa.terms = bf16_only ? 1 : 3;
       // one polling wave per workgroup (+ a barrier) instead of every wave polling for itself: measured 2.19 -> 2.02 us per
-      // step at B = 32 -- the polls of 4 x 30 waves per XCD load its L2 enough to delay what they wait for (ONSSEN_XCD_POLL=0:
-      // per-wave polling, |2: s_sleep between polls)
+      // step at B = 32 -- the polls of 4 x 30 waves per XCD load its L2 enough to delay what they wait for.  Compile-time
+      // (a run-time switch inside the step loop cost 7 %); ONSSEN_XCD_POLL=0 selects the per-wave instantiation
       static const int xcd_poll = getenv("ONSSEN_XCD_POLL") ? atoi(getenv("ONSSEN_XCD_POLL")) : 1;
       xa.poll = xcd_poll;
       xa.save_g = save_g; xa.save_c = save_c;
