@@ -1,6 +1,6 @@
 """Training losses needed by the data-parallel step.
 
-With autograd (training): stock PyTorch ops.  Without (``trainer.validate``, onssen/utils/train.py:91-99, runs the
+With autograd (training): PyTorch ops (the affinity norms as one Gram product with an analytic backward).  Without (``trainer.validate``, onssen/utils/train.py:91-99, runs the
 loss under ``no_grad``): the HIP kernel ``onssen_loss_dc_f32``, which streams the embedding once.
 Semantics follow onssen/loss/loss_dc.py:6-44 and loss_util.py:4-11 exactly,
 including their quirks: the affinity terms are Frobenius *norms* (not squared
@@ -27,15 +27,38 @@ def loss_dc(output, label):
     V = embedding.reshape(B, T * F, D)
     Y = one_hot.reshape(B, T * F, C)
     mag = mag_mix.detach().reshape(B, T * F)
-    V = Y.sum(2, keepdim=True) * V                       # silent TF bins do not contribute
     total = mag.sum(1, keepdim=True)
     w = torch.sqrt(mag / total).unsqueeze(-1)            # W_i = |x_i| / sum_j |x_j|, applied to both factors
-    V, Y = V * w, Y * w
-    vtv = torch.bmm(V.transpose(1, 2), V)
-    vty = torch.bmm(V.transpose(1, 2), Y)
-    yty = torch.bmm(Y.transpose(1, 2), Y)
-    per_utt = _fro(vtv) - 2 * _fro(vty) + _fro(yty)      # (B,)
+    scale = Y.sum(2, keepdim=True) * w                   # silent TF bins do not contribute
+    per_utt = _AffinityNorms.apply(V, scale.detach(), (Y * w).detach())      # (B,)
     return per_utt * total                               # (B,) * (B,1) -> (B,B), as upstream
+
+
+class _AffinityNorms(torch.autograd.Function):
+    """||Vm^T Vm||_F - 2 ||Vm^T Ym||_F + ||Ym^T Ym||_F per utterance with Vm = scale * V (onssen/loss/loss_dc.py:36-42),
+    as ONE Gram product of Z = [Vm | Ym] forward and ONE product backward instead of the three `bmm`s (and six in
+    autograd's backward) of the literal form -- each contracts over all T*F bins.  Same value and gradient:
+      d||Vm^T Vm|| = 2 Vm (Vm^T Vm) / ||.||,   d||Vm^T Ym|| = Ym (Vm^T Ym)^T / ||.||."""
+
+    @staticmethod
+    def forward(ctx, V, scale, Ym):
+        D = V.shape[2]
+        Z = torch.cat([V * scale, Ym], 2)
+        G = torch.bmm(Z.transpose(1, 2), Z)              # (B, D+C, D+C): blocks Vm^T Vm, Vm^T Ym, Ym^T Ym
+        nvv, nvy, nyy = _fro(G[:, :D, :D]), _fro(G[:, :D, D:]), _fro(G[:, D:, D:])
+        ctx.save_for_backward(Z, scale, G, nvv, nvy)
+        ctx.D = D
+        return nvv - 2 * nvy + nyy
+
+    @staticmethod
+    def backward(ctx, g):
+        Z, scale, G, nvv, nvy = ctx.saved_tensors
+        D = ctx.D
+        # dL/dVm = Z M with M = [2 Gvv / ||Gvv|| ; -2 Gvy^T / ||Gvy||]   (a zero norm has a zero block: no contribution)
+        top = 2 * G[:, :D, :D] / nvv.clamp_min(1e-30)[:, None, None]
+        bot = -2 * G[:, :D, D:].transpose(1, 2) / nvy.clamp_min(1e-30)[:, None, None]
+        dVm = torch.bmm(Z, torch.cat([top, bot], 1))
+        return dVm * scale * g[:, None, None], None, None
 
 
 _WS = {}

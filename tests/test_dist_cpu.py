@@ -131,3 +131,28 @@ def test_chimera_losses_match_reference_fixture(golden_dir):
     psa = loss_chimera_psa(out, [tt(z["one_hot"]), tt(z["mag"]), tt(z["s1"]), tt(z["s2"]), tt(z["c1"]), tt(z["c2"])])
     np.testing.assert_allclose(msa.numpy(), z["msa"], rtol=1e-5)
     np.testing.assert_allclose(psa.numpy(), z["psa"], rtol=1e-5)
+
+
+def test_loss_dc_gram_form_equals_the_literal_form():
+    """loss_dc's single-Gram forward / analytic backward (onssen_amd/loss.py:_AffinityNorms) against the literal three-bmm
+    form of onssen/loss/loss_dc.py:36-44 under autograd, in float64: value and gradient w.r.t. the embedding."""
+    torch.manual_seed(4)
+    B, T, F, D, C = 3, 7, 9, 5, 2
+    emb = torch.randn(B, T, F, D, dtype=torch.float64, requires_grad=True)
+    one_hot = torch.nn.functional.one_hot(torch.randint(0, C + 1, (B, T, F)), C + 1)[..., :C].double()   # some bins silent
+    mag = torch.rand(B, T, F, dtype=torch.float64) + 0.01
+    V = emb.reshape(B, T * F, D)
+    Y = one_hot.reshape(B, T * F, C)
+    V = Y.sum(2, keepdim=True) * V
+    total = mag.reshape(B, -1).sum(1, keepdim=True)
+    w = torch.sqrt(mag.reshape(B, -1) / total).unsqueeze(-1)
+    V, Y = V * w, Y * w
+    fro = lambda x: torch.sqrt((x * x).flatten(1).sum(1))
+    ref = (fro(V.transpose(1, 2) @ V) - 2 * fro(V.transpose(1, 2) @ Y) + fro(Y.transpose(1, 2) @ Y)) * total
+    g_ref, = torch.autograd.grad(ref.mean(), emb)
+    emb2 = emb.detach().clone().requires_grad_(True)
+    got = loss_dc([emb2], [one_hot, mag])
+    g_got, = torch.autograd.grad(got.mean(), emb2)
+    assert got.shape == (B, B)
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(g_got.numpy(), g_ref.numpy(), rtol=1e-9, atol=1e-14)
