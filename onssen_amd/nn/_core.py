@@ -386,7 +386,7 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
 def use_hip_path(module):
     """Inference (eval mode, no autograd graph needed) -> HIP kernels.
     Anything that needs autograd or train-mode BatchNorm/dropout takes the
-    documented ATen training path."""
+    training path (HIP forward/backward of the BLSTM stack and the heads, nn/_train.py; the rest on ATen autograd)."""
     if module.training:
         return False
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
