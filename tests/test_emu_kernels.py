@@ -612,3 +612,22 @@ def test_head_linear_on_the_split_bf16_kernel(lib):
     dx, dW, db = linear_x3_backward(lib, None, dy, x, w)
     for got, ref in ((out, x @ w.t() + b), (dx, dy @ w), (dW, dy.t() @ x), (db, dy.sum(0))):
         assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()
+
+
+def test_linear_x3_images_plain_bf16_products(lib):
+    """ONSSEN_EPI_BF16 (opt-in precision mode): onssen_linear_x3p multiplies only the hi halves of the images -- the result
+    equals the fp64 product of the bf16-ROUNDED operands (accumulation error only), and is bf16-grade (1e-3..1e-2) away
+    from the product of the unrounded ones."""
+    rng = np.random.default_rng(12)
+    M, K, N = 70, 75, 170
+    x, W, bias = rand(rng, M, K), rand(rng, N, K), rand(rng, N)
+    KB = (K + 31) // 32
+    a_img, w_img = np.zeros((M, KB, 2, 32), np.uint16), np.zeros((N, KB, 2, 32), np.uint16)
+    lib.x3_image(P(x), K, 0, 1, M, K, P(a_img), None)
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    out = np.full((M, N), np.nan, np.float32)
+    lib.linear_x3p(P(a_img), M, K, P(w_img), P(bias), N, _abi.EPI_BIAS | _abi.EPI_BF16, 0, 0.0, P(out), 1, N, 0, None)
+    xr, Wr = O.bf16_round(x).astype(np.float64), O.bf16_round(W).astype(np.float64)
+    np.testing.assert_allclose(out, xr @ Wr.T + bias, atol=2e-5, rtol=1e-5)
+    full = x.astype(np.float64) @ W.T.astype(np.float64) + bias
+    assert 1e-4 < np.abs(out - full).max() < 0.2
