@@ -22,6 +22,7 @@
 
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef unsigned int u32x4 __attribute__((vector_size(16)));
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
 typedef short s16x8 __attribute__((vector_size(16)));       // 8 bf16 bit patterns = one MFMA A/B fragment
 typedef __bf16 bf16x8_t __attribute__((vector_size(16)));
 
@@ -560,18 +561,15 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       const bool vtail = fuse0 && (flags & ONSSEN_BLSTM_FUSE_TAIL) && (in_dim % 32) == 1 && in_dim > 1;
       xa.KCM = vtail ? xa.KC0 - 1 : xa.KC0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
       xa.wtail = vtail ? bias_p_host[0] + 2 * NP : nullptr;
-      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 31;
+      xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 8;
       xa.terms = bf16_only ? 1 : 3;
-      // one polling wave per workgroup (+ a barrier) instead of every wave polling for itself: measured 2.19 -> 2.02 us per
-      // step at B = 32 -- the polls of 4 x 30 waves per XCD load its L2 enough to delay what they wait for.  Compile-time
-      // (a run-time switch inside the step loop cost 7 %); ONSSEN_XCD_POLL=0 selects the per-wave instantiation
-      static const int xcd_poll = getenv("ONSSEN_XCD_POLL") ? atoi(getenv("ONSSEN_XCD_POLL")) : 1;
-      xa.poll = xcd_poll;
       xa.save_g = save_g; xa.save_c = save_c;
+      static const int d_cell = getenv("ONSSEN_XCD_DELAY_CELL") ? atoi(getenv("ONSSEN_XCD_DELAY_CELL")) : 0;
+      static const int d_idle = getenv("ONSSEN_XCD_DELAY_IDLE") ? atoi(getenv("ONSSEN_XCD_DELAY_IDLE")) : 0;
+      xa.delay_cell = d_cell; xa.delay_idle = d_idle;
       ONSSEN_CLEAR_ERROR();
-      // waves per workgroup: 4; ONSSEN_XCD_WAVES=8 (two per SIMD: denser MFMA issue, one cell-update pass) measured
-      // 2.71 vs 2.54 us per step at H=600 -- the longer flag wait of 8 pollers outweighs the shorter MFMA phase
-      static const int xcd_nw = getenv("ONSSEN_XCD_WAVES") && atoi(getenv("ONSSEN_XCD_WAVES")) == 8 ? 8 : 4;
+      // waves per workgroup (K is split over them): 8 = two per SIMD; ONSSEN_XCD_WAVES=4 keeps the one-per-SIMD form for comparison
+      static const int xcd_nw = getenv("ONSSEN_XCD_WAVES") && atoi(getenv("ONSSEN_XCD_WAVES")) == 4 ? 4 : 8;
       switch (ug) {
         case 4: rc = launch_xcd<1>(xa, xcd_nw, st); break;
         case 8: rc = launch_xcd<2>(xa, xcd_nw, st); break;

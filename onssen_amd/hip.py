@@ -6,7 +6,8 @@ import os
 from ._abi import Lib, OnssenError
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libonssen_hip.so")
+# ONSSEN_HIP_LIB: a profiling / A-B build of the same source (tools/ab_variants.py), never a different implementation
+LIB_PATH = os.environ.get("ONSSEN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libonssen_hip.so")
 
 
 def get_lib():

@@ -291,6 +291,35 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, __amdgpu_
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
   }
 }
+typedef unsigned int emu_u32x2 __attribute__((vector_size(8)));
+static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  if ((unsigned long)(unsigned)voff + 8 <= (unsigned long)r.bytes) {
+    uint64_t u; memcpy(&u, &v, 8);
+    __atomic_store_n(reinterpret_cast<uint64_t*>(r.base + voff + soff), u, __ATOMIC_SEQ_CST);
+  }
+}
+// DPP quad_perm (ctrl 0..255: two selector bits per lane of a quad), full row / bank masks: lane l receives the source
+// value of lane (l & ~3) + sel.  Every lane of the wave must call it (lanes are threads here).
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+  // quad_perm (ctrl 0..255: two selector bits per lane of a quad) and row_shl:n (0x101..0x10f: lane l receives lane l+n of
+  // its row of 16; beyond the row: 0 with bound_ctrl, else `old`), full row / bank masks.  Every lane of the wave must call it.
+  if (ctrl < 0 || (ctrl > 255 && (ctrl < 0x101 || ctrl > 0x10f))) { fprintf(stderr, "emu: DPP control not emulated\n"); abort(); }
+  auto& w = emu::ctx->wbuf[emu::wave];
+  memcpy(&w.a[emu::lane], &src, 4);
+  emu::wave_sync();
+  int r = old;
+  if (ctrl <= 255) {
+    memcpy(&r, &w.a[(emu::lane & ~3) + ((ctrl >> (2 * (emu::lane & 3))) & 3)], 4);
+  } else {
+    const int srcl = (emu::lane & 15) + (ctrl - 0x100);
+    if (srcl < 16) memcpy(&r, &w.a[(emu::lane & ~15) + srcl], 4);
+    else if (bound_ctrl) r = 0;
+  }
+  emu::wave_sync();
+  return r;
+}
+// the lanes of an emulated wave are threads with their own copy of every wave-uniform value
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline bool __all(bool p) {
   auto& w = emu::ctx->wbuf[emu::wave];
   w.a[emu::lane] = p ? 1.0f : 0.0f;

@@ -331,7 +331,7 @@ def _shm(shape, fill=0.0, dtype=np.float32):
 
 # fuse 2: FUSE_IN0 + FUSE_TAIL, F = 33; bf16 1: ONSSEN_BLSTM_BF16 (opt-in plain bf16 products)
 @pytest.mark.parametrize("scramble,fuse,bf16", [("0", 0, 0), ("1", 0, 0), ("0", 1, 0), ("0", 2, 0), ("0", 0, 1), ("0", 1, 1)])
-@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3)])
+@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3), (32, 4, 2, 6)])
 def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fuse, bf16):
     """ONSSEN_BLSTM_XCD: one persistent launch per layer, h exchanged inside the launch.  The mock runtime runs
     every workgroup concurrently (forked) over shared memory; scramble=1 makes the members of a group report

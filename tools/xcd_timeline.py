@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Profiling aid (GPU box): in-kernel timestamps of the XCD-local persistent recurrence (workgroup 0)."""
+"""Profiling aid (GPU box): in-kernel timestamps of the XCD-local persistent recurrence (workgroup 0, steps 64..127,
+collected in the LDS and written out at the end of the launch: [step][16]; wave 0 -> slots 0..7, polling wave -> 8, 9)."""
 import os, sys
 import numpy as np
 import torch
@@ -22,15 +23,17 @@ def layer(dbgflag):
 AB = int(os.environ.get('AB', 0))
 for _ in range(3): layer(32 | AB)
 torch.cuda.synchronize()
-d = ws[nb - 65536:].cpu().numpy().view(np.int64)[:T * 8].reshape(T, 8)[50:350].astype(np.float64)
+d = ws[nb - 65536:].cpu().numpy().view(np.int64)[:64 * 16].reshape(64, 16)[2:62].astype(np.float64)
 per = (d[1:, 0] - d[:-1, 0]).mean()
-seg = [(d[:, i + 1] - d[:, i]).mean() for i in range(5)]
+m = lambda a, b: (d[:, a] - d[:, b]).mean()
 st = ws[:2048].cpu().numpy().view(np.uint32)
-print(f"   seg1 detail: poll-done -> h loads issued {(d[:,6]-d[:,1]).mean():.0f} | G prefetch issued {(d[:,7]-d[:,6]).mean():.0f} | -> MFMA+LDS write done {(d[:,2]-d[:,7]).mean():.0f}")
-print(f"ablate={AB} B={B} ug={ug}: cycles/step {per:.0f} (~{per/2.3e3:.2f} us) | G-load+poll {seg[0]:.0f} | h load+MFMA {seg[1]:.0f} | reduce barrier {seg[2]:.0f} | "
-      f"epilogue+stores {seg[3]:.0f} | drain+barrier {seg[4]:.0f} | abort={st[280]} safe={st[281]}")
+print(f"ablate={AB} B={B} ug={ug} waves={os.environ.get('ONSSEN_XCD_WAVES', 8)}: cycles/step {per:.0f} | wave 0: step start->first chunk complete {m(8,0):.0f} | "
+      f"all chunks + MFMA {m(7,8):.0f} | partials written {m(2,7):.0f} | barrier {m(3,2):.0f} | G prefetch + cell update + hand-off stores issued {m(4,3):.0f} | "
+      f"output stores + pause {m(6,4):.0f} | next chunks requested {m(5,6):.0f} | to next step {(d[1:, 0] - d[:-1, 5]).mean():.0f} | abort={st[280]} safe={st[281]} nonfinite={st[282]}"
+      f" || passes per step: wave 0 {d[:,15].mean():.2f}, last wave {d[:,14].mean():.2f}"
+      f" || last wave: chunks requested {(d[:-1, 9] - d[:-1, 3]).mean():.0f} after the barrier | first chunk complete {(d[1:, 10] - d[:-1, 9]).mean():.0f} | MFMA done {m(11,10):.0f} | wave 0's MFMA done {m(7,11):.0f} later")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5): layer(AB)
 e1.record(); torch.cuda.synchronize()
-print(f"ablate={AB}: layer (GEMM ~0.6 ms + persistent recurrence), no stamps: {e0.elapsed_time(e1)/5:.3f} ms")
+print(f"ablate={AB}: layer (GEMM + persistent recurrence), no stamps: {e0.elapsed_time(e1)/5:.3f} ms")
