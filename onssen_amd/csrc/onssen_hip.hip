@@ -391,7 +391,7 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
 
 
 size_t onssen_batch_sdr_workspace_bytes(int B) {
-  return B > 0 ? ((size_t)B * sdr::NBLK * sdr::PSTRIDE + (size_t)B * sdr::SMAX) * sizeof(float) : 0;
+  return B > 0 ? ((size_t)B * sdr::NBLK * sdr::PSTRIDE + (size_t)B * sdr::SMAX) * sizeof(double) : 0;
 }
 
 int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
@@ -400,13 +400,14 @@ int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, 
   if (ws_bytes < onssen_batch_sdr_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)stream;
-  float* partial = (float*)ws;
-  float* means = partial + (size_t)B * sdr::NBLK * sdr::PSTRIDE;
+  if ((reinterpret_cast<uintptr_t>(ws) & 7u) != 0) return ONSSEN_E_ALIGN;
+  double* partial = (double*)ws;      // fp64 sums: see loss_sdr.inc
+  double* means = partial + (size_t)B * sdr::NBLK * sdr::PSTRIDE;
   const dim3 grid(sdr::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((sdr_partial_kernel<0>), grid, dim3(256), 0, st, est, org, mask, C, n, (const float*)nullptr, partial);
-  hipLaunchKernelGGL(sdr_means_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)partial, C, n, means);
-  hipLaunchKernelGGL((sdr_partial_kernel<1>), grid, dim3(256), 0, st, est, org, mask, C, n, (const float*)means, partial);
-  hipLaunchKernelGGL(sdr_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)partial, C, sdr_out, perm_out);
+  hipLaunchKernelGGL((sdr_partial_kernel<0>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)nullptr, partial);
+  hipLaunchKernelGGL(sdr_means_kernel, dim3((unsigned)B), dim3(64), 0, st, (const double*)partial, C, n, means);
+  hipLaunchKernelGGL((sdr_partial_kernel<1>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)means, partial);
+  hipLaunchKernelGGL(sdr_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const double*)partial, C, sdr_out, perm_out);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

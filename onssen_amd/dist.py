@@ -56,8 +56,9 @@ def gradient_buckets(model):
 
 
 def allreduce_gradients(model, world, group=None, buckets=None):
-    """Average gradients across ranks: one flat fp32 all-reduce(sum) per bucket, issued
-    asynchronously, then scaled by 1/world and scattered back."""
+    """Average gradients across ranks AFTER backward: one flat fp32 all-reduce(sum) per bucket, issued
+    asynchronously, then scaled by 1/world and scattered back.  (The non-overlapped form; ``GradientReducer`` issues
+    the same buckets while backward is still running.)"""
     if world == 1:
         return
     buckets = buckets if buckets is not None else gradient_buckets(model)
@@ -78,14 +79,121 @@ def allreduce_gradients(model, world, group=None, buckets=None):
             off += n
 
 
+class GradientReducer:
+    """The exchange of ``train_step`` overlapped with backward ("bucket by LSTM layer so layer-L buckets
+    reduce while layer L-1 back-propagates"; slot: onssen/utils/train.py:82-83).
+
+    A bucket's all-reduce is issued the moment its last gradient exists:
+      * heads / BatchNorm (they sit on top of the stack: their gradients come first) and, on the ATen path, the LSTM
+        parameters: ``register_post_accumulate_grad_hook`` per parameter, a countdown per bucket;
+      * the HIP BLSTM backward (one autograd Function for the whole stack, nn/_train.py) hands every layer's fresh
+        gradient tensors to ``layer_hook`` as soon as that layer's contractions are queued -- the reduce of layer l then
+        runs on RCCL's stream under the backward recurrence of layer l-1 -- and collects them, averaged in place, before
+        it returns them to autograd.
+    ``finish()`` (before clipping) waits for what is still in flight and writes the averages into ``p.grad``.
+    ``issued_in_backward`` counts the buckets issued before ``finish()`` was called -- the tests assert on it."""
+
+    def __init__(self, model, world, group=None):
+        self.world, self.group = world, group
+        self.buckets = gradient_buckets(model)
+        self.pending, self.layer_pending = [], []
+        self.issued_in_backward = 0
+        self._count = [0] * len(self.buckets)
+        self._handles = []
+        if world > 1:
+            for bi, ps in enumerate(self.buckets):
+                for p in ps:
+                    self._handles.append(p.register_post_accumulate_grad_hook(lambda p, bi=bi: self._ready(bi)))
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def begin(self):
+        self._count = [0] * len(self.buckets)
+        self.pending, self.layer_pending = [], []
+        self.issued_in_backward = 0
+
+    def _issue(self, tensors):
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.issued_in_backward += 1
+        return work, flat, tensors
+
+    def _ready(self, bi):
+        self._count[bi] += 1
+        ps = [p for p in self.buckets[bi] if p.requires_grad]
+        if self._count[bi] == len(ps):
+            if any(getattr(p, "_onssen_reduced", False) for p in ps):     # reduced inside the HIP backward already
+                for p in ps:
+                    p._onssen_reduced = False
+                return
+            self.pending.append(self._issue([p.grad for p in ps]))
+
+    # -- called by BLSTMTrainFunction.backward (nn/_train.py) --------------------------------------------------
+    def layer_hook(self, grad_tensors, params):
+        if self.world > 1:
+            self.layer_pending.append(self._issue(grad_tensors))
+            for p in params:
+                p._onssen_reduced = True
+
+    def layer_collect(self):
+        for work, flat, tensors in self.layer_pending:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        self.layer_pending = []
+
+    def finish(self):
+        issued = self.issued_in_backward
+        self.layer_collect()
+        for work, flat, tensors in self.pending:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        self.pending = []
+        self.issued_in_backward = issued
+
+
+def _reducer_for(model, world, group):
+    r = getattr(model, "_onssen_reducer", None)
+    if r is None or r.world != world or r.group is not group:
+        if r is not None:
+            r.close()
+        r = GradientReducer(model, world, group)
+        object.__setattr__(model, "_onssen_reducer", r)
+    return r
+
+
 def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, clip_norm=5.0):
     """One optimizer step in the order of onssen/utils/train.py:75-86 with the data-parallel
-    exchange inserted before gradient clipping.  Returns the local mean loss (float)."""
+    exchange inserted before gradient clipping (issued bucket by bucket DURING backward, see GradientReducer).
+    Returns the local mean loss (float).  If a persistent recurrence launch of this step's forward or backward
+    aborted, the exception is raised BEFORE the optimizer step: the weights stay untouched."""
+    from .nn import _train
+    from .nn._core import _XcdStatus
     output = model(input)
     loss_avg = torch.mean(loss_fn(output, label))
     optimizer.zero_grad()
-    loss_avg.backward()
-    allreduce_gradients(model, world, group)
+    reducer = _reducer_for(model, world, group) if world > 1 else None
+    if reducer is not None:
+        reducer.begin()
+    _train.LAYER_GRAD_REDUCER[0] = reducer
+    try:
+        loss_avg.backward()
+    finally:
+        _train.LAYER_GRAD_REDUCER[0] = None
+    if reducer is not None:
+        reducer.finish()
+    if input[0].is_cuda:
+        _XcdStatus.flush()            # aborted exchange / non-finite activations: raise here, not after the update
     torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return float(loss_avg.item())

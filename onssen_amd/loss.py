@@ -99,6 +99,8 @@ def _mask_term_hip(mask_A, mask_B, mag_mix, s1, s2, c1=None, c2=None):
     if (base is None or getattr(mask_B, "_base", None) is not base or mask_A.stride() != mask_B.stride()
             or mask_A.stride(2) * mask_A.shape[2] != mask_A.stride(1)):
         mask_A, mask_B = mask_A.contiguous(), mask_B.contiguous()   # not the strided views of one (B,T,F,2) buffer
+    if mask_A.dtype != torch.float32 or mask_B.dtype != torch.float32:   # autocast / a user-supplied half estimate: the kernel reads fp32
+        mask_A, mask_B = mask_A.float().contiguous(), mask_B.float().contiguous()
     f32 = lambda t: None if t is None else t.float().contiguous()
     mag, s1, s2, c1, c2 = f32(mag_mix), f32(s1), f32(s2), f32(c1), f32(c2)
     out = torch.empty(B, device=mag.device, dtype=torch.float32)

@@ -63,11 +63,18 @@ def recurrence_plan(B, H):
 
 
 class _XcdStatus:
-    """The persistent kernel bounds every wait and reports through two workspace words instead of hanging:
+    """The persistent kernels bound every wait and report through workspace words instead of hanging:
     [280] != 0 -> a wait gave up, the launch aborted, outputs are invalid; [281] == 1 -> some exchange group was
-    spread over several XCDs and used the slower placement-independent protocol.  They are fetched with an
-    asynchronous copy after each eager forward and examined at the next call (never inside a graph capture),
-    so a failure is reported one call late instead of costing a synchronisation per forward."""
+    spread over several XCDs and used the slower placement-independent accesses; [282] == 1 -> a non-finite h was seen
+    (a NaN cannot carry the exchange's data tag: it was replaced by 0, so the outputs are NOT the reference's NaNs).
+    The words are fetched with an asynchronous copy after each eager forward and examined
+      * by ``flush()`` -- called where a result is about to be consumed anyway: the end of ``separation.separate_*``,
+        ``dist.train_step`` BEFORE the optimizer step (an aborted forward or backward must never reach the weights), at
+        interpreter exit, and after every forward when ONSSEN_CHECK=1 (tests);
+      * otherwise at the next forward (never inside a graph capture), so that a plain ``model(x)`` does not pay a
+        synchronisation per call.
+    On an abort the words are reset (a stale abort word would abort every later launch on that workspace) and the
+    persistent forms are disabled for the process: inference and training take the launch-per-step / ATen paths."""
     pending = []
     safe_protocol_seen = False
 
@@ -75,30 +82,57 @@ class _XcdStatus:
     def post(cls, wsb):
         if torch.cuda.is_current_stream_capturing():
             return
-        host = torch.empty(2, dtype=torch.int32).pin_memory()
-        host.copy_(wsb[1120:1128].view(torch.int32), non_blocking=True)     # u32 words 280, 281
+        host = torch.empty(3, dtype=torch.int32).pin_memory()
+        host.copy_(wsb[1120:1132].view(torch.int32), non_blocking=True)     # u32 words 280, 281, 282
         ev = torch.cuda.Event()
         ev.record()
-        cls.pending.append((ev, host))
+        cls.pending.append((ev, host, wsb))
 
     @classmethod
     def poll(cls, wait=False):
-        keep = []
-        for ev, host in cls.pending:
+        keep, err = [], None
+        for ev, host, wsb in cls.pending:
             if wait:
                 ev.synchronize()
             if not ev.query():
-                keep.append((ev, host))
+                keep.append((ev, host, wsb))
                 continue
             if int(host[1]) == 1:
                 cls.safe_protocol_seen = True
-            if int(host[0]) != 0:
-                cls.pending = []
-                _XCD_DISABLED[0] = True
-                raise _abi.OnssenError(
-                    f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
-                    "of that forward are invalid.  The per-step recurrence is used from now on.")
+            if int(host[0]) != 0 or int(host[2]) != 0:
+                wsb[1120:1132].zero_()                  # abort / non-finite words: the next launch starts clean
+                if int(host[0]) != 0:
+                    _XCD_DISABLED[0] = True
+                    err = err or _abi.OnssenError(
+                        f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
+                        "(and, in training, the gradients) of that call are invalid.  The launch-per-step recurrence "
+                        "(inference) and the ATen LSTM (training) are used from now on.")
+                else:
+                    err = err or _abi.OnssenError(
+                        "non-finite activations inside the persistent recurrence (NaN / Inf in the input or the weights): "
+                        "they cannot pass its tagged exchange and were replaced by 0, so the outputs of that call are not the "
+                        "reference's NaNs.  ONSSEN_XCD=0 (launch per step) propagates them like nn.LSTM.")
         cls.pending = keep
+        if err is not None:
+            raise err
+
+    @classmethod
+    def flush(cls):
+        """Wait for every recorded status and raise if a launch aborted (see the class docstring)."""
+        if cls.pending and not torch.cuda.is_current_stream_capturing():
+            cls.poll(wait=True)
+
+
+def _flush_at_exit():
+    try:
+        _XcdStatus.flush()
+    except _abi.OnssenError as e:       # nobody is left to catch it: at least say so
+        import sys
+        print(f"onssen_amd: {e}", file=sys.stderr)
+
+
+import atexit
+atexit.register(_flush_at_exit)
 
 
 class BLSTMParams(nn.Module):
@@ -136,7 +170,8 @@ class BLSTMParams(nn.Module):
         """Training path (needs autograd).  On a ROCm device with H <= 640: the HIP forward with saved state and the
         HIP backward recurrence (nn/_train.py); ONSSEN_TRAIN_HIP=0, a CPU tensor or a wider layer
         take the stock ATen LSTM op instead."""
-        if x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+        if (x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"
+                and not _XCD_DISABLED[0]):
             from ._train import BLSTMTrainFunction
             if getattr(self, "_train_packed", None) is None:
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))
@@ -149,8 +184,46 @@ class BLSTMParams(nn.Module):
         return out
 
 
+_WEIGHT_EPOCH = [0]          # bumped by invalidate_packed_weights(): every packed image is rebuilt at its next use
+
+
+def invalidate_packed_weights():
+    """Drop every packed weight image of the process (they are rebuilt from the live parameters at the next forward).
+
+    The packed images are keyed on (data_ptr, tensor._version, device) of their source parameters.  In-place updates
+    through autograd-visible ops (optimizer steps, ``p.copy_()``, ``load_state_dict``) bump ``_version`` and are seen;
+    updates through ``p.data`` (``p.data.add_()``, EMA / weight-averaging code, hand-written checkpoint loaders) change
+    neither the version nor the pointer -- call this (or ``module.repack()``) after such an update.  ``load_state_dict``
+    and ``module.to()/.float()/...`` call it themselves; ``ONSSEN_CHECK_WEIGHTS=1`` adds a device-side checksum of the
+    parameters to the key (one synchronisation per forward: a debugging aid that finds forgotten calls)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 def _version_key(tensors):
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors)
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors) + (_WEIGHT_EPOCH[0],)
+    if os.environ.get("ONSSEN_CHECK_WEIGHTS") == "1" and not torch.cuda.is_current_stream_capturing():
+        key += (float(torch.stack([t.detach().double().abs().sum() for t in tensors]).sum()),)
+    return key
+
+
+class PackedWeightsMixin:
+    """nn.Module mixin of the onssen_amd.nn models: keeps the packed weight images honest across the ways parameters
+    change behind autograd's back (see invalidate_packed_weights)."""
+
+    def _init_packed_hooks(self):
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: invalidate_packed_weights())
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float() / .half() ...
+        out = super()._apply(fn, *args, **kwargs)
+        invalidate_packed_weights()
+        return out
+
+    def repack(self):
+        """Rebuild the packed weight images from the live parameters at the next forward."""
+        invalidate_packed_weights()
+        return self
+
+    invalidate = repack
 
 
 class PackedBLSTM:
@@ -350,7 +423,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
         y.x3_image = (wsb, off)                        # keeps the workspace alive with y
         _XcdStatus.post(wsb)
         if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
-            _XcdStatus.poll(wait=True)
+            _XcdStatus.flush()
     return y
 
 
@@ -392,6 +465,12 @@ def use_hip_path(module):
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         return False
     return True
+
+
+def needs_graph(*inputs):
+    """True when autograd is on and an INPUT wants a gradient (frozen parameters, e.g. input saliency): the HIP inference
+    path builds no graph, so such a forward must take the training path too."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in inputs)
 
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = _abi.EPI_BIAS, _abi.EPI_L2NORM, _abi.EPI_SIGMOID, _abi.EPI_RELU

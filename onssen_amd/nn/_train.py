@@ -126,8 +126,15 @@ class _Workspace:
         return buf
 
 
+LAYER_GRAD_REDUCER = [None]     # dist.GradientReducer of the running train_step, or None: see its layer_hook
+
+
 class BLSTMTrainFunction(torch.autograd.Function):
-    """y = BLSTM_stack(x) with HIP forward and backward.  x (B,T,In) -> (B,T,2H)."""
+    """y = BLSTM_stack(x) with HIP forward and backward.  x (B,T,In) -> (B,T,2H).
+
+    Differentiable ONCE: the backward recurrence overwrites the saved gate activations with dL/d(pre-activation) in
+    place, so a second backward through the same graph (retain_graph=True, double backward) raises instead of using
+    them.  All tensors are fp32 (autocast / bf16 inputs are cast on entry, never reinterpreted)."""
 
     @staticmethod
     def forward(ctx, x, packed, p_drop, *flat):
@@ -143,7 +150,9 @@ class BLSTMTrainFunction(torch.autograd.Function):
         Hp, NP = pk.Hp, pk.NP
         st = torch.cuda.current_stream().cuda_stream
         dev = x.device
-        x = x.contiguous()
+        if any(t.dtype != torch.float32 for t in flat):
+            raise TypeError("BLSTMTrainFunction: the LSTM parameters must be float32 (the kernels read them through raw fp32 pointers)")
+        x = x.float().contiguous()
         saved = []
         xin, xs_b, xs_t, in_l = x, T * In, In, In
         xp = x.transpose(0, 1).reshape(T * B, In)                        # time-major rows for the weight gradients
@@ -174,8 +183,13 @@ class BLSTMTrainFunction(torch.autograd.Function):
         return y[..., :H].reshape(T, B, 2 * H).transpose(0, 1).contiguous()
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy_bt):
         lib = get_lib()
+        if ctx.saved_layers is None:
+            raise RuntimeError("BLSTMTrainFunction: backward was already run on this graph -- its saved gate activations were "
+                               "overwritten in place by the backward recurrence (retain_graph / double backward are not supported)")
+        dy_bt = dy_bt.float()
         B, T, In, H, L, Hp, NP = ctx.dims
         ug, pk = ctx.ug, ctx.packed.get(ctx.ug)
         st = torch.cuda.current_stream().cuda_stream
@@ -208,7 +222,9 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 dx_rows, g = layer_gradients(gates, x_rows, y, w_ih, H, ug)
             for d in range(2):
                 o = (2 * l + d) * 4
-                grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = g[d][0], g[d][1], g[d][2], g[d][2]
+                grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = g[d][0], g[d][1], g[d][2], g[d][2].clone()
+            if LAYER_GRAD_REDUCER[0] is not None:     # data parallel: this layer's exchange runs under the layers below
+                LAYER_GRAD_REDUCER[0].layer_hook(grads[(2 * l) * 4:(2 * l + 2) * 4], flat[(2 * l) * 4:(2 * l + 2) * 4])
             if l > 0:
                 if use_x3:
                     dyl = dx_rows.view(T, B, 2, Hp)              # already the padded layout of the layer below
@@ -219,6 +235,8 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 dy = (dyl.reshape(T, B, 2 * Hp) * mprev).view(T, B, 2, Hp) if mprev is not None else dyl
                 dy = dy.contiguous()
         dx = dx_rows[:, :In].reshape(T, B, In).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
+        if LAYER_GRAD_REDUCER[0] is not None:
+            LAYER_GRAD_REDUCER[0].layer_collect()     # averaged in place before autograd accumulates them
         ctx.saved_layers = None
         return (dx, None, None) + tuple(grads)
 

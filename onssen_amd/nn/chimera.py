@@ -3,11 +3,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ._train import head_linear
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
+from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
 
-class chimera(nn.Module):
+class chimera(PackedWeightsMixin, nn.Module):
     """Drop-in for onssen.nn.chimera (onssen/nn/chimera.py:5-46).
 
     forward([x (B,T,F)]) -> [embedding (B,T,F,D), mask_A (B,T,F), mask_B (B,T,F)];
@@ -25,12 +25,13 @@ class chimera(nn.Module):
         self._head_dc = PackedHead(self.fc_dc, None, hidden_dim)
         self._head_mi = PackedHead(self.fc_mi, None, hidden_dim)
         self._ws = _Workspaces()
+        self._init_packed_hooks()
 
     def forward(self, input):
         assert len(input) == 1, "There must be one tensor in the input for the chimera network"
         x = input[0].float()
         batch_size, frame, frequency = x.size()
-        if not use_hip_path(self):
+        if not use_hip_path(self) or needs_graph(*input):
             return self._autograd_forward(x)
         emb, masks = self.embedding_and_masks(x)
         return [emb, masks[:, :, :, 0], masks[:, :, :, 1]]

@@ -3,11 +3,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ._train import head_linear
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
+from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
 
-class deep_clustering(nn.Module):
+class deep_clustering(PackedWeightsMixin, nn.Module):
     """Drop-in for onssen.nn.deep_clustering (onssen/nn/deep_clustering.py:5-43):
     same constructor, parameter names/shapes and list-in/list-out forward.
 
@@ -27,12 +27,13 @@ class deep_clustering(nn.Module):
         self._packed = PackedBLSTM(self.rnn)
         self._head = PackedHead(self.fc_dc, self.bn, hidden_dim)
         self._ws = _Workspaces()
+        self._init_packed_hooks()
 
     def forward(self, input):
         assert len(input) == 1, "There must be one tensor in the input for the deep clustering model"
         x = input[0].float()
         batch_size, frame, frequency = x.size()
-        if not use_hip_path(self):
+        if not use_hip_path(self) or needs_graph(*input):
             return [self._autograd_forward(x)]
         require_device(x, "deep_clustering")
         y = run_blstm(self._packed, self._ws, x,

@@ -1,12 +1,12 @@
 import torch
 import torch.nn as nn
 
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_RELU, EPI_SIGMOID, _stream, _version_key,
+from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_RELU, EPI_SIGMOID, _stream, _version_key,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 from ..hip import get_lib
 
 
-class enhance(nn.Module):
+class enhance(PackedWeightsMixin, nn.Module):
     """Drop-in for onssen.nn.enhance (onssen/nn/enhancement.py:5-52): same constructor, parameter names/shapes
     (rnn.*, bn.*, fc_mi, fc_pre, fc_post) and forward contract.
 
@@ -27,6 +27,7 @@ class enhance(nn.Module):
         self._packed = PackedBLSTM(self.rnn)
         self._head = PackedHead(self.fc_mi, self.bn, hidden_dim)
         self._ws = _Workspaces()
+        self._init_packed_hooks()
         self._small = None      # (key, w_pre, w_post): F x F weights padded to a multiple of 4 columns
 
     def _small_weights(self):
@@ -47,7 +48,7 @@ class enhance(nn.Module):
         assert len(input) == 2, "There must be two tensors in the input for the enhance network"
         x, mag_noisy = input[0].float(), input[1].float()
         batch_size, frame, frequency = x.size()
-        if not use_hip_path(self):
+        if not use_hip_path(self) or needs_graph(*input):
             return [self._autograd_forward(x, mag_noisy)]
         require_device(x, "enhance")
         lib = get_lib()

@@ -3,12 +3,12 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import get_lib
-from ._core import (BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
+from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
                     require_device, run_blstm, run_head, use_hip_path)
 from .chimera import chimera
 
 
-class phase_net(nn.Module):
+class phase_net(PackedWeightsMixin, nn.Module):
     """Drop-in for onssen.nn.phase_net (onssen/nn/phase_network.py:7-67).
 
     Upstream's constructor raises NameError on an undefined ``output_dim``
@@ -31,11 +31,12 @@ class phase_net(nn.Module):
         self._packed = PackedBLSTM(self.rnn)
         self._head = PackedHead(self.fc_phase, self.bn, hidden_dim)
         self._ws = _Workspaces()
+        self._init_packed_hooks()
 
     def forward(self, input):
         assert len(input) == 2, "There must be 2 tensors in the input for phase network"
         [x_mag, x_phase] = input
-        if not use_hip_path(self):
+        if not use_hip_path(self) or needs_graph(*input):
             return self._autograd_forward(x_mag.float(), x_phase.float())
         x_mag, x_phase = x_mag.float().contiguous(), x_phase.float().contiguous()
         require_device(x_mag, "phase_net")

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from .features import mask_istft, stft_logmag
+from .nn._core import _XcdStatus
 
 
 @torch.no_grad()
@@ -14,7 +15,9 @@ def separate_chimera(model, wav, window_size=256, hop_size=64):
     """wav (B, n) cuda float32 -> (B, 2, n): masks straight from the network."""
     logmag, ri = stft_logmag(wav, window_size, hop_size)
     _, masks = model.embedding_and_masks(logmag)
-    return mask_istft(ri, masks, hop_size, wav.shape[-1])
+    out = mask_istft(ri, masks, hop_size, wav.shape[-1])
+    _XcdStatus.flush()            # an aborted recurrence is reported by THIS call, not by the next one
+    return out
 
 
 def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
@@ -42,7 +45,10 @@ def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, hos
     logmag, ri = stft_logmag(wav, window_size, hop_size)
     emb, = model([logmag])
     if not host_kmeans:
-        return mask_istft(ri, dc_masks(emb, logmag, db_threshold), hop_size, wav.shape[-1])
+        out = mask_istft(ri, dc_masks(emb, logmag, db_threshold), hop_size, wav.shape[-1])
+        _XcdStatus.flush()        # an aborted recurrence is reported by THIS call, not by the next one
+        return out
+    _XcdStatus.flush()
     from sklearn.cluster import KMeans
     B, T, F, D = emb.shape
     masks = torch.zeros(B, T, F, 2, device=wav.device, dtype=torch.float32)

@@ -52,6 +52,16 @@ def _worker(rank, world, port, out):
     # ---- a full step keeps replicas identical
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     loss = odist.train_step(m, opt, loss_dc, inp, lab, world)
+    # ---- the exchange is issued DURING backward: with the reducer armed by hand, every bucket's all-reduce exists
+    #      when backward() returns (layer buckets reduce under the layers below), and finish() yields the mean
+    m2 = _model().eval()
+    red = odist.GradientReducer(m2, world)
+    red.begin()
+    torch.mean(loss_dc(m2(inp), lab)).backward()
+    issued = red.issued_in_backward
+    red.finish()
+    overl = [p.grad.clone() for p in m2.parameters()]
+    red.close()
     w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
     ws = [torch.empty_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
@@ -62,7 +72,8 @@ def _worker(rank, world, port, out):
     got = odist.gather_utterances(allx[lo:hi] * 2, n, world)
     if rank == 0:
         out.put(dict(local0=[g.numpy() for g in local], synced=[g.numpy() for g in synced], loss=loss,
-                     same=bool(torch.equal(ws[0], ws[1])), gathered=got.numpy()))
+                     same=bool(torch.equal(ws[0], ws[1])), gathered=got.numpy(), issued=issued, n_buckets=len(red.buckets),
+                     overl=[g.numpy() for g in overl]))
     else:
         out.put(dict(local1=[g.numpy() for g in local]))
     dist.barrier()
@@ -86,6 +97,9 @@ def test_two_rank_gloo_allreduce_and_sharding():
     for a, b, s in zip(res["local0"], res["local1"], res["synced"]):
         np.testing.assert_allclose(s, (a + b) / 2, rtol=1e-5, atol=1e-7)
     assert res["same"] and np.isfinite(res["loss"])
+    assert res["issued"] == res["n_buckets"] == 1 + 2 * 2            # all buckets were in flight before backward() returned
+    for o, s in zip(res["overl"], res["synced"]):
+        np.testing.assert_allclose(o, s, rtol=1e-6, atol=1e-8)
     np.testing.assert_array_equal(res["gathered"], np.arange(15, dtype=np.float32).reshape(5, 3) * 2)
 
 

@@ -443,6 +443,25 @@ def test_batch_sdr(lib, B, C, n, use_mask):
     np.testing.assert_array_equal(perm, ref_perm)
 
 
+@pytest.mark.parametrize("noise", [1e-2, 1e-4, 0.0])
+def test_batch_sdr_near_perfect_estimates(lib, noise):
+    """the residual power from a Gram matrix (ee - 2 s eo + s^2 oo) cancels; with fp32 sums the metric was off
+    by 0.1 dB at 50 dB and NaN from ~70 dB (oracle masks, est == ref sanity checks).  The sums are fp64 now: 40 dB, 80 dB
+    and the est == org ceiling (res_power = 1e-8, sdr.py:30) must all come out like the reference's direct sum."""
+    rng = np.random.default_rng(33)
+    B, C, n = 2, 2, 4000
+    org = rand(rng, B, C, n)
+    est = (org + noise * rand(rng, B, C, n)).astype(np.float32)
+    sdr = np.full(B, np.nan, np.float32); perm = np.full(B, -1, np.int32)
+    ws = aligned_f32(lib.batch_sdr_workspace_bytes(B) // 4 + 64)
+    lib.batch_sdr(P(est), P(org), None, B, C, n, P(sdr), P(perm), P(ws), ws.nbytes, None)
+    ref_sdr, ref_perm = O.batch_sdr(est, org, None)
+    assert np.all(np.isfinite(sdr)) and ref_sdr.min() > 35.0
+    # fp32 inputs: the centred signals differ from the fp64 restatement by ~1e-7 relative, i.e. a floor near -140 dB
+    np.testing.assert_allclose(sdr, ref_sdr, atol=0.02 if noise else 0.5)
+    np.testing.assert_array_equal(perm, ref_perm)
+
+
 @pytest.mark.parametrize("psa", [False, True])
 def test_loss_mask_term(lib, psa):
     """onssen_loss_mask_f32 against NumPy: both speaker assignments, MSA and PSA targets, strided mask views."""

@@ -27,11 +27,11 @@ d = ws[nb - 65536:].cpu().numpy().view(np.int64)[:64 * 16].reshape(64, 16)[2:62]
 per = (d[1:, 0] - d[:-1, 0]).mean()
 m = lambda a, b: (d[:, a] - d[:, b]).mean()
 st = ws[:2048].cpu().numpy().view(np.uint32)
-print(f"ablate={AB} B={B} ug={ug} waves={os.environ.get('ONSSEN_XCD_WAVES', 8)}: cycles/step {per:.0f} | wave 0: step start->first chunk complete {m(8,0):.0f} | "
-      f"all chunks + MFMA {m(7,8):.0f} | partials written {m(2,7):.0f} | barrier {m(3,2):.0f} | G prefetch + cell update + hand-off stores issued {m(4,3):.0f} | "
+print(f"ablate={AB} B={B} ug={ug} waves={os.environ.get('ONSSEN_XCD_WAVES', 8)}: cycles/step {per:.0f} | wave 0: step start->all chunks complete {m(8,0):.0f} | "
+      f"MFMA {m(7,8):.0f} | partials written {m(2,7):.0f} | barrier {m(3,2):.0f} | G prefetch + cell update + hand-off stores issued {m(4,3):.0f} | "
       f"output stores + pause {m(6,4):.0f} | next chunks requested {m(5,6):.0f} | to next step {(d[1:, 0] - d[:-1, 5]).mean():.0f} | abort={st[280]} safe={st[281]} nonfinite={st[282]}"
       f" || passes per step: wave 0 {d[:,15].mean():.2f}, last wave {d[:,14].mean():.2f}"
-      f" || last wave: chunks requested {(d[:-1, 9] - d[:-1, 3]).mean():.0f} after the barrier | first chunk complete {(d[1:, 10] - d[:-1, 9]).mean():.0f} | MFMA done {m(11,10):.0f} | wave 0's MFMA done {m(7,11):.0f} later")
+      f" || last wave: chunks requested {(d[:-1, 9] - d[:-1, 3]).mean():.0f} after the barrier | all chunks complete {(d[1:, 10] - d[:-1, 9]).mean():.0f} | MFMA done {m(11,10):.0f} | wave 0's MFMA done {m(7,11):.0f} later")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5): layer(AB)
