@@ -90,6 +90,12 @@ def istft(spec_tf, hop, length):
     spec_tf: (T, F) complex.  n_fft = 2(F-1); periodic-Hann synthesis window;
     overlap-add; divide by the window sum-of-squares where it exceeds
     ``tiny``; drop the first n_fft//2 samples; fix length.  float64 result.
+
+    One deliberate difference from librosa 0.7/0.8: its ``istft`` overlap-adds the frames and the window sum in ``dtype``
+    = float32 by default; this restatement accumulates in float64 (the HIP kernel stores float32 frames and accumulates
+    the <= 4 overlapping ones in float64).  The two differ by ~1e-7 of the signal scale -- far inside the 2e-6 tolerance
+    of the parity tests, but it is why those tests do not ask for bit equality.  Cross-checked against torch.istft and
+    scipy.signal.istft in tests/test_oracle.py (librosa itself is not installable here: parity unpinned).
     """
     spec_tf = np.asarray(spec_tf)
     T, F = spec_tf.shape

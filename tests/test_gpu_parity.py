@@ -381,6 +381,113 @@ def test_mask_istft_and_roundtrip(dev, n_fft, hop, n, length):
     np.testing.assert_allclose(y[:, :k], wav[:, :k], atol=2e-6)
 
 
+def cfg5_inputs(seed, B, n_samples=16000, n_fft=512, hop=128):
+    """The input recipe of tools/gen_golden_cfg5.py (seeded synthetic 16 kHz mixtures -> log-magnitude, (Re, Im))."""
+    mags, phs = [], []
+    for b in range(B):
+        X = O.stft(synth_mixture(seed * 100 + b, n_samples=n_samples, sr=16000), n_fft, hop)
+        mags.append(O.log_magnitude(X))
+        phs.append(O.phase_re_im(X))
+    return np.stack(mags).astype(np.float32), np.stack(phs).astype(np.float32)
+
+
+def test_cfg5_phase_net_full_shape_golden(dev, golden_dir, prec):
+    """BASELINE config 5 at its full shape: phase_net with F = 257 (STFT 512/128 at 16 kHz), H = 600,
+    L = 4, T = 126 one-second chunks -- the first layer of the phase BLSTM has K = 3F = 771, its head is the residual +
+    2-wide L2-norm -- against the reference's strided subsample and per-frame checksums (tools/gen_golden_cfg5.py)."""
+    z = np.load(f"{golden_dir}/g2_cfg5_phase_L4.npz")
+    m, _ = build("phase_net", z, dev)
+    x_mag, x_phase = cfg5_inputs(int(z["x_seed"]), int(z["B"]))
+    with torch.no_grad():
+        emb, ma, mb, pa, pb = [o.cpu().numpy() for o in m([torch.from_numpy(x_mag).to(dev), torch.from_numpy(x_phase).to(dev)])]
+    assert emb.shape == (2, 126, 257, 20) and pa.shape == (2, 126, 257, 2)
+    e_sub = emb[:, ::9, ::16, :]
+    print(f"[{prec['name']}] cfg5: emb max abs err {np.abs(e_sub - z['emb_sub']).max():.3e}, rel-L2 {rel_l2(e_sub, z['emb_sub']).max():.3e}; "
+          f"phase max abs err {max(np.abs(pa[:, ::5, ::4] - z['phase_A_sub']).max(), np.abs(pb[:, ::5, ::4] - z['phase_B_sub']).max()):.3e}")
+    np.testing.assert_allclose(e_sub, z["emb_sub"], atol=1e-5, rtol=1e-4)
+    assert rel_l2(e_sub, z["emb_sub"]).max() < 1e-4
+    np.testing.assert_allclose(emb.astype(np.float64).sum(axis=(2, 3)), z["emb_sum_per_frame"], atol=5e-3)
+    np.testing.assert_allclose(ma[:, ::5, :], z["mask_A_sub"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(mb[:, ::5, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
+    # the phase outputs normalise a 2-vector (re, im) + residual that can be short: round-off is amplified there
+    # (the oracle itself needs 3e-5 on the tiny fixture); unit norm is checked exactly
+    ptol = 2e-4 if prec["name"] != "f32" else 1e-4
+    np.testing.assert_allclose(pa[:, ::5, ::4, :], z["phase_A_sub"], atol=ptol)
+    np.testing.assert_allclose(pb[:, ::5, ::4, :], z["phase_B_sub"], atol=ptol)
+    np.testing.assert_allclose(np.linalg.norm(pa, axis=-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(pa.astype(np.float64).sum(axis=(2, 3)), z["phase_A_sum_per_frame"], atol=2e-2)
+    np.testing.assert_allclose(pb.astype(np.float64).sum(axis=(2, 3)), z["phase_B_sum_per_frame"], atol=2e-2)
+
+
+def test_cfg3_chimera_batch_64_matches_aten_oracle(dev, monkeypatch):
+    """BASELINE config 3 at its bench batch: chimera++ L = 4, H = 600 with B = 64 -- 16-row exchange
+    groups, the first layer's projection fused into the recurrence launch, two heads on the x3 image -- against the
+    ATen-on-CPU oracle (itself pinned to the reference by the B = 1 fixture g2_cfg3_chimera_L4)."""
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    monkeypatch.setenv("ONSSEN_XCD", "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    B, T = 64, 80
+    m, sd = build("chimera", dict(F=129, H=600, L=4, D=20, C=2, seed=0, gain=1.0), dev)
+    x = logmag_input(13, B, T)
+    ref = [r.numpy() for r in TC.chimera_forward(sd, x)]
+    with torch.no_grad():
+        outs = [o.cpu().numpy() for o in m([torch.from_numpy(x).to(dev)])]
+    print(f"cfg3 B=64: emb max abs err {np.abs(outs[0] - ref[0]).max():.3e}, rel-L2 {rel_l2(outs[0], ref[0]).max():.3e}")
+    np.testing.assert_allclose(outs[0], ref[0], atol=1e-5, rtol=1e-4)
+    assert rel_l2(outs[0], ref[0]).max() < 1e-4
+    np.testing.assert_allclose(outs[1], ref[1], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(outs[2], ref[2], atol=1e-5, rtol=1e-4)
+
+
+def test_feature_kernels_match_reference_fixture(dev, golden_dir):
+    """the label kernel (one_hot / |S| / cos) against the REFERENCE's get_one_hot / get_cos_difference
+    outputs (tests/golden/g3_features.npz, tools/gen_golden_features.py) on the fixture's STFTs."""
+    from onssen_amd.features import training_labels
+    z = np.load(f"{golden_dir}/g3_features.npz")
+    for tag in ("a", "b"):
+        X, S1, S2 = z[f"{tag}_X"], z[f"{tag}_S1"], z[f"{tag}_S2"]
+        ri = lambda c: torch.from_numpy(np.stack([c.real, c.imag], -1).astype(np.float32))[None].to(dev)
+        feat = torch.from_numpy(z[f"{tag}_log_magnitude"])[None].to(dev)
+        for db in (40, 20):
+            oh, mm, m1, m2, c1, c2 = training_labels(ri(X), ri(S1), ri(S2), feat, float(db), with_cos=True)
+            ref = z[f"{tag}_one_hot_{db}"]
+            # argmax ties (|S1| == |S2| to the last bit, e.g. both silent) are the only bins allowed to differ
+            diff = (oh[0].cpu().numpy() != ref).any(-1)
+            assert np.all(np.abs(np.abs(S1) - np.abs(S2))[diff] <= 1e-6 * (np.abs(S1) + np.abs(S2))[diff] + 1e-12), diff.sum()
+            assert diff.mean() < 1e-3
+        np.testing.assert_allclose(mm[0].cpu().numpy(), np.abs(X), rtol=2e-6, atol=1e-8)
+        big = (np.abs(X) > 1e-3) & (np.abs(S1) > 1e-3) & (np.abs(S2) > 1e-3)
+        np.testing.assert_allclose(c1[0].cpu().numpy()[big], z[f"{tag}_cos_s1"][big], atol=1e-4)
+        np.testing.assert_allclose(c2[0].cpu().numpy()[big], z[f"{tag}_cos_s2"][big], atol=1e-4)
+
+
+def test_end_to_end_separation_dc_matches_oracle(dev, monkeypatch):
+    """deep-clustering separation end to end -- separate_dc(host_kmeans=True), i.e. upstream's
+    sklearn KMeans(2, random_state=0) on the active bins -- against the oracle's mask-apply + iSTFT fed with the SAME
+    labels computed here from the oracle's embedding (egs/wsj0-2mix/deep_clustering/evaluate.py:31-45)."""
+    from sklearn.cluster import KMeans
+    from onssen_amd.separation import separate_dc
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16x3")
+    m, sd = build("deep_clustering", dict(F=129, H=48, L=2, D=20, C=2, seed=8, gain=1.5), dev)
+    n = 6400
+    wav = np.stack([synth_mixture(75 + b, n) for b in range(2)])
+    sig = separate_dc(m, torch.from_numpy(wav).to(dev), host_kmeans=True).cpu().numpy()
+    for b in range(2):
+        X = O.stft(wav[b], 256, 64)
+        feat = O.log_magnitude(X)
+        emb = O.deep_clustering_forward(sd, feat[None])[0]
+        act = O.dc_active_bins(feat)
+        lab = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(emb[act])
+        masks = O.dc_binary_masks(feat, lab)                       # (2, T, F): label 1 -> speaker 0 like evaluate.py:38-41
+        ref = O.mask_istft(X, masks, 64, n)
+        # a bin whose embedding sits between the clusters may flip with the 1e-5 embedding difference: compare per speaker
+        # with the better of the two label orders and allow a few flipped bins' worth of energy
+        err = min(np.abs(sig[b] - ref).max(), np.abs(sig[b] - ref[::-1]).max())
+        assert err < 5e-3, err
+        best = ref if np.abs(sig[b] - ref).max() <= np.abs(sig[b] - ref[::-1]).max() else ref[::-1]
+        assert np.mean(np.abs(sig[b] - best) > 5e-5) < 0.02
+
+
 def test_end_to_end_separation_chimera(dev, prec):
     from onssen_amd.separation import separate_chimera
     m, sd = build("chimera", dict(F=129, H=48, L=2, D=20, C=2, seed=4, gain=1.5), dev)

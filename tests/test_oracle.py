@@ -163,3 +163,51 @@ def test_batch_sdr_restatement_matches_reference_fixture(golden_dir):
         sdr, perm = O.batch_sdr(z[f"{tag}_est"], z[f"{tag}_org"], z[f"{tag}_mask"] if f"{tag}_mask" in z.files else None)
         np.testing.assert_allclose(sdr, z[f"{tag}_sdr"], rtol=1e-4, atol=1e-4)
         np.testing.assert_array_equal(perm, z[f"{tag}_perm"])
+
+
+# ----------------------------------------------------------------------------- G3: label / feature helpers pinned by the reference
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_feature_helpers_match_reference_fixture(golden_dir, tag):
+    """get_log_magnitude / get_phase / get_cos_difference / get_one_hot of the reference
+    (onssen/data/feature_utils.py:49-95, run by tools/gen_golden_features.py) against the oracle restatements --
+    bit for bit: they are the same NumPy expressions."""
+    z = np.load(f"{golden_dir}/g3_features.npz")
+    X, S1, S2 = z[f"{tag}_X"], z[f"{tag}_S1"], z[f"{tag}_S2"]
+    feat = O.log_magnitude(X)
+    assert feat.dtype == z[f"{tag}_log_magnitude"].dtype == np.float32
+    np.testing.assert_array_equal(feat, z[f"{tag}_log_magnitude"])
+    np.testing.assert_array_equal(O.log_magnitude(X, 1e-3), z[f"{tag}_log_magnitude_eps3"])
+    np.testing.assert_array_equal(O.phase_re_im(X), z[f"{tag}_phase"])
+    np.testing.assert_array_equal(O.cos_difference(X, S1), z[f"{tag}_cos_s1"])
+    np.testing.assert_array_equal(O.cos_difference(X, S2), z[f"{tag}_cos_s2"])
+    for db in (40, 20):
+        oh = O.one_hot_labels(feat, np.abs(S1), np.abs(S2), db)
+        assert oh.dtype == z[f"{tag}_one_hot_{db}"].dtype == np.float64          # the reference yields float64 labels
+        np.testing.assert_array_equal(oh, z[f"{tag}_one_hot_{db}"])
+    assert 0.0 < z[f"{tag}_one_hot_40"].sum(-1).mean() < 1.0                     # silent bins exist, active bins exist
+
+
+@pytest.mark.filterwarnings("ignore:NOLA")
+@pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 25536), (512, 128, 16000), (256, 64, 5000)])
+def test_stft_istft_second_cross_check_scipy(n_fft, hop, n):
+    """The STFT / iSTFT legs are unpinned by the reference (librosa is not installable here).  Second independent
+    cross-check next to torch.stft / torch.istft: scipy.signal (scipy 1.15) with librosa's conventions spelled out --
+    periodic Hann, reflect padding of n_fft/2, no scaling on the forward transform."""
+    from scipy import signal
+    sig = synth_mixture(3, n)
+    X = O.stft(sig, n_fft, hop)                                   # (T, F) complex64
+    w = signal.get_window("hann", n_fft, fftbins=True)
+    padded = np.pad(sig.astype(np.float64), n_fft // 2, mode="reflect")
+    _, _, Z = signal.stft(padded, window=w, nperseg=n_fft, noverlap=n_fft - hop, boundary=None, padded=False,
+                          return_onesided=True, scaling="spectrum")
+    Z = (Z * w.sum()).T                                           # undo scipy's 1/sum(w) scaling
+    assert Z.shape == X.shape
+    np.testing.assert_allclose(X, Z.astype(np.complex64), atol=2e-5 * np.abs(Z).max())
+    # inverse: scipy's istft (overlap-add / window sum-of-squares normalisation, NOLA) on the same spectrum
+    y = O.istft(X, hop, n)
+    _, ys = signal.istft((X.T.astype(np.complex128)) / w.sum(), window=w, nperseg=n_fft, noverlap=n_fft - hop, input_onesided=True,
+                         boundary=None, scaling="spectrum")
+    ys = ys[n_fft // 2:n_fft // 2 + n]
+    m = min(len(ys), n)
+    np.testing.assert_allclose(y[:m], ys[:m], atol=2e-6)
+    np.testing.assert_allclose(y[n_fft:m - n_fft], sig[n_fft:m - n_fft], atol=2e-6)      # and the round trip itself
