@@ -7,8 +7,9 @@ One "step" = one pass of the hot path over one batch of synthetic 8 kHz
 2-speaker mixtures that is already resident in HBM:
     K1+K2  framed STFT 256/64 + log-magnitude
     K3-K8  deep-clustering network (BASELINE configs[1]: 2 x BLSTM-600, fc_dc + per-bin L2 normalise)
-    K10    mask-apply + iSTFT overlap-add for 2 speakers (binary masks resident in HBM: the
-           K-means assignment is host-side and not part of the timed path)
+    K10    mask-apply + iSTFT overlap-add for 2 speakers (binary masks resident in HBM; the same step
+           with the device-side threshold + 2-means back end in front of K10 is reported next to the headline as
+           "separate_dc_with_device_kmeans")
 captured once in a hipGraph and replayed.  N>1: one process per GPU (launched by
 torch.distributed.run), every rank separates its own batch -- utterances are independent, so
 there is no data-path collective ("scaling": "weak").
@@ -161,8 +162,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        per_rank_ms = [1e3 * elapsed / args.steps]
         if world > 1:
             te = torch.tensor([elapsed], device="cpu" if one_dev else dev, dtype=torch.float64)
+            every = [torch.empty_like(te) for _ in range(world)]
+            dist.all_gather(every, te)                     # every rank's own clock: a straggler shows up by rank
+            per_rank_ms = [1e3 * float(t.item()) / args.steps for t in every]
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
@@ -203,6 +208,7 @@ def main():
         "frames_per_s": frames / elapsed,
         "sep_hours_per_s": audio_s / elapsed / 3600.0,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "per_rank_ms_per_step": per_rank_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16": "bf16 products, fp32 accumulate / gates / state (opt-in, below the 1e-4 parity contract)",
                   "bf16x3": "f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate)"}[args.precision],
@@ -221,9 +227,9 @@ def main():
     _XcdStatus.poll(wait=True)     # raises if a persistent launch aborted
     for mod in (model, getattr(model, "chimera", None)):      # the graph replays' own status words
         for buf in (mod._ws.cache.values() if mod is not None else ()):
-            st = buf[1120:1128].cpu().view(torch.int32)
-            if int(st[0]) != 0:
-                raise SystemExit(f"persistent recurrence aborted during the timed region (code {int(st[0])})")
+            st = buf[1120:1132].cpu().view(torch.int32)
+            if int(st[0]) != 0 or int(st[2]) != 0:
+                raise SystemExit(f"persistent recurrence aborted / saw non-finite activations during the timed region (words {st.tolist()})")
             _XcdStatus.safe_protocol_seen |= int(st[1]) == 1
     result["config"]["recurrence"] = ("XCD-local persistent kernel (one launch per layer)" if recurrence_plan(B, H)[1] & 4
                                       else "one launch per time step")
@@ -382,8 +388,9 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
            "achieved": flop_rec / t_rec / 1e12, "peak": peak, "unit": "TFLOP/s",
            "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
            "peak_note": "dense bf16 MFMA 2500 TF" if bf16_only else "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
-           "bound_note": "a serial chain of T dependent time steps: the kernel is bound by the per-step exchange latency "
-                         "(two L2 round trips + barrier), not by MFMA issue or HBM -- see DESIGN.md",
+           "bound_note": "a serial chain of T dependent time steps: each is cell update -> tagged h stores -> L2 -> polled "
+                         "fragment loads -> MFMAs -> LDS reduction, bound by that chain's latency, not by MFMA issue or HBM "
+                         "-- see DESIGN.md",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
            "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
@@ -399,33 +406,35 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
 
 
 def cpu_baseline(sd, kind, wav_np, masks_np):
-    """The oracle restatement (NumPy STFT/iSTFT + ATen-on-CPU network) timed on this host's cores on
-    a bounded sample of the same workload."""
+    """The oracle restatement (NumPy STFT/iSTFT + ATen-on-CPU network) timed on this host's cores on a bounded sample of
+    the same workload.  ``value`` = the whole hot path on 8 of the batch's chunks per pass (best of a few thread counts:
+    ATen's LSTM does not scale to every core of a big host).  ``network_only`` = SURVEY 8(d)'s CPU reference timing of the
+    network forward alone: eval mode, no_grad, fp32, all cores torch uses by default, 3 warm-ups, median of 10 (B = 1) /
+    of up to 5 within 8 s (B = 32), T = 400."""
     from oracle import np_oracle as O
     from oracle import torch_cpu as TC
     n_thr = torch.get_num_threads()
     Bs = min(len(wav_np), 8)                     # bounded sample: 8 chunks of the batch
-    wav_np, masks_np = wav_np[:Bs], masks_np[:Bs]
+    wav_s, masks_s = wav_np[:Bs], masks_np[:Bs]
 
     def once():
-        X = [O.stft(w, NFFT, HOP) for w in wav_np]
+        X = [O.stft(w, NFFT, HOP) for w in wav_s]
         lm = np.stack([O.log_magnitude(x) for x in X])
         if kind == "chimera":
             _, a, b = TC.chimera_forward(sd, lm)
             mk = np.stack([a.numpy(), b.numpy()], 1)
         else:
             TC.deep_clustering_forward(sd, lm)
-            mk = masks_np.transpose(0, 3, 1, 2)
+            mk = masks_s.transpose(0, 3, 1, 2)
         for i in range(Bs):
             O.mask_istft(X[i], mk[i], HOP, N_SAMPLES)
 
-    # ATen's LSTM does not scale to every core of a big host: time a few thread counts, keep the best
     best = None
     for thr in sorted({min(n_thr, 8), min(n_thr, 16), min(n_thr, 32), n_thr}):
         torch.set_num_threads(thr)
         once()
         ts, t_start = [], time.perf_counter()
-        while len(ts) < 5 and time.perf_counter() - t_start < 6.0:
+        while len(ts) < 5 and time.perf_counter() - t_start < 4.0:
             t0 = time.perf_counter()
             once()
             ts.append(time.perf_counter() - t0)
@@ -433,12 +442,29 @@ def cpu_baseline(sd, kind, wav_np, masks_np):
         if best is None or med_t < best[0]:
             best = (med_t, thr, len(ts))
     torch.set_num_threads(n_thr)
-    med, n_thr, n_pass = best
-    ts = [0] * n_pass
+    med, best_thr, n_pass = best
+
+    fwd = TC.chimera_forward if kind == "chimera" else TC.deep_clustering_forward
+    lm_all = np.stack([O.log_magnitude(O.stft(w, NFFT, HOP)) for w in wav_np[:min(len(wav_np), 32)]])
+    if len(lm_all) < 32:
+        lm_all = np.concatenate([lm_all] * (32 // len(lm_all) + 1))[:32]
+    net = {}
+    for nb, reps, cap in ((1, 10, 4.0), (32, 5, 8.0)):
+        x = lm_all[:nb]
+        for _ in range(3 if nb == 1 else 1):
+            fwd(sd, x)
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < reps and (not ts or time.perf_counter() - t_start < cap):
+            t0 = time.perf_counter()
+            fwd(sd, x)
+            ts.append(time.perf_counter() - t0)
+        m = float(np.median(ts))
+        net[f"B{nb}"] = {"ms": 1e3 * m, "x_real_time": nb * (T_FRAMES * HOP / SR) / m, "passes": len(ts), "threads": n_thr}
     return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
-            "frames_per_s": Bs * T_FRAMES / med, "cores": n_thr, "kind": "port",
-            "sample": f"{Bs} of the batch's 400-frame chunks per pass, median of {len(ts)} passes "
-                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {n_thr} threads)"}
+            "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "kind": "port",
+            "sample": f"{Bs} of the batch's 400-frame chunks per pass, median of {n_pass} passes "
+                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads)",
+            "network_only": net}
 
 
 if __name__ == "__main__":

@@ -1,14 +1,18 @@
 // libonssen_hip.so -- hand-written HIP kernels for gfx950 (MI355X / CDNA4) behind the C ABI of
 // include/onssen_hip.h.  See DESIGN.md for the data layouts and the per-kernel rooflines.
 //
-// Kernel inventory:
-//   stft_logmag_kernel   K1+K2   fp64 radix-2 FFT in LDS, one wavefront per frame, fused log10(|X|+eps)
-//   linear_kernel        K3/K7/K8/K9  128x80x16 LDS-tiled GEMM on v_mfma_f32_16x16x4_f32 (exact fp32),
-//                        epilogues: bias | bias(+residual)+group L2-normalise (wave shuffles) | bias+sigmoid
-//   lstm_step_kernel     K4      one launch per time step, both directions; K split over the 4 waves of a
-//                        workgroup, LDS reduction, fused sigmoid/tanh cell update
-//   mask_istft_kernel    K10     mask-apply + fp64 inverse FFT + gather overlap-add (no atomics)
-//   pack_* kernels       one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold)
+// Kernel inventory (one translation unit, the parts are the .inc files next to this one):
+//   fft.inc             stft_logmag_kernel (K1+K2: fp64 radix-4 FFT in LDS, one wavefront per frame, fused log10(|X|+eps)),
+//                       mask_istft_kernel (K10: mask-apply + fp64 inverse FFT, two speakers per transform, gather overlap-add)
+//   gemm.inc            linear_x3p_kernel (K3/K7/K8/K9 on pre-split bf16 images: 256x160 tiles, 8 waves, register epilogues
+//                       bias | sigmoid | grouped L2-norm), linear_x3_kernel / linear_kernel (fp32-A forms, exact-fp32 MFMA),
+//                       x3_image(_t)_kernel (fp32 -> split-bf16 operand images)
+//   lstm.inc            lstm_xcd_kernel (K4, default: XCD-local persistent recurrence, ONE launch per layer, data-tagged h
+//                       exchange through the XCD's L2), lstm_step_kernel (one launch per time step: fallback and f32 mode)
+//   lstm_bwd.inc        lstm_xcd_bwd_kernel / lstm_bwd_step_kernel (training: backward recurrence)
+//   labels_cluster.inc  labels_kernel (training labels), kmeans2_* (deep-clustering back end)
+//   loss_sdr.inc        loss_dc_* / loss_mask_* (loss values), sdr_* (batch SI-SDR with best permutation, fp64 sums)
+//   pack.inc            one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold)
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 

@@ -11,6 +11,10 @@ the host and yields ``(input_list, label_list)``.  There is no corpus here, so u
     "chimera"   [feature_mix] , [one_hot, mag_mix, mag_s1, mag_s2]
     "chimera++" [feature_mix] , [one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2]
     "phase"     [feature_mix, phase_mix] , [one_hot, mag_mix, mag_s1, mag_s2, phase_s1, phase_s2]
+
+``one_hot`` is float64 like upstream's (np.zeros default, feature_utils.py:86; the losses cast).  Partition "tt" follows
+the EVALUATION contract (wsj0_2mix_eval_dataset, wsj0_2mix.py:166-245): whole utterances, batch 1,
+``[feature_mix (1,T,F)] , [stft_r_mix (1,T,F), stft_i_mix (1,T,F), sig_ref (1,2,n)]`` with n padded to a multiple of 32.
 """
 import numpy as np
 import torch
@@ -29,13 +33,28 @@ class SyntheticWsj02mix:
         self.db_threshold = float(g("db_threshold"))
         self.device = torch.device(device if device is not None else "cuda:0")
         self.num_batches = num_batches
+        self.partition = partition
         self.seed = seed + {"tr": 0, "cv": 10_000, "tt": 20_000}.get(partition, 30_000)
         self.n_samples = self.hop_size * (self.frame_length + 40)     # a little longer than one chunk: crops differ
 
     def __len__(self):
         return self.num_batches
 
+    def _iter_eval(self):
+        for it in range(self.num_batches):
+            n = self.hop_size * (self.frame_length + 17 * (it % 3)) + 5 * it          # utterances differ in length
+            mix, s1, s2 = synth_mixture(self.seed + it, n, self.sampling_rate, return_sources=True)
+            gap = 32 - n % 32                                                          # get_sigs (wsj0_2mix.py:216-228)
+            pad = lambda a: np.pad(a, (0, gap))
+            wav = torch.from_numpy(pad(mix)[None]).to(self.device)
+            logmag, ri = stft_logmag(wav, self.window_size, self.hop_size)
+            sig_ref = torch.from_numpy(np.stack([pad(s1), pad(s2)])[None]).to(self.device)
+            yield [logmag], [ri[..., 0].contiguous(), ri[..., 1].contiguous(), sig_ref]
+
     def __iter__(self):
+        if self.partition == "tt":
+            yield from self._iter_eval()
+            return
         rng = np.random.default_rng(self.seed)
         B, L = self.batch_size, self.frame_length
         for it in range(self.num_batches):
@@ -51,6 +70,7 @@ class SyntheticWsj02mix:
             with_cos = self.model_name == "chimera++"
             out = training_labels(mix, s1, s2, feat, self.db_threshold, with_cos=with_cos)
             one_hot, mm, m1, m2 = out[:4]
+            one_hot = one_hot.double()
             if self.model_name == "dc":
                 yield [feat], [one_hot, mm]
             elif self.model_name == "chimera":

@@ -28,3 +28,88 @@ def batch_SDR_torch(estimation, origin, mask=None, return_perm=False):
     lib.batch_sdr(est.data_ptr(), org.data_ptr(), mk.data_ptr() if mk is not None else None, B, C, n, sdr.data_ptr(),
                   perm.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     return (sdr, perm.long()) if return_perm else sdr
+
+
+# ----------------------------------------------------------------------------- tester.get_est_sig-shaped adapters
+class tester:
+    """Body of onssen.utils.tester (onssen/utils/test.py:7-41) around this package's back end: ``args`` carries ``model``,
+    ``test_loader`` and ``device`` like upstream; checkpoint loading stays with the caller (``model`` is used as given
+    unless ``args`` has a ``checkpoint_path`` whose ``final.mdl`` exists).  ``eval()`` returns the mean SI-SDR (upstream
+    only prints it).  The evaluation loader yields, per utterance (onssen/data/wsj0_2mix.py:231-245, batch 1 upstream, any
+    batch here): ``[feature_mix (B,T,F)]``, ``[stft_r_mix (B,T,F), stft_i_mix (B,T,F), sig_ref (B,C,n)]``."""
+
+    def __init__(self, args):
+        import os
+        g = (lambda k, d=None: args.get(k, d)) if isinstance(args, dict) else (lambda k, d=None: getattr(args, k, d))
+        self.model_name, self.test_loader = g("model_name"), g("test_loader")
+        self.device = torch.device(g("device", "cuda:0"))
+        self.model = g("model")
+        ck = g("checkpoint_path")
+        if ck and os.path.exists(os.path.join(ck, "final.mdl")):
+            self.model.load_state_dict(torch.load(os.path.join(ck, "final.mdl"))["model"])
+        self.model = self.model.to(self.device)
+
+    def get_est_sig(self, input, label, output):
+        raise NotImplementedError
+
+    def eval(self):
+        from .nn._core import _XcdStatus
+        total, count = 0.0, 0
+        self.model = self.model.eval()
+        with torch.no_grad():
+            for input, label in self.test_loader:
+                output = self.model(input)
+                sig_est, sig_ref = self.get_est_sig(input, label, output)
+                sdr = batch_SDR_torch(sig_est, sig_ref)
+                _XcdStatus.flush()
+                total += float(sdr.sum())
+                count += sdr.numel()
+        return total / max(count, 1)
+
+
+def _mix_ri(label):
+    stft_r_mix, stft_i_mix, sig_ref = label
+    return torch.stack([stft_r_mix.float(), stft_i_mix.float()], -1).contiguous(), sig_ref
+
+
+class tester_dc(tester):
+    """egs/wsj0-2mix/deep_clustering/evaluate.py:11-47: threshold at max - 40/20, 2-means on the active bins'
+    embeddings, binary masks, mask-apply + iSTFT -- on the device (``host_kmeans=True``: upstream's sklearn path)."""
+
+    def __init__(self, args, hop_size=64, host_kmeans=False):
+        super().__init__(args)
+        self.hop_size, self.host_kmeans = hop_size, host_kmeans
+
+    def get_est_sig(self, input, label, output):
+        from .features import mask_istft
+        from .separation import dc_masks
+        feature_mix, = input
+        embedding, = output
+        ri, sig_ref = _mix_ri(label)
+        if self.host_kmeans:
+            import numpy as np
+            from sklearn.cluster import KMeans
+            masks = torch.zeros(tuple(feature_mix.shape) + (2,), device=feature_mix.device)
+            for b in range(feature_mix.shape[0]):
+                act = feature_mix[b] >= (feature_mix[b].max() - 40 / 20)
+                lab = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(embedding[b][act].cpu().numpy())
+                lab = torch.from_numpy(lab.astype(np.int64)).to(feature_mix.device).float()
+                masks[b][act] = torch.stack([lab, 1.0 - lab], -1)
+        else:
+            masks = dc_masks(embedding, feature_mix.float(), 40.0)
+        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1]), sig_ref.float()
+
+
+class tester_chimera(tester):
+    """egs/wsj0-2mix/chimera/evaluate.py:23-45: the network's masks, mask-apply + iSTFT."""
+
+    def __init__(self, args, hop_size=64):
+        super().__init__(args)
+        self.hop_size = hop_size
+
+    def get_est_sig(self, input, label, output):
+        from .features import mask_istft
+        _, mask_A, mask_B = output
+        ri, sig_ref = _mix_ri(label)
+        masks = torch.stack([mask_A, mask_B], -1)
+        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1]), sig_ref.float()

@@ -1,0 +1,39 @@
+"""The small pieces of onssen.utils that the recipes' run.py files touch next to the hot path (SURVEY 5 "Config" row):
+the config container and the optimizer factory.  The trainer / tester LOOPS stay the reference's own host code (they are
+out of scope: control flow around the path); ``onssen_amd.dist.train_step`` and ``onssen_amd.evaluate.tester`` are the
+counterparts of their bodies."""
+import torch
+
+
+class AttrDict(dict):
+    """Dictionary whose keys are also attributes, nested -- what ``attrdict.AttrDict`` gives the reference's run.py
+    (egs/wsj0-2mix/deep_clustering/run.py:19-23: ``args = AttrDict(json.load(f))``, then both ``args['model_options']`` and
+    ``args.feature_options.batch_size``).  The ``attrdict`` package is dead on Python >= 3.10 (collections.Mapping)."""
+
+    def __getattr__(self, name):
+        try:
+            v = self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+        return AttrDict(v) if isinstance(v, dict) and not isinstance(v, AttrDict) else v
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def __delattr__(self, name):
+        try:
+            del self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+
+def build_optimizer(params, optimizer_options):
+    """onssen/utils/basic.py:5-11: ``{"name": "adam" | "sgd" | "rmsprop", "lr": ...}``."""
+    name, lr = optimizer_options["name"], optimizer_options["lr"]
+    if name == "adam":
+        return torch.optim.Adam(params, lr=lr)
+    if name == "sgd":
+        return torch.optim.SGD(params, lr=lr, momentum=0.9)
+    if name == "rmsprop":
+        return torch.optim.RMSprop(params, lr=lr)
+    raise ValueError(f"unknown optimizer {name!r}")

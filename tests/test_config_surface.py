@@ -1,0 +1,70 @@
+"""The config-JSON surface of the recipes (SURVEY 5 "Config" row): the committed fixtures carry the keys
+and values of egs/wsj0-2mix/deep_clustering/config.json:1-27 and chimera/psa/config.json; run.py builds everything from
+them (run.py:19-28)."""
+import json
+import os
+
+import pytest
+import torch
+
+from onssen_amd import nn as onn
+from onssen_amd.utils import AttrDict, build_optimizer
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name):
+    with open(os.path.join(HERE, "golden", name)) as f:
+        return AttrDict(json.load(f))
+
+
+def test_attrdict_shim_behaves_like_the_recipes_need():
+    args = load("config_dc.json")
+    assert args.model_name == "dc" and args["model_options"]["hidden_dim"] == 600
+    assert args.feature_options.batch_size == 16 and args.feature_options["hop_size"] == 64      # nested attribute access
+    args.model = "anything"                                            # run.py:23 assigns attributes
+    assert args["model"] == "anything"
+    with pytest.raises(AttributeError):
+        args.no_such_key
+    assert dict(**args["model_options"]) == {"input_dim": 129, "hidden_dim": 600, "embedding_dim": 20, "num_layers": 3}
+
+
+@pytest.mark.parametrize("cfg,cls,n_params", [("config_dc.json", "deep_clustering", 23_908_980), ("config_chimera_psa.json", "chimera", 32_866_038)])
+def test_modules_build_from_the_config_fixture(cfg, cls, n_params):
+    """``nn.<model>(**args['model_options'])`` with the shipped option keys; parameter counts of SURVEY 8a (A4, A9)."""
+    args = load(cfg)
+    model = getattr(onn, cls)(**args["model_options"])
+    assert sum(p.numel() for p in model.parameters()) == n_params
+    opt = build_optimizer(model.parameters(), args.optimizer_options)
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == 0.001
+    assert torch.device(args.device).type == "cuda"                    # "cuda:0" / "cuda": PyTorch's name on ROCm too
+
+
+@pytest.mark.gpu
+def test_recipe_flow_from_config_on_the_gpu():
+    """run.py's sequence on the GPU box: config -> model -> loaders -> optimizer -> one training step -> tester.eval()
+    on the evaluation loader (whole utterances, batch 1, label [Re, Im, sig_ref])."""
+    from onssen_amd import dist as odist
+    from onssen_amd.data import wsj0_2mix_dataloader
+    from onssen_amd.evaluate import tester_chimera, tester_dc
+    from onssen_amd.loss import loss_chimera_psa, loss_dc
+    for cfg, cls, loss_fn, tester_cls in (("config_dc.json", "deep_clustering", loss_dc, tester_dc),
+                                          ("config_chimera_psa.json", "chimera", loss_chimera_psa, tester_chimera)):
+        args = load(cfg)
+        device = torch.device(args.device)
+        args.model = getattr(onn, cls)(**args["model_options"])
+        args.model.to(device)
+        args.train_loader = wsj0_2mix_dataloader(args.model_name, args.feature_options, "tr", device)
+        args.test_loader = wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", device)
+        args.optimizer = build_optimizer(args.model.parameters(), args.optimizer_options)
+        inp, lab = next(iter(args.train_loader))
+        assert inp[0].shape == (args.feature_options.batch_size, 400, 129) and lab[0].dtype == torch.float64
+        args.model.train()
+        loss = odist.train_step(args.model, args.optimizer, loss_fn, inp, lab)
+        assert loss == loss and abs(loss) < 1e9
+        inp, lab = next(iter(args.test_loader))
+        assert inp[0].shape[0] == 1 and len(lab) == 3 and lab[2].shape[:2] == (1, 2) and lab[2].shape[2] % 32 == 0
+        assert lab[0].shape == inp[0].shape == lab[1].shape
+        args.checkpoint_path = None
+        sdr = tester_cls(args).eval()
+        assert sdr == sdr and -60.0 < sdr < 60.0                        # random weights: a finite, unremarkable SI-SDR

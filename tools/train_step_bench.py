@@ -66,7 +66,7 @@ def main():
         print(json.dumps({"metric": "training real_time_factor (forward + loss_dc + backward + all-reduce + clip + Adam)",
                           "value": frames * 64 / 8000 / dt, "unit": "audio-seconds trained per wall-second, whole job",
                           "frames_per_s": frames / dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": ("f32 as split-bf16 in the HIP BLSTM forward/backward recurrence, fp32 rocBLAS weight-gradient GEMMs"
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": ("f32 as split-bf16 (bf16x3 MFMA, fp32 accumulate) in the HIP BLSTM forward/backward recurrences, the weight/input-gradient GEMMs and the heads"
                                     if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "f32 (ATen / MIOpen autograd path)"),
                           "blstm_path": "hip" if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "aten",
                           "data": "synthetic", "last_loss": loss,
