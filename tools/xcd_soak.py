@@ -31,5 +31,5 @@ for kind, H, L, B, T in (("deep_clustering", 600, 2, 32, 400), ("chimera", 600, 
             torch.cuda.synchronize()
             if not torch.equal(out, refs[i]): bad += 1
     torch.cuda.synchronize()
-    st = [buf[1120:1128].cpu().view(torch.int32).tolist() for buf in m._ws.cache.values()]
-    print(f"{kind} H={H} L={L} B={B} T={T}: {N} replays in {time.time() - t0:.1f} s, mismatching samples {bad}, status(abort,safe) {st}")
+    st = [buf[1120:1132].cpu().view(torch.int32).tolist() for buf in m._ws.cache.values()]
+    print(f"{kind} H={H} L={L} B={B} T={T}: {N} replays in {time.time() - t0:.1f} s, mismatching samples {bad}, status(abort,safe,nonfinite) {st}")
