@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 4
+#define ONSSEN_ABI_VERSION 5   /* 5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -47,12 +47,15 @@ extern "C" {
                                      wih_p_host[l] to onssen_linear_pack_bf16x3 planes of the [2*NP][K_l] matrix
                                      (ld = K_l rounded up to 32): the input projections run split-bf16 too.
                                      H <= 640. */
-#define ONSSEN_BLSTM_XCD 4        /* (with BF16X3) one persistent launch per layer: every (direction, 16-row group)
+#define ONSSEN_BLSTM_XCD 4        /* (with BF16X3) one persistent launch per layer: every (direction, 4 / 8 / 16-row group)
                                      recurrence runs inside one XCD, W_hh register-resident, h_t exchanged through
-                                     that XCD's L2.  Needs ceil(H/ug) <= 32, H <= 640, ug <= 20.  The kernel verifies
-                                     the placement itself and otherwise uses a placement-independent (slower)
-                                     protocol; bounded waits: ws word [281] = 1 reports that, word [280] != 0 an
-                                     aborted launch (outputs invalid).
+                                     that XCD's L2 as data-tagged bf16 words (no flags).  Needs ceil(H/ug) <= 32,
+                                     H <= 640, ug <= 20.  The kernel verifies the placement itself and otherwise
+                                     uses placement-independent (write-through / system-scope) accesses; bounded
+                                     waits: ws word [281] = 1 reports that, word [280] != 0 an aborted launch
+                                     (outputs invalid), word [282] = 1 a non-finite activation (a NaN cannot carry
+                                     the exchange's tag: it was replaced by 0 -- outputs are NOT nn.LSTM's NaNs;
+                                     the launch-per-step form propagates them).
                                      In this form the activations travel between the layers as x3 images (see
                                      onssen_linear_x3p) written by the recurrence epilogue: wih_p_host[l] must be the
                                      x3 image (onssen_x3_image_f32) of the packed [2*NP][K_l] input-projection
@@ -69,9 +72,10 @@ extern "C" {
                                      projections, h W_hh^T) uses the bf16 hi halves only -- one MFMA instead of
                                      three, bf16-grade results (~1e-2 relative), outside the 1e-4 parity contract.
                                      Same images, same workspace; accumulation, gates and cell state stay fp32. */
-/* Debug flags (0 in production).  Bits 8..11 switch off parts of the recurrence kernel
- * for profiling ablations only (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA,
- * 0x800 G/c loads; 0x1000 selects libm-grade gate non-linearities. */
+/* Debug flags (0 in production).  Launch-per-step form only: bits 8..11 switch off parts of the kernel for profiling
+ * ablations (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA, 0x800 G/c loads; 0x1000 selects
+ * libm-grade gate non-linearities.  ONSSEN_BLSTM_XCD form: 0x800 = TEST bit, rotates the exchange groups across the XCDs
+ * so that the placement-independent accesses run; its profiling switches are build variants (lstm.inc). */
 
 /* epilogue modes of onssen_linear_f32 */
 #define ONSSEN_EPI_BIAS 0     /* C = A W^T + b                                   (nn.Linear)            */
@@ -198,7 +202,8 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
  *             and no call memsets it (so a hipGraph replay does not depend on a memset node reaching the kernel's
  *             L2); the k padding of the x3 images further back is never written and must read as zero.  u32 word
  *             [280] != 0: a launch gave up waiting (outputs invalid); word [281] = 1: some launch used the
- *             placement-independent protocol.
+ *             placement-independent accesses; word [282] = 1: a non-finite activation was replaced by 0 (see
+ *             ONSSEN_BLSTM_XCD).  The host resets [280] and [282] after reporting them.
  * Default form: one input-projection GEMM + T recurrence launches per layer; capture the call in a hipGraph
  * to amortise launch cost.  ONSSEN_BLSTM_XCD: one GEMM + ONE persistent launch per layer (DESIGN.md,
  * "XCD-local persistent recurrence").
@@ -306,6 +311,8 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
  *   sdr_out[b] = max over permutations P of (1/C) sum_i SDR(est[b,i], org[b,P(i)]), signals zero-mean, optional
  *   (B, n) mask applied after centring; perm_out[b] (nullable) = index of P in lexicographic order.
  * Replaces calc_sdr_torch + batch_SDR_torch (onssen/evaluate/sdr.py:11-87).  est, org (B, C, n); C <= 4.
+ * Means, Gram matrix and the SDR table are accumulated / evaluated in fp64 (the residual power from a Gram matrix cancels:
+ * fp32 sums were wrong by 0.1 dB at 50 dB and NaN from ~70 dB); ws 8-byte aligned.
  */
 size_t onssen_batch_sdr_workspace_bytes(int B);
 int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
