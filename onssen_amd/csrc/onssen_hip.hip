@@ -34,8 +34,10 @@ typedef __bf16 bf16x8_t __attribute__((vector_size(16)));
 // (The host-side emulation of tests/emu defines ONSSEN_HOST_EMULATION: no such reordering there, and no VGPR constraints.)
 #ifdef ONSSEN_HOST_EMULATION
 #define ONSSEN_USE_AFTER(x, after) ((void)0)
+#define ONSSEN_LDS_PTR(p) ((void*)(p))
 #else
 #define ONSSEN_USE_AFTER(x, after) asm volatile("" : "+v"(x) : "v"(after))
+#define ONSSEN_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))     // LDS pointer for buffer_load ... lds
 #endif
 
 // ---- split-bf16 ("bf16x3") arithmetic ---------------------------------------------------------------
@@ -355,9 +357,35 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  // tile shape: 256 x 320 or 256 x 256 (linear_x3q_kernel, LDS-DMA staging) unless ONSSEN_X3Q=0 selects the round-1 kernel
+  // (256 x 160).  One workgroup per CU: the width that needs fewer (rounds of 256 workgroups) x (tile columns) wins;
+  // the L2NORM epilogue needs whole feature groups per wave (80 columns) and stays at 320.  ONSSEN_X3Q=320 / 256 forces one.
+  const char* env_q = getenv("ONSSEN_X3Q");   // read per call: the tests switch it
+  const int use_q = env_q ? atoi(env_q) : 1;
+  if (use_q && (long)lxq::BM * KB * 128 <= 0x7fffffffL) {
+    const long mt = ceil_div(M, lxq::BM);
+    const long c320 = ceil_div(mt * ceil_div(N, 320), 256) * 320, c256 = ceil_div(mt * ceil_div(N, 256), 256) * 256;
+    const bool narrow = mode != ONSSEN_EPI_L2NORM && (use_q == 256 || (use_q != 320 && c256 < c320));
+    const dim3 gridq((unsigned)ceil_div(N, narrow ? 256 : 320), (unsigned)mt);
+#define ONSSEN_XQ(MODE_)                                                                                        \
+  do {                                                                                                          \
+    if (narrow && bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 1, false, 256>), gridq, dim3(512), 0, st, p); \
+    else if (narrow) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 3, false, 256>), gridq, dim3(512), 0, st, p);  \
+    else if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 1>), gridq, dim3(512), 0, st, p);           \
+    else hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 3>), gridq, dim3(512), 0, st, p);                          \
+  } while (0)
+    if (mode == ONSSEN_EPI_BIAS) ONSSEN_XQ(ONSSEN_EPI_BIAS);
+    else if (mode == ONSSEN_EPI_L2NORM) {
+      if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 1>), gridq, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 3>), gridq, dim3(512), 0, st, p);
+    } else ONSSEN_XQ(ONSSEN_EPI_SIGMOID);
+#undef ONSSEN_XQ
+    ONSSEN_LAUNCH_CHECK();
+    return ONSSEN_OK;
+  }
   static const int xp_wms = getenv("ONSSEN_X3P_WAVES") && atoi(getenv("ONSSEN_X3P_WAVES")) == 4 ? 2 : 4;   // 8 waves unless =4
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(128 * xp_wms);
-  hipStream_t st = (hipStream_t)stream;
 #define ONSSEN_XP(MODE_)                                                                                       \
   do {                                                                                                         \
     if (xp_wms == 4 && bf16_only) hipLaunchKernelGGL((linear_x3p_kernel<MODE_, 4, 1>), grid, block, 0, st, p);    \

@@ -321,6 +321,13 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
 }
 // the lanes of an emulated wave are threads with their own copy of every wave-uniform value
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+// buffer_load_dwordx4 ... lds: every lane copies `size` bytes (zeros when out of range) to lds + lane * size
+static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, int voff, int soff, int off, int) {
+  char* dst = static_cast<char*>(lds) + emu::lane * size;
+  if ((unsigned long)(unsigned)voff + size <= (unsigned long)r.bytes) memcpy(dst, r.base + voff + soff + off, size);
+  else memset(dst, 0, size);
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
 static inline bool __all(bool p) {
   auto& w = emu::ctx->wbuf[emu::wave];
   w.a[emu::lane] = p ? 1.0f : 0.0f;

@@ -239,11 +239,13 @@ def test_linear_split_bf16(lib, mode, group, K):
 
 @pytest.mark.parametrize("mode,group,K", [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40),
                                           (_abi.EPI_L2NORM, 40, 33)])
-def test_linear_x3_images(lib, mode, group, K):
-    """onssen_x3_image_f32 + onssen_linear_x3p (pre-split operands, 256x160 tile, register epilogue): ragged M/N/K,
-    strided A rows and C rows, all epilogues."""
+@pytest.mark.parametrize("tile", ["0", "256", "320"])
+def test_linear_x3_images(lib, mode, group, K, tile, monkeypatch):
+    """onssen_x3_image_f32 + onssen_linear_x3p (pre-split operands; 256x160 register-staged tile, 256x256 / 256x320
+    LDS-DMA tiles; register epilogue): ragged M/N/K, strided A rows and C rows, all epilogues."""
+    monkeypatch.setenv("ONSSEN_X3Q", tile)
     rng = np.random.default_rng(8)
-    Bb, Tt, N = 3, 91, 200           # M = 273 (2 row blocks), N = 200 (2 column blocks)
+    Bb, Tt, N = 3, 91, 440           # M = 273 (2 row blocks), N = 440 (3 / 2 / 2 column blocks, the last one ragged)
     x = rand(rng, Bb, Tt, K)
     W = rand(rng, N, K)
     bias = rand(rng, N)
