@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 5   /* 5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -251,6 +251,12 @@ int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out
 size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form);
 int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
                                    const float* cs, void* ws, size_t ws_bytes, int form, void* stream);
+/* The inter-layer dropout of nn.LSTM(dropout=p) (onssen/nn/deep_clustering.py:15-22) as ONE pass:
+ *   out[i] = keep(seed, i) ? x[i] / (1 - p) : 0,   keep = counter-based hash of (seed, i) compared with p
+ * -- no mask tensor: the backward pass calls it again on dL/d(out) with the same seed.  Like the reference's (the RNN
+ * library's own generator) the random stream is not torch's; the caller draws `seed` from torch's generator, so runs
+ * repeat under torch.manual_seed.  0 <= p < 1; out may alias x; n elements, 16-byte aligned when n % 4 == 0. */
+int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 glue  recurrent input of the phase network for all C speakers at once:

@@ -9,7 +9,7 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 5
+ABI_VERSION = 6
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -50,6 +50,7 @@ SIGNATURES = {
     "onssen_lstm_pack_whhR_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_dropout_f32": (_i, [_vp, _i64, _f, C.c_uint64, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -204,6 +205,9 @@ class Lib:
     def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream):
         self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream),
                    "onssen_lstm_train_backward_f32")
+
+    def dropout(self, x, n, p, seed, out, stream):
+        self.check(self.dll.onssen_dropout_f32(x, n, p, seed, out, stream), "onssen_dropout_f32")
 
     def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
         self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,

@@ -733,28 +733,37 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     if (Hp / ug > 32 || NUB > 40) return ONSSEN_E_ARG;
     static const unsigned xcd_spin = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
     static const int ablate_env = getenv("ONSSEN_BWD_ABLATE") ? atoi(getenv("ONSSEN_BWD_ABLATE")) : 0;
+    static const int delay_env = getenv("ONSSEN_BWD_DELAY") ? atoi(getenv("ONSSEN_BWD_DELAY")) : 0;
     XcdBwdArgs xa;
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
     xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
-    xa.spin_limit = xcd_spin; xa.ablate = ablate_env;
-    // profiling only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
+    xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env;
+    // ONSSEN_XCD_PROFILE builds only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
     static const bool dbg_env = getenv("ONSSEN_BWD_DBG") != nullptr;
     xa.dbg = dbg_env && ws_bytes >= onssen_lstm_train_backward_workspace_bytes(B, H, ug, form) + (size_t)T * 64
                  ? (long long*)((char*)ws + onssen_lstm_train_backward_workspace_bytes(B, H, ug, form)) : nullptr;
     ONSSEN_CLEAR_ERROR();
     const dim3 grid((unsigned)(8 * xa.NU));
+    const int E = xa.RG * ug, parts = 4 * E <= 320 ? 4 : 2 * E <= 320 ? 2 : 1;   // polling lanes per element (320 polling threads)
     for (int r0 = 0; r0 < B; r0 += 4 * xa.RG) {
       const int rows = B - r0 < 4 * xa.RG ? B - r0 : 4 * xa.RG;
       xa.row0 = r0;
       xa.nbg = ceil_div(rows, xa.RG);
+#define ONSSEN_BWD_UG(UG_)                                                                                   \
+  do {                                                                                                       \
+    if (parts == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 4>), grid, dim3(512), 0, st, xa);            \
+    else if (parts == 2) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 2>), grid, dim3(512), 0, st, xa);       \
+    else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1>), grid, dim3(512), 0, st, xa);                       \
+  } while (0)
       switch (ug) {
-        case 4: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<4>), grid, dim3(512), 0, st, xa); break;
-        case 8: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<8>), grid, dim3(512), 0, st, xa); break;
-        case 12: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<12>), grid, dim3(512), 0, st, xa); break;
-        case 16: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<16>), grid, dim3(512), 0, st, xa); break;
-        default: hipLaunchKernelGGL((lstm_xcd_bwd_kernel<20>), grid, dim3(512), 0, st, xa); break;
+        case 4: ONSSEN_BWD_UG(4); break;
+        case 8: ONSSEN_BWD_UG(8); break;
+        case 12: ONSSEN_BWD_UG(12); break;
+        case 16: ONSSEN_BWD_UG(16); break;
+        default: ONSSEN_BWD_UG(20); break;
       }
+#undef ONSSEN_BWD_UG
     }
     ONSSEN_LAUNCH_CHECK();
     return ONSSEN_OK;
@@ -771,6 +780,20 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     p.step = s;
     hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(64 * recb::NW), 0, st, p);
   }
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, void* stream) {
+  if (!x || !out || n <= 0 || !(p >= 0.0f) || !(p < 1.0f)) return ONSSEN_E_ARG;
+  const int vec = (n % 4) == 0 && aligned16(x) && aligned16(out);
+  const double t = (double)p * 4294967296.0;
+  const unsigned thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;     // hash < thr: dropped
+  const long work = vec ? n / 4 : n;
+  const long nb = (work + 255) / 256;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, (hipStream_t)stream, x, (long)n, thr,
+                     1.0f / (1.0f - p), (unsigned long long)seed, out, vec);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

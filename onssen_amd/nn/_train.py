@@ -6,7 +6,8 @@ activations / cell states (``onssen_lstm_train_forward_f32``), the backward recu
 (XCD-local persistent launch; one launch per time step with ONSSEN_BWD_XCD=0), and the weight / input gradient
 contractions run on the package's split-bf16 MFMA GEMM (``onssen_linear_x3p`` / ``_batched``) over operand images written by
 ``onssen_x3_image_t_f32`` (ONSSEN_TRAIN_GEMM=blas: fp32 library GEMMs through ``torch.mm`` instead).  The inter-layer
-dropout of ``nn.LSTM(dropout=0.3)`` (deep_clustering.py:15-22) is applied between the layers with torch's generator.
+dropout of ``nn.LSTM(dropout=0.3)`` (deep_clustering.py:15-22) is applied between the layers by ``onssen_dropout_f32`` (one
+pass, mask regenerated from a seed in the backward pass; the seed comes from torch's generator).
 ``head_linear`` puts the heads' nn.Linear (fc_dc, fc_mi) on the same GEMM for a training forward / backward."""
 import os
 
@@ -170,15 +171,18 @@ class BLSTMTrainFunction(torch.autograd.Function):
             if l < L - 1:
                 nxt = y.view(T, B, 2 * Hp)
                 if p_drop > 0.0:
-                    mask = (torch.rand_like(nxt) >= p_drop).to(torch.float32) * (1.0 / (1.0 - p_drop))
-                    nxt = nxt * mask
+                    # one pass, no mask tensor: the backward pass regenerates the mask from the seed (drawn from torch's
+                    # CPU generator: repeatable under torch.manual_seed, no device synchronisation)
+                    mask = int(torch.randint(0, 2 ** 62, (1,)).item())
+                    nxt = torch.empty_like(nxt)
+                    lib.dropout(y.data_ptr(), y.numel(), float(p_drop), mask, nxt.data_ptr(), st)
                 saved.append((xp, y, gates, cs, mask))
                 xin, xs_b, xs_t, in_l = nxt, 2 * Hp, B * 2 * Hp, 2 * Hp
                 xp = nxt.view(T * B, 2 * Hp)                             # padded [fwd(Hp) | rev(Hp)] rows
             else:
                 saved.append((xp, y, gates, cs, None))
         ctx.saved_layers = saved
-        ctx.packed, ctx.ug, ctx.dims = packed, ug, (B, T, In, H, L, Hp, NP)
+        ctx.packed, ctx.ug, ctx.dims, ctx.p_drop = packed, ug, (B, T, In, H, L, Hp, NP), p_drop
         ctx.flat = flat
         return y[..., :H].reshape(T, B, 2 * H).transpose(0, 1).contiguous()
 
@@ -231,9 +235,10 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 else:
                     dyl = dx_rows.view(T, B, 2, H)
                     dyl = Fn.pad(dyl, (0, Hp - H)) if Hp != H else dyl
-                mprev = ctx.saved_layers[l - 1][4]
-                dy = (dyl.reshape(T, B, 2 * Hp) * mprev).view(T, B, 2, Hp) if mprev is not None else dyl
-                dy = dy.contiguous()
+                mprev = ctx.saved_layers[l - 1][4]      # the dropout seed of the boundary below this layer, or None
+                dy = dyl.contiguous()
+                if mprev is not None:
+                    lib.dropout(dy.data_ptr(), dy.numel(), float(ctx.p_drop), mprev, dy.data_ptr(), st)
         dx = dx_rows[:, :In].reshape(T, B, In).transpose(0, 1).contiguous() if ctx.needs_input_grad[0] else None
         if LAYER_GRAD_REDUCER[0] is not None:
             LAYER_GRAD_REDUCER[0].layer_collect()     # averaged in place before autograd accumulates them

@@ -652,3 +652,28 @@ def test_linear_x3_images_plain_bf16_products(lib):
     np.testing.assert_allclose(out, xr @ Wr.T + bias, atol=2e-5, rtol=1e-5)
     full = x.astype(np.float64) @ W.T.astype(np.float64) + bias
     assert 1e-4 < np.abs(out - full).max() < 0.2
+
+
+@pytest.mark.parametrize("n", [4096, 4099])
+def test_dropout_one_pass(lib, n):
+    """onssen_dropout_f32 (nn.LSTM's inter-layer dropout, onssen/nn/deep_clustering.py:15-22): kept elements are x / (1 - p),
+    the rest 0; the keep rate is 1 - p; the same seed gives the same mask (what the backward pass relies on), another seed
+    another one; in place works; p = 0 is the identity."""
+    rng = np.random.default_rng(3)
+    x = np.abs(rand(rng, n)) + 0.5
+    p = 0.3
+    a, b, c = (np.full(n, np.nan, np.float32) for _ in range(3))
+    lib.dropout(P(x), n, p, 1234, P(a), None)
+    lib.dropout(P(x), n, p, 1234, P(b), None)
+    lib.dropout(P(x), n, p, 1235, P(c), None)
+    np.testing.assert_array_equal(a, b)
+    kept = a != 0
+    np.testing.assert_allclose(a[kept], x[kept] / np.float32(1 - p), rtol=1e-6)
+    assert abs(kept.mean() - (1 - p)) < 0.03 and 0.3 < ((c != 0) == kept).mean() < 0.75
+    # neighbouring elements are not correlated
+    assert abs(np.corrcoef(kept[:-1], kept[1:])[0, 1]) < 0.06
+    y = x.copy()
+    lib.dropout(P(y), n, p, 1234, P(y), None)
+    np.testing.assert_array_equal(y, a)
+    lib.dropout(P(x), n, 0.0, 7, P(b), None)
+    np.testing.assert_array_equal(b, x)

@@ -723,6 +723,73 @@ def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,F,H,L", [(16, 30, 129, 600, 3), (3, 11, 20, 30, 2)])
+def test_blstm_training_with_dropout_matches_autograd_under_the_same_masks(dev, monkeypatch, B, T, F, H, L):
+    """nn.LSTM(dropout=0.3) in training (onssen/nn/deep_clustering.py:15-22): the HIP path applies the inter-layer dropout with
+    onssen_dropout_f32 (mask regenerated from the seed in the backward pass).  Reference: single-layer nn.LSTMs in float64 on
+    the CPU with the SAME masks (the kernel run on ones with the seeds the path draws) -- outputs and every gradient agree
+    as in the dropout-free test."""
+    from onssen_amd.hip import get_lib
+    from onssen_amd.nn._core import BLSTMParams
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    p = 0.3
+    torch.manual_seed(H + L)
+    ref = torch.nn.LSTM(F, H, L, batch_first=True, bidirectional=True).double()
+    rnn = BLSTMParams(F, H, L, dropout=p)
+    rnn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    rnn = rnn.to(dev)
+    x = torch.randn(B, T, F, dtype=torch.float64)
+    R = torch.randn(B, T, 2 * H, dtype=torch.float64)
+    torch.manual_seed(77)
+    seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(L - 1)]
+    lib = get_lib()
+    ug = 4 * -(-H // 128)
+    Hp = lib.lstm_geometry(H, ug)[0]
+    masks = []
+    for sd in seeds:
+        ones = torch.ones(T, B, 2, Hp, device=dev)
+        m = torch.empty_like(ones)
+        lib.dropout(ones.data_ptr(), ones.numel(), p, sd, m.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        masks.append(m[..., :H].reshape(T, B, 2 * H).transpose(0, 1).cpu().double())
+        assert abs((masks[-1] != 0).double().mean().item() - (1 - p)) < 5 * (p * (1 - p) / masks[-1].numel()) ** 0.5
+    # the reference stack, one layer at a time
+    layers = []
+    for l in range(L):
+        one = torch.nn.LSTM(F if l == 0 else 2 * H, H, 1, batch_first=True, bidirectional=True).double()
+        sdl = {}
+        for kind in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            for sfx in ("", "_reverse"):
+                sdl[f"{kind}_l0{sfx}"] = ref.state_dict()[f"{kind}_l{l}{sfx}"]
+        one.load_state_dict(sdl)
+        layers.append(one)
+    xr = x.clone().requires_grad_(True)
+    h = xr
+    for l, one in enumerate(layers):
+        h, _ = one(h)
+        if l < L - 1:
+            h = h * masks[l]
+    (h * R).sum().backward()
+    torch.manual_seed(77)
+    xg = x.float().to(dev).requires_grad_(True)
+    yg = rnn.autograd_forward(xg, True)
+    (yg * R.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert (yg.detach().cpu().double() - h.detach()).abs().max() < 4e-5
+    bad = []
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        err, scale = (a - b).abs().max().item(), b.abs().max().item()
+        if not err <= 3e-4 * max(scale, 1e-6):
+            bad.append(f"{what}: max err {err:.3e} vs max |ref| {scale:.3e}")
+    close(xg.grad, xr.grad, "dx")
+    for name, prm in rnn.named_parameters():
+        l = int(name.replace("_reverse", "").rsplit("_l", 1)[1])
+        close(prm.grad, getattr(layers[l], name.replace(f"_l{l}", "_l0")).grad, name)      # e.g. weight_hh_l2_reverse -> layer 2's weight_hh_l0_reverse
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.gpu
 def test_dc_training_step_hip_vs_aten(dev, monkeypatch):
     """One deep-clustering training forward + loss_dc + backward (dropout off so both paths see the same network): the
     HIP BLSTM path and the stock ATen LSTM give the same loss and gradients (2e-3 of each tensor's largest entry: two

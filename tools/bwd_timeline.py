@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Per-step timeline of the persistent backward recurrence (lstm_xcd_bwd_kernel), workgroup 0 / thread 0:
-ONSSEN_BWD_DBG=1 makes the kernel leave 8 clock64 stamps per step in the tail of an oversized workspace.
-    ONSSEN_BWD_DBG=1 python tools/bwd_timeline.py [B T H]"""
+a library built with -DONSSEN_XCD_PROFILE=1 (tools/ab_variants.py build prof "-DONSSEN_XCD_PROFILE=1") leaves 8 clock64 stamps
+for each of the steps 64..127 in the tail of an oversized workspace when ONSSEN_BWD_DBG=1.
+    ONSSEN_HIP_LIB=build_variants/libonssen_hip_prof.so python tools/bwd_timeline.py [B T H]"""
 import os, sys
 os.environ["ONSSEN_BWD_DBG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,11 +44,12 @@ def main():
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     d = wsb[nb:nb + T * 64].cpu().numpy().view(np.int64).reshape(T, 8)
-    st_ = d[20:T - 5]
-    names = ["wait flags", "read partials -> red", "prefetch + barrier + sum + elementwise + barrier", "MFMA", "partial stores issued", "vmcnt(0)", "flag + dP store -> next step"]
-    nxt = d[21:T - 4, 0]
+    st_ = d[66:126]
+    names = ["poll the partial sums (tagged data)", "sum + DPP + cell arithmetic + fragments to LDS", "barrier", "MFMA",
+             "tagged partial stores issued", "dP store", "first request for the next step's sums", "-> next step"]
+    nxt = d[67:127, 0]
     edges = [st_[:, 1] - st_[:, 0], st_[:, 2] - st_[:, 1], st_[:, 3] - st_[:, 2], st_[:, 4] - st_[:, 3], st_[:, 5] - st_[:, 4],
-             st_[:, 6] - st_[:, 5], nxt - st_[:, 6]]
+             st_[:, 7] - st_[:, 5], st_[:, 6] - st_[:, 7], nxt - st_[:, 6]]
     period = np.mean(nxt - st_[:, 0])
     print(f"B={B} T={T} H={H}: launch {ms * 1e3:.0f} us = {ms * 1e3 / T:.2f} us per step; clock64 period per step {period:.0f} ticks "
           f"({period / (ms * 1e3 / T):.0f} ticks/us)")

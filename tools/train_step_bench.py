@@ -36,7 +36,8 @@ def main():
     fo = dict(batch_size=16, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
     torch.manual_seed(0)
     model = onn.deep_clustering(129, 600, args.layers, 20, dropout=args.dropout).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    from onssen_amd.utils import build_optimizer
+    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})      # egs/*/config.json: adam, 1e-3
     loader = wsj0_2mix_dataloader("dc", fo, "tr", device=str(dev))
     batches = []
     for i, b in enumerate(loader):
