@@ -319,6 +319,21 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
   emu::wave_sync();
   return r;
 }
+// v_perm_b32: result byte i = byte sel[i] of {s0 (bytes 4-7), s1 (bytes 0-3)}; selectors 0x0c -> 0x00, >= 0x0d -> 0xff
+static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+  const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned c = (sel >> (8 * i)) & 0xffu;
+    unsigned b;
+    if (c < 8) b = (unsigned)(src >> (8 * c)) & 0xffu;
+    else if (c == 0x0c) b = 0;
+    else if (c >= 0x0d) b = 0xffu;
+    else { fprintf(stderr, "emu: v_perm_b32 selector %u not emulated\n", c); abort(); }
+    r |= b << (8 * i);
+  }
+  return r;
+}
 // the lanes of an emulated wave are threads with their own copy of every wave-uniform value
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 // buffer_load_dwordx4 ... lds: every lane copies `size` bytes (zeros when out of range) to lds + lane * size

@@ -1,6 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x -k "train or dropout or grad or robust" 2>&1 | tail -3
-for i in 1 2; do timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3', r.get('ms_per_step'), r.get('value'))"; done
-ONSSEN_FUSED_ADAM=0 timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3 unfused adam', r.get('ms_per_step'), r.get('value'))"
-timeout 200 python tools/train_step_bench.py --layers 2 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L2', r.get('ms_per_step'), r.get('value'))"
+python tools/ab_variants.py run base perm -- bench.py --no-cpu-baseline --steps 40
+timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x -k "golden or xcd or cfg or finite or abort" 2>&1 | tail -2
