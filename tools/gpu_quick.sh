@@ -1,4 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python tools/ab_variants.py run base perm -- bench.py --no-cpu-baseline --steps 40
-timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x -k "golden or xcd or cfg or finite or abort" 2>&1 | tail -2
+python tools/ab_variants.py run base nobr st2 st3 -- bench.py --no-cpu-baseline --steps 40
