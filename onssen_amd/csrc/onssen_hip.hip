@@ -597,9 +597,6 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 8;
       xa.terms = bf16_only ? 1 : 3;
       xa.save_g = save_g; xa.save_c = save_c;
-      static const int d_cell = getenv("ONSSEN_XCD_DELAY_CELL") ? atoi(getenv("ONSSEN_XCD_DELAY_CELL")) : 0;
-      static const int d_idle = getenv("ONSSEN_XCD_DELAY_IDLE") ? atoi(getenv("ONSSEN_XCD_DELAY_IDLE")) : 0;
-      xa.delay_cell = d_cell; xa.delay_idle = d_idle;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup (K is split over them): 8 = two per SIMD; ONSSEN_XCD_WAVES=4 keeps the one-per-SIMD form for comparison
       static const int xcd_nw = getenv("ONSSEN_XCD_WAVES") && atoi(getenv("ONSSEN_XCD_WAVES")) == 4 ? 4 : 8;
