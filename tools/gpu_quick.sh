@@ -1,5 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python tools/ab_variants.py run base nobr2 -- bench.py --no-cpu-baseline --steps 40
-python tools/ab_variants.py run base nobr2 -- bench.py --no-cpu-baseline --steps 20 --config chimera_l4
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x 2>&1 | tail -2
+for c in dc_l2 dc_l3 phase_l4; do for f in auto 1 auto 1; do echo -n "$c fuse=$f: "; ONSSEN_FUSE_IN0=$f timeout 100 python bench.py --no-cpu-baseline --steps 40 --config $c | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['roofline']['us_per_time_step'])"; done; done
