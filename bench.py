@@ -394,7 +394,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
            "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
-    gem = {"kernel": "linear_x3p_kernel" if images else "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+    gem = {"kernel": "linear_x3q_kernel (onssen_linear_x3p; 256x320 / 256x256 tiles, LDS-DMA staging)" if images else "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
            "achieved_by_call": {"input_proj_l0": 2.0 * B * T * 8 * H * F / t_g0 / 1e12,
                                 "input_proj_l1": (flop_gin / t_gin / 1e12) if lyr else None,
                                 "fc_dc_l2norm": flop_head / t_head / 1e12},

@@ -1,3 +1,14 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for c in dc_l2 dc_l3 phase_l4; do for f in auto 1 auto 1; do echo -n "$c fuse=$f: "; ONSSEN_FUSE_IN0=$f timeout 100 python bench.py --no-cpu-baseline --steps 40 --config $c | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['roofline']['us_per_time_step'])"; done; done
+for gn in 4 5 8 15; do echo "GN=$gn"; ONSSEN_X3_GN=$gn SHAPES="[(12800,4800,1200),(12800,2580,1200),(12800,4800,129),(25600,4800,1200)]" timeout 100 python tools/gemm_probe.py; done
+cd /tmp
+for gn in 4 8; do
+ONSSEN_X3_GN=$gn SHAPES="[(12800,4800,1200)]" timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_gn$gn -- python $GRAFT_REPO_ROOT/tools/gemm_probe.py > /dev/null 2>&1
+python - <<PY
+import csv,glob
+f=glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pmc_gn$gn/*/*counter_collection.csv")[0]
+v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if 'linear_x3q' in r['Kernel_Name']]
+print("GN=$gn FETCH_SIZE KB per call", sorted(set(round(x) for x in v))[:5], len(v))
+PY
+done
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_gn*
