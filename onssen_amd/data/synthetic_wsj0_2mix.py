@@ -84,5 +84,6 @@ class SyntheticWsj02mix:
 
 
 def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
-    """Same call signature as onssen.data.wsj0_2mix_dataloader (wsj0_2mix.py:26)."""
+    """Same call signature as onssen.data.wsj0_2mix_dataloader (wsj0_2mix.py:26); always synthetic -- the package-level factory
+    (onssen_amd.data.wsj0_2mix_dataloader) reads real files when feature_options.data_path has them."""
     return SyntheticWsj02mix(model_name, feature_options, partition, device)

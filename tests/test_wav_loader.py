@@ -1,0 +1,129 @@
+"""Row N4 tail / H1: wav I/O and the wsj0-2mix loader over real files (onssen/data/wsj0_2mix.py:26-37,78-79,103-158,216-228;
+feature_utils.get_stft:5-21).  The corpus here is a handful of synthetic utterances written as RIFF files in the corpus layout."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from onssen_amd.data import Wsj02mixFiles, read_wav, write_wav, wsj0_2mix_dataloader
+from onssen_amd.synthetic import synth_mixture
+from oracle import np_oracle as O
+
+FO = dict(batch_size=2, frame_length=40, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
+
+
+def make_corpus(root, partition, lengths, rate=8000, subtype="PCM_16"):
+    for sub in ("mix", "s1", "s2"):
+        os.makedirs(os.path.join(root, "wav8k", "min", partition, sub), exist_ok=True)
+    sigs = []
+    for i, n in enumerate(lengths):
+        trip = synth_mixture(500 + i, n, rate, return_sources=True)
+        # keep the triple additive after 16-bit quantisation of the sources
+        q = [np.rint(t * 0.5 * 32768) / 32768 for t in trip[1:]]
+        trip = [(q[0] + q[1]).astype(np.float32), q[0].astype(np.float32), q[1].astype(np.float32)]
+        for sub, sig in zip(("mix", "s1", "s2"), trip):
+            write_wav(os.path.join(root, "wav8k", "min", partition, sub, f"utt{i:02d}.wav"), sig, rate, subtype)
+        sigs.append(trip)
+    return sigs
+
+
+def test_read_wav_formats(tmp_path):
+    from scipy.io import wavfile
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(1000) * 0.2).astype(np.float32)
+    write_wav(tmp_path / "a.wav", x, 8000)                       # PCM16: quantised to 2^-15
+    y, r = read_wav(tmp_path / "a.wav")
+    assert r == 8000 and y.dtype == np.float32 and np.abs(y - x).max() <= 2.0 ** -16 + 1e-9
+    write_wav(tmp_path / "b.wav", x, 16000, "FLOAT")
+    y, r = read_wav(tmp_path / "b.wav")
+    assert r == 16000 and np.array_equal(y, x)
+    st = np.stack([x, -0.5 * x], 1)                               # two channels -> their mean (librosa mono=True)
+    wavfile.write(tmp_path / "c.wav", 8000, st)
+    y, _ = read_wav(tmp_path / "c.wav")
+    np.testing.assert_allclose(y, 0.25 * x, atol=1e-7)
+    wavfile.write(tmp_path / "d.wav", 8000, (x * 2 ** 31).astype(np.int32))
+    y, _ = read_wav(tmp_path / "d.wav")
+    np.testing.assert_allclose(y, x, atol=1e-6)
+    wavfile.write(tmp_path / "e.wav", 8000, np.clip(np.rint(x * 128 + 128), 0, 255).astype(np.uint8))
+    y, _ = read_wav(tmp_path / "e.wav")
+    assert np.abs(y - x).max() <= 1 / 128
+
+
+def test_factory_picks_files_or_synthetic(tmp_path):
+    make_corpus(str(tmp_path), "tr", [3000, 2500, 2800])
+    fo = dict(FO, data_path=str(tmp_path))
+    dl = wsj0_2mix_dataloader("dc", fo, "tr", device="cpu")
+    assert isinstance(dl, Wsj02mixFiles) and len(dl) == 2 and len(dl.file_list) == 3
+    assert not isinstance(wsj0_2mix_dataloader("dc", fo, "cv", device="cpu"), Wsj02mixFiles)       # no cv files: synthetic
+    assert not isinstance(wsj0_2mix_dataloader("dc", FO, "tr", device="cpu"), Wsj02mixFiles)       # no data_path
+    with pytest.raises(ValueError):
+        Wsj02mixFiles("conv-tasnet", fo, "tr")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["dc", "chimera++", "phase"])
+def test_training_batches_from_files_match_the_oracle(tmp_path, model_name):
+    """Batches over files: list layout per model, one utterance shorter than frame_length (repeated before the crop), the
+    crop the seeded generator draws, log-magnitude / labels against the NumPy restatement of the reference's helpers."""
+    dev = torch.device("cuda:0")
+    L = FO["frame_length"]
+    lengths = [64 * 70 + 13, 64 * 25, 64 * 55 + 7]          # 71, 26 (<= L: repeated twice), 56 frames
+    sigs = make_corpus(str(tmp_path), "tr", lengths)
+    fo = dict(FO, data_path=str(tmp_path))
+    dl = Wsj02mixFiles(model_name, fo, "tr", device=dev, shuffle=False, seed=11)
+    batches = list(dl)
+    assert len(batches) == 2 and batches[0][0][0].shape == (2, L, 129) and batches[1][0][0].shape == (1, L, 129)
+    nlab = {"dc": 2, "chimera++": 6, "phase": 6}[model_name]
+    assert all(len(lab) == nlab for _, lab in batches) and batches[0][1][0].dtype == torch.float64
+    rng = np.random.default_rng(11)
+    k = 0
+    for inp, lab in batches:
+        for b in range(inp[0].shape[0]):
+            trip = sigs[k]; k += 1
+            specs = [O.stft(s, 256, 64) for s in trip]
+            T = specs[0].shape[0]
+            if T <= L:
+                specs = [np.concatenate([s] * (L // T + 1), 0) for s in specs]
+            start = int(rng.integers(0, specs[0].shape[0] - L))
+            X, S1, S2 = (s[start:start + L] for s in specs)
+            feat = O.log_magnitude(X)
+            np.testing.assert_allclose(inp[0][b].cpu().numpy(), feat, atol=2e-5)
+            got = lab[0][b].cpu().numpy()
+            ref = O.one_hot_labels(feat, np.abs(S1), np.abs(S2), 40.0)
+            assert (got != ref).mean() < 2e-4            # bins within rounding of the threshold / of a tie may flip
+            np.testing.assert_allclose(lab[1][b].cpu().numpy(), np.abs(X), rtol=2e-5, atol=1e-6)
+            if model_name == "chimera++":      # the phase of a bin with (almost) no energy is rounding noise: compare where both have some
+                ok = np.minimum(np.abs(X), np.abs(S1)) > 1e-4
+                assert ok.mean() > 0.5
+                np.testing.assert_allclose(lab[4][b].cpu().numpy()[ok], O.cos_difference(X, S1)[ok], atol=2e-3)
+            if model_name == "phase":
+                np.testing.assert_allclose(inp[1][b].cpu().numpy(), np.stack([X.real, X.imag], -1), atol=2e-5)
+                np.testing.assert_allclose(lab[5][b].cpu().numpy(), np.stack([S2.real, S2.imag], -1), atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_eval_partition_from_files_and_tester(tmp_path):
+    """Partition "tt": whole utterances, batch 1, [Re, Im, sig_ref] with the signals padded by 32 - n % 32 (get_sigs); the
+    batches drive onssen_amd.evaluate.tester like the reference's test loop drives its tester."""
+    dev = torch.device("cuda:0")
+    lengths = [4000, 5017]
+    sigs = make_corpus(str(tmp_path), "tt", lengths)
+    fo = dict(FO, data_path=str(tmp_path))
+    dl = wsj0_2mix_dataloader("dc", fo, "tt", device=dev)
+    assert isinstance(dl, Wsj02mixFiles) and len(dl) == 2
+    for (inp, lab), n, trip in zip(dl, lengths, sigs):
+        npad = n + 32 - n % 32
+        T = 1 + npad // 64
+        assert inp[0].shape == (1, T, 129) and lab[0].shape == (1, T, 129) and lab[2].shape == (1, 2, npad)
+        np.testing.assert_array_equal(lab[2][0, 0, :n].cpu().numpy(), trip[1])
+        assert not lab[2][0, :, n:].any()
+        X = O.stft(np.pad(trip[0], (0, npad - n)), 256, 64)
+        np.testing.assert_allclose(lab[0][0].cpu().numpy(), X.real, atol=2e-5)
+    from onssen_amd import nn as onn
+    from onssen_amd.evaluate import tester_dc
+    torch.manual_seed(0)
+    model = onn.deep_clustering(129, 32, 1, 8).to(dev).eval()
+    t = tester_dc(dict(model_name="dc", model=model, test_loader=dl, device="cuda:0"), hop_size=64)
+    sdr = t.eval()
+    assert np.isfinite(sdr)
