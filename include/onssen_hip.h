@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -293,7 +293,7 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
                           int iters, float* masks, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * N1 (forward)  deep-clustering loss VALUE (validation / monitoring; the training backward stays on autograd):
+ * N1  deep-clustering loss: VALUE (onssen_loss_dc_f32) and its GRADIENT w.r.t. the embedding (onssen_loss_dc_grad_f32):
  *   per_utt[b] = ||V^T V||_F - 2 ||V^T Y||_F + ||Y^T Y||_F,  V = w * (sum_c Y) * emb, Y = w * one_hot,
  *   w_r = sqrt(mag_r / total_mag[b]),  total_mag[b] = sum_r mag_r            (Frobenius NORMS, as upstream)
  * Replaces onssen/loss/loss_dc.py:24-43 + loss_util.py:4-11; the caller forms upstream's (B,B) product
@@ -311,6 +311,12 @@ int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb,
 size_t onssen_loss_dc_workspace_bytes(int B);
 int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
                        float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream);
+/* d_emb (B, TF, D) = sum_b g_per_utt[b] * d per_utt[b] / d emb -- what autograd derives from loss_dc.py:36-44 (the norms of the
+ * affinity blocks): with Z = [V | Y] (weighted as above) and G = Z^T Z, dV = Z [2 Gvv/||Gvv|| ; -2 Gvy^T/||Gvy||], scaled back
+ * through the weights.  `ws` must be the workspace onssen_loss_dc_f32 has just filled for the SAME emb / one_hot / mag (its
+ * partial Grams are reused); the embedding is read once and d_emb written once.  C <= 4. */
+int onssen_loss_dc_grad_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
+                            const float* g_per_utt, float* d_emb, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N4  batch SI-SDR with the best source permutation (evaluation metric of tester.eval):

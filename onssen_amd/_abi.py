@@ -61,6 +61,7 @@ SIGNATURES = {
     "onssen_batch_sdr_workspace_bytes": (_sz, [_i]),
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
@@ -124,6 +125,10 @@ class Lib:
     def loss_dc(self, emb, one_hot, mag, B, TF, D, Cc, per_utt, total_mag, ws, ws_bytes, stream):
         self.check(self.dll.onssen_loss_dc_f32(emb, one_hot, mag, B, TF, D, Cc, per_utt, total_mag, ws, ws_bytes, stream),
                    "onssen_loss_dc_f32")
+
+    def loss_dc_grad(self, emb, one_hot, mag, B, TF, D, Cc, g_per_utt, d_emb, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_loss_dc_grad_f32(emb, one_hot, mag, B, TF, D, Cc, g_per_utt, d_emb, ws, ws_bytes, stream),
+                   "onssen_loss_dc_grad_f32")
 
     def blstm_workspace_bytes(self, B, T, in_dim, H, L, ug):
         return int(self.dll.onssen_blstm_workspace_bytes(B, T, in_dim, H, L, ug))

@@ -402,8 +402,8 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
 }
 
 
-size_t onssen_loss_dc_workspace_bytes(int B) {
-  return B > 0 ? (size_t)B * lossdc::NBLK * (lossdc::ZMAX * lossdc::ZMAX + 1) * sizeof(float) : 0;
+size_t onssen_loss_dc_workspace_bytes(int B) {   // partial Grams + (gradient pass) one M matrix and sum(mag) per utterance
+  return B > 0 ? (size_t)B * (lossdc::NBLK + 1) * (lossdc::ZMAX * lossdc::ZMAX + 1) * sizeof(float) : 0;
 }
 
 int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
@@ -421,6 +421,26 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
   return ONSSEN_OK;
 }
 
+
+int onssen_loss_dc_grad_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
+                            const float* g_per_utt, float* d_emb, void* ws, size_t ws_bytes, void* stream) {
+  if (!emb || !one_hot || !mag || !g_per_utt || !d_emb || !ws || B <= 0 || TF <= 0 || D <= 0 || C <= 0 || C > 4 ||
+      D + C > lossdc::ZMAX)
+    return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_loss_dc_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  float* gm = (float*)ws + (size_t)B * lossdc::NBLK * (lossdc::ZMAX * lossdc::ZMAX + 1);
+  hipLaunchKernelGGL(loss_dc_gradm_kernel, dim3((unsigned)B), dim3(256), 0, st, (const float*)ws, D, C, gm);
+  const int nb = ceil_div(TF, 256) > 64 ? 64 : ceil_div(TF, 256);
+  const dim3 grid((unsigned)nb, (unsigned)B);
+  if (D == 20 && aligned16(emb) && aligned16(d_emb))
+    hipLaunchKernelGGL((loss_dc_grad_kernel<20>), grid, dim3(256), 0, st, emb, one_hot, mag, gm, g_per_utt, TF, D, C, d_emb);
+  else
+    hipLaunchKernelGGL((loss_dc_grad_kernel<0>), grid, dim3(256), 0, st, emb, one_hot, mag, gm, g_per_utt, TF, D, C, d_emb);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
 
 size_t onssen_batch_sdr_workspace_bytes(int B) {
   return B > 0 ? ((size_t)B * sdr::NBLK * sdr::PSTRIDE + (size_t)B * sdr::SMAX) * sizeof(double) : 0;

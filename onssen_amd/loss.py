@@ -1,12 +1,16 @@
 """Training losses needed by the data-parallel step.
 
-With autograd (training): PyTorch ops (the affinity norms as one Gram product with an analytic backward).  Without (``trainer.validate``, onssen/utils/train.py:91-99, runs the
-loss under ``no_grad``): the HIP kernel ``onssen_loss_dc_f32``, which streams the embedding once.
+On a GPU the value comes from ``onssen_loss_dc_f32`` (one pass over the embedding builds the Gram of ``[V | Y]``) and, when
+autograd needs it, the gradient from ``onssen_loss_dc_grad_f32`` (``dV = Z M`` from the same Gram: one more pass); on the CPU
+(tests, the gloo path) PyTorch ops with the same single-Gram forward and analytic backward.  ``ONSSEN_LOSS_HIP=0`` keeps the
+PyTorch form on the GPU.
 Semantics follow onssen/loss/loss_dc.py:6-44 and loss_util.py:4-11 exactly,
 including their quirks: the affinity terms are Frobenius *norms* (not squared
 norms) and the final product ``(B,) * (B,1)`` broadcasts to a (B, B) tensor
 whose mean the trainer takes (onssen/utils/train.py:78-79).
 """
+import os
+
 import torch
 
 
@@ -22,8 +26,13 @@ def loss_dc(output, label):
     one_hot = one_hot.float()
     B, T, F, C = one_hot.shape
     D = embedding.shape[-1]
-    if embedding.is_cuda and not (torch.is_grad_enabled() and embedding.requires_grad) and D + C <= 34:
-        return _loss_dc_hip(embedding.float().contiguous(), one_hot.contiguous(), mag_mix.float().contiguous(), B, T * F, D, C)
+    needs_grad = torch.is_grad_enabled() and embedding.requires_grad
+    if embedding.is_cuda and D + C <= 34 and (not needs_grad or (C <= 4 and os.environ.get("ONSSEN_LOSS_HIP", "1") == "1")):
+        emb, oh, mag = embedding.float().contiguous(), one_hot.contiguous(), mag_mix.float().contiguous()
+        if not needs_grad:
+            return _loss_dc_hip(emb, oh, mag, B, T * F, D, C)
+        per_utt, total = _LossDcHip.apply(emb.view(B, T * F, D), oh, mag)
+        return per_utt * total.unsqueeze(1)              # (B,) * (B,1) -> (B,B), as upstream
     V = embedding.reshape(B, T * F, D)
     Y = one_hot.reshape(B, T * F, C)
     mag = mag_mix.detach().reshape(B, T * F)
@@ -64,19 +73,53 @@ class _AffinityNorms(torch.autograd.Function):
 _WS = {}
 
 
-def _loss_dc_hip(emb, one_hot, mag, B, TF, D, C):
+def _loss_dc_launch(emb, one_hot, mag, B, TF, D, C, own_ws=False):
     from .hip import get_lib
     lib = get_lib()
     dev = emb.device
     nbytes = lib.loss_dc_workspace_bytes(B)
-    ws = _WS.get((dev, B))
-    if ws is None:
-        ws = _WS[(dev, B)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if own_ws:      # kept alive by the autograd graph: the backward pass reads the partial Grams the forward left in it
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    else:
+        ws = _WS.get((dev, B))
+        if ws is None:
+            ws = _WS[(dev, B)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     per_utt = torch.empty(B, device=dev, dtype=torch.float32)
     total = torch.empty(B, device=dev, dtype=torch.float32)
     lib.loss_dc(emb.data_ptr(), one_hot.data_ptr(), mag.data_ptr(), B, TF, D, C, per_utt.data_ptr(), total.data_ptr(),
                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    return per_utt, total, ws
+
+
+def _loss_dc_hip(emb, one_hot, mag, B, TF, D, C):
+    per_utt, total, _ = _loss_dc_launch(emb, one_hot, mag, B, TF, D, C)
     return per_utt * total.unsqueeze(1)                  # (B,) * (B,1) -> (B,B), as upstream
+
+
+class _LossDcHip(torch.autograd.Function):
+    """(per_utt, total_mag) of loss_dc with the embedding's gradient from onssen_loss_dc_grad_f32 (one_hot and mag_mix are
+    labels: no gradient, like upstream's detached weights)."""
+
+    @staticmethod
+    def forward(ctx, emb, one_hot, mag):
+        B, TF, D = emb.shape
+        C = one_hot.shape[-1]
+        per_utt, total, ws = _loss_dc_launch(emb, one_hot, mag, B, TF, D, C, own_ws=True)
+        ctx.save_for_backward(emb, one_hot, mag, ws)
+        ctx.mark_non_differentiable(total)
+        return per_utt, total
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, _g_total):
+        from .hip import get_lib
+        emb, one_hot, mag, ws = ctx.saved_tensors
+        B, TF, D = emb.shape
+        d_emb = torch.empty_like(emb)
+        g = g.float().contiguous()
+        get_lib().loss_dc_grad(emb.data_ptr(), one_hot.data_ptr(), mag.data_ptr(), B, TF, D, one_hot.shape[-1], g.data_ptr(),
+                               d_emb.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return d_emb, None, None
 
 
 # ----------------------------------------------------------------------------- chimera / chimera++ losses

@@ -428,6 +428,37 @@ def test_loss_dc_value(lib, B, TF, D, C):
     np.testing.assert_allclose(per_utt, ref, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,TF,D,C", [(2, 300, 20, 2), (1, 700, 6, 3)])
+def test_loss_dc_gradient(lib, B, TF, D, C):
+    """onssen_loss_dc_grad_f32 against float64 autograd through the LITERAL form of onssen/loss/loss_dc.py:24-44 (three products,
+    Frobenius norms, detached weights), for an arbitrary upstream gradient per utterance."""
+    import torch
+    rng = np.random.default_rng(6)
+    emb = rand(rng, B, TF, D)
+    emb /= np.linalg.norm(emb, axis=-1, keepdims=True)
+    lab = rng.integers(0, C + 1, size=(B, TF))
+    one_hot = np.zeros((B, TF, C), np.float32)
+    for c in range(C):
+        one_hot[..., c] = lab == c
+    mag = np.abs(rand(rng, B, TF)) + 0.01
+    g = rand(rng, B)
+    per_utt, total = np.full(B, np.nan, np.float32), np.full(B, np.nan, np.float32)
+    ws = aligned_f32(lib.loss_dc_workspace_bytes(B) // 4 + 64)
+    lib.loss_dc(P(emb), P(one_hot), P(mag), B, TF, D, C, P(per_utt), P(total), P(ws), ws.nbytes, None)
+    d_emb = np.full((B, TF, D), np.nan, np.float32)
+    lib.loss_dc_grad(P(emb), P(one_hot), P(mag), B, TF, D, C, P(g), P(d_emb), P(ws), ws.nbytes, None)
+    V = torch.from_numpy(emb).double().requires_grad_(True)
+    Y, m = torch.from_numpy(one_hot).double(), torch.from_numpy(mag).double()
+    w = torch.sqrt(m / m.sum(1, keepdim=True)).unsqueeze(-1)
+    Vm, Ym = V * Y.sum(2, keepdim=True) * w, Y * w
+    fro = lambda x: torch.sqrt((x * x).flatten(1).sum(1))
+    val = fro(Vm.transpose(1, 2) @ Vm) - 2 * fro(Vm.transpose(1, 2) @ Ym) + fro(Ym.transpose(1, 2) @ Ym)
+    (val * torch.from_numpy(g).double()).sum().backward()
+    np.testing.assert_allclose(per_utt, val.detach().numpy(), rtol=1e-4)
+    ref = V.grad.numpy()
+    assert np.abs(d_emb - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("B,C,n,use_mask", [(2, 2, 1500, False), (1, 3, 900, True), (1, 4, 700, False)])
 def test_batch_sdr(lib, B, C, n, use_mask):
     """onssen_batch_sdr_f32 against the NumPy restatement of batch_SDR_torch (values and permutation index)."""

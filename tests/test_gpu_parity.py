@@ -602,6 +602,52 @@ def test_xcd_placement_independent_protocol(dev, monkeypatch, B, T, H, L):
     np.testing.assert_array_equal(emb, emb2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hip", ["1", "0"])
+def test_loss_dc_with_gradient_on_device(dev, golden_dir, monkeypatch, hip):
+    """N1: loss_dc WITH a gradient on the device -- onssen_loss_dc_f32 + onssen_loss_dc_grad_f32 behind autograd (ONSSEN_LOSS_HIP=0:
+    the PyTorch Gram form) -- (a) against the reference's own loss / gradient fixture (G4: value, (B,B) shape quirk, gradient norm
+    over all parameters, fc_dc bias gradient) and (b) at the training shape against float64 autograd through the literal
+    three-product form of onssen/loss/loss_dc.py:36-44."""
+    from onssen_amd import nn as onn
+    from onssen_amd.loss import loss_dc
+    monkeypatch.setenv("ONSSEN_LOSS_HIP", hip)
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")          # eval-mode network with a graph: the HIP training path (MIOpen's RNN refuses)
+    z = np.load(f"{golden_dir}/g4_loss_dc.npz")
+    sd = make_state_dict("deep_clustering", 129, int(z["H"]), int(z["L"]), 20, 2, seed=int(z["seed"]))
+    m = onn.deep_clustering(129, int(z["H"]), int(z["L"]), 20, dropout=0.0)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    out = m([torch.from_numpy(z["x"]).to(dev)])
+    assert out[0].requires_grad
+    loss = loss_dc(out, [torch.from_numpy(z["one_hot"]).to(dev), torch.from_numpy(z["mag"]).to(dev)])
+    assert tuple(loss.shape) == (3, 3)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), z["loss"], rtol=2e-5)
+    torch.mean(loss).backward()
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    np.testing.assert_allclose(gn.item(), float(z["grad_norm"]), rtol=2e-4)
+    gb, rb = m.fc_dc.bias.grad.cpu().numpy(), z["grad_fc_dc_bias"]      # fp32 sums over 3 x T rows: bound by the largest entry
+    assert np.abs(gb - rb).max() <= 5e-4 * np.abs(rb).max(), (np.abs(gb - rb).max(), np.abs(rb).max())
+    # (b) 4 x 400 x 129 bins, D = 20
+    torch.manual_seed(3)
+    B, T, F, D, C = 4, 400, 129, 20, 2
+    emb = torch.nn.functional.normalize(torch.randn(B, T, F, D), dim=-1)
+    one_hot = torch.nn.functional.one_hot(torch.randint(0, C + 1, (B, T, F)), C + 1)[..., :C].float()
+    mag = torch.rand(B, T, F) + 0.01
+    e64 = emb.double().requires_grad_(True)
+    V = e64.reshape(B, T * F, D); Y = one_hot.double().reshape(B, T * F, C); mg = mag.double().reshape(B, -1)
+    tot = mg.sum(1, keepdim=True); w = torch.sqrt(mg / tot).unsqueeze(-1)
+    Vm, Ym = V * Y.sum(2, keepdim=True) * w, Y * w
+    fro = lambda x: torch.sqrt((x * x).flatten(1).sum(1))
+    ref = (fro(Vm.transpose(1, 2) @ Vm) - 2 * fro(Vm.transpose(1, 2) @ Ym) + fro(Ym.transpose(1, 2) @ Ym)) * tot
+    g_ref, = torch.autograd.grad(ref.mean(), e64)
+    eg = emb.to(dev).requires_grad_(True)
+    got = loss_dc([eg], [one_hot.double().to(dev), mag.to(dev)])
+    g_got, = torch.autograd.grad(got.mean(), eg)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=5e-5)
+    assert (g_got.cpu().double() - g_ref).abs().max() <= 5e-5 * g_ref.abs().max()
+
+
 def test_loss_dc_value_on_device_matches_reference_fixture(dev, golden_dir, monkeypatch):
     """N1 (forward): validation-style loss -- HIP forward + onssen_loss_dc_f32 under no_grad -- against the value the
     reference's loss_dc produced (G4 fixture), and against the oracle on a full-size batch."""
