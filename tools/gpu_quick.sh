@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_config_surface.py -m gpu -q -x -k "loss_dc or training_step or config or recipe" 2>&1 | tail -5
-for v in 1 0 1 0; do ONSSEN_LOSS_HIP=$v timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3 loss_hip=$v', r.get('ms_per_step'), r.get('last_loss'))"; done
+for pe in 1 0 1 0; do echo "persist=$pe"; ONSSEN_X3Q_PERSIST=$pe SHAPES="[(12800,4800,1200),(12800,2580,1200),(12800,4800,129),(25600,4800,1200),(6400,4800,1200)]" timeout 100 python tools/gemm_probe.py; done
+for pe in 1 0 1 0; do echo -n "bench persist=$pe: "; ONSSEN_X3Q_PERSIST=$pe timeout 100 python bench.py --no-cpu-baseline --steps 40 | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['roofline']['other_kernels']['ms_by_call'])"; done
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or linear or gemm or cfg" 2>&1 | tail -2
