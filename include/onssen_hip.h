@@ -61,7 +61,7 @@ extern "C" {
                                      x3 image (onssen_x3_image_f32) of the packed [2*NP][K_l] input-projection
                                      matrix, and the last layer's output image stays in the workspace for the
                                      heads (onssen_blstm_y_image). */
-#define ONSSEN_BLSTM_FUSE_IN0 16   /* (with XCD, in_dim <= 160) the first layer's input projection is computed inside its
+#define ONSSEN_BLSTM_FUSE_IN0 16   /* (with XCD, in_dim <= 128, or = 129 with FUSE_TAIL) the first layer's input projection is computed inside its
                                      recurrence launch: wih_p_host[0] must be the B-fragment image made by
                                      onssen_lstm_pack_wih_bf16x3 of the layer's two W_ih, back to back; no G is
                                      written or read for that layer. */

@@ -574,7 +574,8 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     const float* yin = ((L - 1 - l) % 2 == 0) ? ybuf : y;
     int rc;
     const bool fuse0 = images && l == 0 && (flags & ONSSEN_BLSTM_FUSE_IN0);
-    if (fuse0 && in_dim > 160) return ONSSEN_E_ARG;
+    // the fused projection keeps <= 4 k-chunks of W_ih fragments in the LDS: in_dim <= 128, or 32k + 1 <= 129 with FUSE_TAIL
+    if (fuse0 && !(in_dim <= 128 || (in_dim == 129 && (flags & ONSSEN_BLSTM_FUSE_TAIL)))) return ONSSEN_E_ARG;
     if (images) {
       const uint16_t* a_img = l == 0 ? img_x : img_ab[(L - l) % 2];   // layer l-1 wrote buffer (L-1-(l-1)) % 2
       if (l == 0) {

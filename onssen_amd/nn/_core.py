@@ -285,7 +285,7 @@ class _PackedImages:
             lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
             self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
             self.wih_img.append(ai)
-            if l == 0 and in_l <= 160:   # fragment image for the fused first-layer input projection (FUSE_IN0)
+            if l == 0 and in_l <= 129:   # fragment image for the fused first-layer input projection (FUSE_IN0: <= 4 MFMA k-chunks)
                 kc = (in_l + 31) // 32
                 f0 = torch.empty(2, (self.Hp // self.ug) * kc * (self.ug // 4) * 1024, device=dev, dtype=torch.int16)
                 for d in range(2):
