@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x -k "train or grad or dropout or robust" 2>&1 | tail -3
-for v in 1 0 1 0; do ONSSEN_BWD_STACK=$v timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3 bwd_stack=$v', r.get('ms_per_step'), r.get('last_loss'))"; done
+for v in base wearly; do echo $v; ONSSEN_HIP_LIB=build_variants/libonssen_hip_$v.so timeout 100 python tools/xcd_startup_probe.py 2>&1 | tail -5; done
+python tools/ab_variants.py run base wearly -- bench.py --no-cpu-baseline --steps 40
