@@ -1,4 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for v in base wearly; do echo $v; ONSSEN_HIP_LIB=build_variants/libonssen_hip_$v.so timeout 100 python tools/xcd_startup_probe.py 2>&1 | tail -5; done
-python tools/ab_variants.py run base wearly -- bench.py --no-cpu-baseline --steps 40
+python tools/ab_variants.py run fold0 fold1 -- bench.py --no-cpu-baseline --steps 40
+python tools/ab_variants.py run fold0 fold1 -- bench.py --no-cpu-baseline --steps 40 --config dc_l3
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or xcd or cfg" 2>&1 | tail -2
