@@ -108,8 +108,8 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   if (!wav || !logmag || B <= 0 || hop <= 0 || n_samples <= n_fft / 2) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
-  const long frames = (long)B * T;
-  const dim3 grid((unsigned)((frames + 3) / 4)), block(256);
+  const long frames = (long)B * T, pairs = (frames + 1) / 2;       // one wave per pair of frames (one complex transform)
+  const dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
     hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
