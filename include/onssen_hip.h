@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -166,6 +166,13 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
  * Used by the training path: the two directions' weight-gradient GEMMs fill the chip only together. */
 int onssen_linear_x3p_batched(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
                               const float* bias, int N, float* C, int64_t c_bs, int64_t ldc, int batch, void* stream);
+/* The same with row map and TWO dense outputs: row m of problem z goes to C + z*c_bs + (m / R)*c_s0 + (m % R)*c_s1 for the
+ * columns n < n_split and to C2 + z*c2_bs + (m / R)*c2_s0 + (m % R)*c2_s1 (column n - n_split) for the rest.  The training
+ * path uses it to write [dW_ih | dW_hh] of both directions straight into nn.LSTM's row order (packed row 4u + gate ->
+ * row gate*H + u: R = 4, c_s0 = ld, c_s1 = H*ld) and into two contiguous matrices: no gather, no strided copies. */
+int onssen_linear_x3p_batched_split(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                                    const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1,
+                                    int n_split, float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream);
 
 /* x3 image of the TRANSPOSE of a row-major fp32 matrix src [K][ld >= M], optionally shifted along k: image row m
  * (0 <= m < M), element k (0 <= k < K) = src[(k + k_shift) * ld + m], 0 where k + k_shift is outside [0, K).  Operands of

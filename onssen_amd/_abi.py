@@ -42,6 +42,8 @@ SIGNATURES = {
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_linear_x3p_batched": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i64, _i64, _i, _vp]),
+    "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
+                                             _i, _vp]),
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
@@ -184,6 +186,11 @@ class Lib:
     def linear_x3p_batched(self, a_img, a_bs, M, K, w_img, w_bs, bias, N, out, c_bs, ldc, batch, stream):
         self.check(self.dll.onssen_linear_x3p_batched(a_img, a_bs, M, K, w_img, w_bs, bias, N, out, c_bs, ldc, batch, stream),
                    "onssen_linear_x3p_batched")
+
+    def linear_x3p_batched_split(self, a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1, n_split, out2, c2_bs,
+                                 c2_s0, c2_s1, batch, stream):
+        self.check(self.dll.onssen_linear_x3p_batched_split(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1, n_split,
+                                                            out2, c2_bs, c2_s0, c2_s1, batch, stream), "onssen_linear_x3p_batched_split")
 
     def x3_image_t(self, src, ld, M, K, k_shift, img, stream):
         self.check(self.dll.onssen_x3_image_t_f32(src, ld, M, K, k_shift, img, stream), "onssen_x3_image_t_f32")

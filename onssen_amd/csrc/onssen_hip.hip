@@ -318,22 +318,39 @@ int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shif
   return ONSSEN_OK;
 }
 
-int onssen_linear_x3p_batched(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
-                              const float* bias, int N, float* C, int64_t c_bs, int64_t ldc, int batch, void* stream) {
-  if (!a_img || !w_img || !bias || !C || M <= 0 || K <= 0 || N <= 0 || batch <= 0 || batch > 65535 || ldc < N) return ONSSEN_E_ARG;
+static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                                   const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1, int n_split,
+                                   float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream) {
+  if (!a_img || !w_img || !bias || !C || M <= 0 || K <= 0 || N <= 0 || R <= 0 || batch <= 0 || batch > 65535) return ONSSEN_E_ARG;
+  if (C2 && (n_split <= 0 || n_split >= N)) return ONSSEN_E_ARG;
   if (!aligned16(a_img) || !aligned16(w_img) || (a_bs % 8) != 0 || (w_bs % 8) != 0) return ONSSEN_E_ALIGN;
   const int KB = ceil_div(K, 32);
   if ((long)lxp::BM * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   LinearXpArgs p;
-  p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)ldc; p.c_s1 = 0; p.R = 1; p.M = M; p.N = N;
+  p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = 0; p.eps = 0.f; p.tile_group = 4;
-  p.c_vec = aligned16(C) && (N % 4) == 0 && (ldc % 4) == 0 && (c_bs % 4) == 0;
+  p.c_vec = !C2 && aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0 && (c_bs % 4) == 0;
   p.a_bs = (long)a_bs; p.w_bs = (long)w_bs; p.c_bs = (long)c_bs;
+  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = (long)c2_bs; p.n_split = n_split;
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM), (unsigned)batch);
   hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS, 4, 3, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
+}
+
+int onssen_linear_x3p_batched(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                              const float* bias, int N, float* C, int64_t c_bs, int64_t ldc, int batch, void* stream) {
+  if (ldc < N) return ONSSEN_E_ARG;
+  return linear_x3p_batched_impl(a_img, a_bs, M, K, w_img, w_bs, bias, N, 1, C, c_bs, ldc, 0, 0, nullptr, 0, 0, 0, batch, stream);
+}
+
+int onssen_linear_x3p_batched_split(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                                    const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1,
+                                    int n_split, float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream) {
+  if (!C2) return ONSSEN_E_ARG;
+  return linear_x3p_batched_impl(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, C, c_bs, c_s0, c_s1, n_split, C2, c2_bs, c2_s0, c2_s1,
+                                 batch, stream);
 }
 
 int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
@@ -354,6 +371,7 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = group; p.eps = eps;
   p.a_bs = p.w_bs = p.c_bs = 0;
+  p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
   static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;

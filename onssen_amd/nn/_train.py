@@ -87,10 +87,18 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
         # the forward direction looks B rows back, the reverse direction B rows ahead
         lib.x3_image_t(y2[:, d * Hp:].data_ptr(), 2 * Hp, Hp, TB, -B if d == 0 else B, w1[d, Kx:].data_ptr(), st)
     zero_bias = torch.zeros(max(N1, wih_p.shape[2]), device=dev, dtype=torch.float32)
-    out1 = torch.empty(2, NP, N1, device=dev, dtype=torch.float32)
     # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
-    lib.linear_x3p_batched(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1,
-                           out1.data_ptr(), NP * N1, N1, 2, st)
+    direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
+    if direct:
+        dW_ih2 = torch.empty(2, 4 * H, Kx, device=dev, dtype=torch.float32)
+        dW_hh2 = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
+        # packed row m = 4u + gate -> row gate*H + u: R = 4, unit stride ld, gate stride H*ld
+        lib.linear_x3p_batched_split(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1, 4,
+                                     dW_ih2.data_ptr(), 4 * H * Kx, Kx, H * Kx, Kx, dW_hh2.data_ptr(), 4 * H * H, H, H * H, 2, st)
+    else:
+        out1 = torch.empty(2, NP, N1, device=dev, dtype=torch.float32)
+        lib.linear_x3p_batched(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1,
+                               out1.data_ptr(), NP * N1, N1, 2, st)
     dx = None
     if need_dx:
         Kp = wih_p.shape[2]
@@ -107,6 +115,9 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
         feat = torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)])
     grads = []
     for d in range(2):
+        if direct:
+            grads.append((dW_ih2[d], dW_hh2[d], db2[d * NP + cols]))
+            continue
         rows = out1[d].index_select(0, cols)                                     # (4H, N1) in nn.LSTM row order
         dW_ih = rows[:, :Kx] if feat is None else rows[:, :Kx].index_select(1, feat)
         dW_hh = rows[:, Kx:Kx + H]

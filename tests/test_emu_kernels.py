@@ -590,7 +590,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     assert np.all(np.array(gates).reshape(T, B, 2, NP // 4, 4)[:, :, :, H:, :] == 0) if ug * (Hp // ug) == Hp and H % ug == 0 else True
 
 
-@pytest.mark.parametrize("H,ug,Kx,first", [(10, 4, 9, True), (10, 4, 24, False), (8, 8, 16, False)])
+@pytest.mark.parametrize("H,ug,Kx,first", [(10, 4, 9, True), (10, 4, 24, False), (8, 8, 16, False), (8, 4, 9, True)])   # the last two: no padded units -> two dense outputs in nn.LSTM row order straight from the GEMM
 def test_layer_gradient_gemms_on_the_split_bf16_kernel(lib, H, ug, Kx, first):
     """nn/_train.py: the weight / input gradient contractions in the packed layouts on onssen_linear_x3p agree with
     the plain torch contractions in the reference's layouts (fp32), within the split-bf16 product error."""

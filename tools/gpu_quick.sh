@@ -1,8 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-python tools/ab_variants.py run base stft2 -- bench.py --no-cpu-baseline --steps 40
-python tools/ab_variants.py run base stft2 -- bench.py --no-cpu-baseline --steps 20 --config phase_l4
-timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_wav_loader.py -m gpu -q -x -k "stft or feature or label or separ or golden or e2e or wav or batches or eval" 2>&1 | tail -2
-cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_stft -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
-f=$(find gpurun_out/prof_stft -name "*kernel_stats.csv" | head -1); grep -i "stft" $f | cut -c1-160
-rm -rf gpurun_out/prof_stft
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py -m gpu -q -x -k "train or grad or dropout or robust or loss" 2>&1 | tail -3
+for i in 1 2; do timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3', r.get('ms_per_step'), r.get('last_loss'))"; done
+timeout 200 python tools/train_step_bench.py --layers 2 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L2', r.get('ms_per_step'), r.get('last_loss'))"
