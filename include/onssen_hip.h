@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -245,7 +245,9 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
  *     protocol exactly as in onssen_blstm_forward_f32).
  *   form ONSSEN_LSTM_BWD_STEPS: one launch per time step (T launches); whh_img = onssen_lstm_pack_whhT_bf16x3 images
  *     (onssen_lstm_whhT_elems).  No requirements on ws contents.
- *   Split-bf16 products, fp32 accumulation and state in both forms. */
+ *   Split-bf16 products, fp32 accumulation and state in both forms.
+ *   db_rows (ONSSEN_LSTM_BWD_XCD only, may be NULL): [B][2][NP], receives sum_t dP[t][b] per batch row -- the kernel has every
+ *   dP in registers as it goes; the bias gradient is the sum of its B rows instead of a pass over all T*B rows of dP. */
 #define ONSSEN_LSTM_BWD_STEPS 0
 #define ONSSEN_LSTM_BWD_XCD 1
 int onssen_lstm_train_forward_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
@@ -257,7 +259,7 @@ int64_t onssen_lstm_whhR_elems(int H, int ug);
 int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream);
 size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form);
 int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
-                                   const float* cs, void* ws, size_t ws_bytes, int form, void* stream);
+                                   const float* cs, void* ws, size_t ws_bytes, int form, float* db_rows, void* stream);
 /* The inter-layer dropout of nn.LSTM(dropout=p) (onssen/nn/deep_clustering.py:15-22) as ONE pass:
  *   out[i] = keep(seed, i) ? x[i] / (1 - p) : 0,   keep = counter-based hash of (seed, i) compared with p
  * -- no mask tensor: the backward pass calls it again on dL/d(out) with the same seed.  Like the reference's (the RNN

@@ -51,7 +51,7 @@ SIGNATURES = {
     "onssen_lstm_whhR_elems": (_i64, [_i, _i]),
     "onssen_lstm_pack_whhR_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "onssen_dropout_f32": (_i, [_vp, _i64, _f, C.c_uint64, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
@@ -214,8 +214,8 @@ class Lib:
     def lstm_train_backward_workspace_bytes(self, B, H, ug, form):
         return int(self.dll.onssen_lstm_train_backward_workspace_bytes(B, H, ug, form))
 
-    def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream):
-        self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream),
+    def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream, db_rows=None):
+        self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, db_rows, stream),
                    "onssen_lstm_train_backward_f32")
 
     def dropout(self, x, n, p, seed, out, stream):

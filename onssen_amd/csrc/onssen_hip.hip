@@ -757,10 +757,11 @@ size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form
 }
 
 int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
-                                   const float* cs, void* ws, size_t ws_bytes, int form, void* stream) {
+                                   const float* cs, void* ws, size_t ws_bytes, int form, float* db_rows, void* stream) {
   int Hp, NP, KQB, NUB;
   if (!whh_img || !dy || !gates_dp || !cs || !ws || B <= 0 || T <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB) ||
-      (form != ONSSEN_LSTM_BWD_STEPS && form != ONSSEN_LSTM_BWD_XCD))
+      (form != ONSSEN_LSTM_BWD_STEPS && form != ONSSEN_LSTM_BWD_XCD) || (db_rows && form != ONSSEN_LSTM_BWD_XCD) ||
+      (db_rows && !aligned16(db_rows)))
     return ONSSEN_E_ARG;
   if (ws_bytes < onssen_lstm_train_backward_workspace_bytes(B, H, ug, form)) return ONSSEN_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0 || !aligned16(gates_dp)) return ONSSEN_E_ALIGN;
@@ -774,7 +775,7 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
     xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
-    xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env;
+    xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env; xa.db_rows = db_rows;
     // ONSSEN_XCD_PROFILE builds only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
     static const bool dbg_env = getenv("ONSSEN_BWD_DBG") != nullptr;
     xa.dbg = dbg_env && ws_bytes >= onssen_lstm_train_backward_workspace_bytes(B, H, ug, form) + (size_t)T * 64

@@ -61,7 +61,7 @@ def _x3_image(lib, st, m):
     return img
 
 
-def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
+def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, db_rows=None):
     """The same contractions as layer_gradients on the split-bf16 MFMA GEMM (onssen_linear_x3p), in the packed layouts
     the kernels use, so that no gather of dP is needed:
 
@@ -107,7 +107,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx):
         lib.x3_image_t(wih_p.data_ptr(), Kp, Kp, 2 * NP, 0, w2.data_ptr(), st)     # image of W_ih(packed)^T
         dx = torch.empty(TB, Kp, device=dev, dtype=torch.float32)
         lib.linear_x3p(a.data_ptr(), TB, 2 * NP, w2.data_ptr(), zero_bias.data_ptr(), Kp, 0, 0, 0.0, dx.data_ptr(), 1, Kp, 0, st)
-    db2 = dp2.sum(0)
+    db2 = db_rows.sum(0) if db_rows is not None else dp2.sum(0)      # (B, 2*NP) row sums left by the backward kernel, or a pass over dP
     cols = packed_columns(H, Hp, ug, dev)
     if Kx == in_features:
         feat = None
@@ -224,13 +224,15 @@ class BLSTMTrainFunction(torch.autograd.Function):
         use_x3 = os.environ.get("ONSSEN_TRAIN_GEMM", "x3") == "x3"
         for l in range(L - 1, -1, -1):
             xp, y, gates, cs, mask = ctx.saved_layers[l]
+            # the persistent kernel also leaves sum_t dP per batch row: the bias gradient without a pass over all of dP
+            db_rows = torch.empty(B, 2 * NP, device=dev, dtype=torch.float32) if form == _abi.LSTM_BWD_XCD else None
             lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
-                                    wsb.data_ptr(), wsb.numel(), form, st)
+                                    wsb.data_ptr(), wsb.numel(), form, st, db_rows.data_ptr() if db_rows is not None else None)
             if form == _abi.LSTM_BWD_XCD:
                 _XcdStatus.post(wsb)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if use_x3:
-                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx)
+                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx, db_rows)
             else:
                 w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
                 x_rows = xp if l == 0 or Hp == H else xp.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H)

@@ -572,7 +572,10 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     dy[:, :, :, :H] = R.numpy().transpose(1, 0, 2).reshape(T, B, 2, H)
     wsb = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug, form) // 4 + 64,))
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)     # scramble=1: the placement-independent protocol
-    lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, form, None)
+    db_rows = _shm((B, 2, NP), fill=np.nan) if xcd else None
+    lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, form, None, P(db_rows) if xcd else None)
+    if xcd:      # the kernel's per-row sums of dP over time (the bias gradient's operand) against the dP it wrote
+        np.testing.assert_allclose(np.array(db_rows), np.array(gates).sum(0), rtol=1e-5, atol=1e-6)
     if xcd:
         assert wsb.view(np.uint32)[280] == 0 and wsb.view(np.uint32)[281] == (1 if scramble == "1" else 0)
     w_ih = (lstm.weight_ih_l0.detach(), lstm.weight_ih_l0_reverse.detach())

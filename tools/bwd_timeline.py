@@ -39,7 +39,7 @@ def main():
         g2 = gates.clone()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.lstm_train_backward(B, T, H, ug, whh.data_ptr(), dy.data_ptr(), g2.data_ptr(), cs.data_ptr(), wsb.data_ptr(), wsb.numel(), form, st)
+        lib.lstm_train_backward(B, T, H, ug, whh.data_ptr(), dy.data_ptr(), g2.data_ptr(), cs.data_ptr(), wsb.data_ptr(), wsb.numel(), form, st, None)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
