@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -266,6 +266,11 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
  * library's own generator) the random stream is not torch's; the caller draws `seed` from torch's generator, so runs
  * repeat under torch.manual_seed.  0 <= p < 1; out may alias x; n elements, 16-byte aligned when n % 4 == 0. */
 int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, void* stream);
+/* F.normalize(x, p=2, dim=-1, eps) over `rows` rows of D floats and its backward -- the embedding's unit norm per TF bin in a
+ * TRAINING forward (onssen/nn/deep_clustering.py:40-41; inference normalises in the GEMM epilogue):
+ *   y = x / max(||x||, eps);   dx = (g - y (y . g)) / ||x||  where ||x|| > eps,  g / eps  elsewhere.   D % 4 == 0, D <= 64. */
+int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float* y, void* stream);
+int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, int D, float eps, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 glue  recurrent input of the phase network for all C speakers at once:

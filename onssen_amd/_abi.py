@@ -53,6 +53,8 @@ SIGNATURES = {
     "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "onssen_dropout_f32": (_i, [_vp, _i64, _f, C.c_uint64, _vp, _vp]),
+    "onssen_l2norm_rows_f32": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
+    "onssen_l2norm_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -217,6 +219,12 @@ class Lib:
     def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream, db_rows=None):
         self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, db_rows, stream),
                    "onssen_lstm_train_backward_f32")
+
+    def l2norm_rows(self, x, rows, D, eps, y, stream):
+        self.check(self.dll.onssen_l2norm_rows_f32(x, rows, D, eps, y, stream), "onssen_l2norm_rows_f32")
+
+    def l2norm_rows_grad(self, x, g, rows, D, eps, dx, stream):
+        self.check(self.dll.onssen_l2norm_rows_grad_f32(x, g, rows, D, eps, dx, stream), "onssen_l2norm_rows_grad_f32")
 
     def dropout(self, x, n, p, seed, out, stream):
         self.check(self.dll.onssen_dropout_f32(x, n, p, seed, out, stream), "onssen_dropout_f32")

@@ -821,6 +821,28 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
   return ONSSEN_OK;
 }
 
+int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float* y, void* stream) {
+  if (!x || !y || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
+  if (!aligned16(x) || !aligned16(y)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  const long nb = (rows + 255) / 256;
+  hipLaunchKernelGGL((l2norm_rows_kernel<false>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x,
+                     (const float*)nullptr, (long)rows, D, eps, y);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, int D, float eps, float* dx, void* stream) {
+  if (!x || !g || !dx || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
+  if (!aligned16(x) || !aligned16(g) || !aligned16(dx)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  const long nb = (rows + 255) / 256;
+  hipLaunchKernelGGL((l2norm_rows_kernel<true>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x, g,
+                     (long)rows, D, eps, dx);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, void* stream) {
   if (!x || !out || n <= 0 || !(p >= 0.0f) || !(p < 1.0f)) return ONSSEN_E_ARG;
   const int vec = (n % 4) == 0 && aligned16(x) && aligned16(out);

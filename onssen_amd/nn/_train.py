@@ -319,3 +319,36 @@ def head_linear(lin, x):
     if x.is_cuda and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
         return LinearX3Function.apply(x, lin.weight, lin.bias)
     return Fn.linear(x, lin.weight, lin.bias)
+
+
+class _L2NormRows(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) on onssen_l2norm_rows_f32 / _grad_f32: one pass forward, one backward, instead of the ~10
+    element-wise ATen kernels of norm / clamp / div and their autograd formulas over a (B, T*F, D) tensor."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        lib.l2norm_rows(x.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], eps, y.data_ptr(), st)
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x, = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx = torch.empty_like(x)
+        lib.l2norm_rows_grad(x.data_ptr(), g.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], ctx.eps, dx.data_ptr(), st)
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=-1, eps) of a training forward: the HIP kernels on a ROCm device (fp32, D % 4 == 0, D <= 64), else ATen."""
+    D = x.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and D % 4 == 0 and D <= 64 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+        return _L2NormRows.apply(x, eps)
+    return Fn.normalize(x, p=2, dim=-1, eps=eps)

@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._train import head_linear
+from ._train import head_linear, l2_normalize
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
@@ -51,6 +51,6 @@ class chimera(PackedWeightsMixin, nn.Module):
     def _autograd_forward(self, x):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
-        e = F.normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1), p=2, dim=-1).reshape(B, T, Fq, -1)
+        e = l2_normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1)).reshape(B, T, Fq, -1)
         m = torch.sigmoid(head_linear(self.fc_mi, r)).reshape(B, T, Fq, -1)
         return [e, m[:, :, :, 0], m[:, :, :, 1]]

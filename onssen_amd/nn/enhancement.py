@@ -68,6 +68,6 @@ class enhance(PackedWeightsMixin, nn.Module):
 
     def _autograd_forward(self, x, mag_noisy):
         r = self.rnn.autograd_forward(x, self.training)
-        r = self.bn(r.permute(0, 2, 1)).permute(0, 2, 1)
+        r = self.bn(r.reshape(-1, r.shape[-1])).reshape(r.shape)      # BatchNorm1d over (B*T, C) rows = over (B, C, T) without the two permuted copies
         mask = torch.sigmoid(self.fc_mi(r))
         return torch.relu(self.fc_post(torch.relu(self.fc_pre(mag_noisy)) * mask))

@@ -64,7 +64,7 @@ class phase_net(PackedWeightsMixin, nn.Module):
         for m in (mask_A, mask_B):
             inp = torch.cat((x_mag * m, x_phase.view(B, T, -1)), 2)
             r = self.rnn.autograd_forward(inp, self.training)
-            r = self.bn(r.permute(0, 2, 1)).permute(0, 2, 1)
+            r = self.bn(r.reshape(-1, r.shape[-1])).reshape(r.shape)      # BatchNorm1d over (B*T, C) rows = over (B, C, T) without the two permuted copies
             p = self.fc_phase(r).reshape(B, T, Fq, -1) + x_phase
             outs.append(F.normalize(p, p=2, dim=-1))
         return [embedding, mask_A, mask_B, outs[0], outs[1]]

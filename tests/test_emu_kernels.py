@@ -711,3 +711,23 @@ def test_dropout_one_pass(lib, n):
     np.testing.assert_array_equal(y, a)
     lib.dropout(P(x), n, 0.0, 7, P(b), None)
     np.testing.assert_array_equal(b, x)
+
+
+@pytest.mark.parametrize("rows,D", [(300, 20), (70, 4)])
+def test_l2norm_rows_forward_and_gradient(lib, rows, D):
+    """onssen_l2norm_rows_f32 / _grad_f32 against F.normalize and its autograd in float64 (incl. an all-zero row: y = 0, dx = g / eps
+    -- what max(||x||, eps) gives)."""
+    import torch
+    rng = np.random.default_rng(9)
+    x = rand(rng, rows, D); x[3] = 0.0
+    g = rand(rng, rows, D)
+    y, dx = np.full((rows, D), np.nan, np.float32), np.full((rows, D), np.nan, np.float32)
+    lib.l2norm_rows(P(x), rows, D, 1e-12, P(y), None)
+    lib.l2norm_rows_grad(P(x), P(g), rows, D, 1e-12, P(dx), None)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    yt = torch.nn.functional.normalize(xt, p=2, dim=-1, eps=1e-12)
+    (yt * torch.from_numpy(g).double()).sum().backward()
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=2e-6, atol=1e-7)
+    ok = np.arange(rows) != 3
+    np.testing.assert_allclose(dx[ok], xt.grad.numpy()[ok], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dx[3], g[3] / np.float32(1e-12), rtol=1e-6)
