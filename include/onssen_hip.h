@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -270,6 +270,17 @@ int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float*
  * TRAINING forward (onssen/nn/deep_clustering.py:40-41; inference normalises in the GEMM epilogue):
  *   y = x / max(||x||, eps);   dx = (g - y (y . g)) / ||x||  where ||x|| > eps,  g / eps  elsewhere.   D % 4 == 0, D <= 64. */
 int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float* y, void* stream);
+/* Train-mode BatchNorm1d over the rows of a row-major (M, C) matrix (onssen/nn/deep_clustering.py:12,36-38: per channel, over all
+ * B*T frames of the batch): y = (x - mean) * invstd * gamma + beta with the batch's biased variance, mean / invstd returned
+ * for the backward pass (the caller updates running_mean / running_var from mean and 1 / invstd^2 - eps, unbiased by
+ * M / (M - 1), as nn.BatchNorm1d does); and its backward: dbeta = sum dy, dgamma = sum dy * xhat,
+ * dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).  Column sums are partial sums of 128-row strips added in a
+ * fixed order (deterministic).  ws: onssen_bn_rows_workspace_bytes(M, C). */
+size_t onssen_bn_rows_workspace_bytes(int64_t M, int C);
+int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float* y,
+                             float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream);
+int onssen_bn_rows_grad_f32(const float* x, const float* dy, int64_t M, int C, const float* gamma, const float* mean,
+                            const float* invstd, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, int D, float eps, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

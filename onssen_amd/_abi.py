@@ -54,6 +54,9 @@ SIGNATURES = {
     "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
     "onssen_dropout_f32": (_i, [_vp, _i64, _f, C.c_uint64, _vp, _vp]),
     "onssen_l2norm_rows_f32": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
+    "onssen_bn_rows_workspace_bytes": (_sz, [_i64, _i]),
+    "onssen_bn_rows_train_f32": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_bn_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_l2norm_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
@@ -219,6 +222,17 @@ class Lib:
     def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream, db_rows=None):
         self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, db_rows, stream),
                    "onssen_lstm_train_backward_f32")
+
+    def bn_rows_workspace_bytes(self, M, Cc):
+        return int(self.dll.onssen_bn_rows_workspace_bytes(M, Cc))
+
+    def bn_rows_train(self, x, M, Cc, gamma, beta, eps, y, mean, invstd, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_bn_rows_train_f32(x, M, Cc, gamma, beta, eps, y, mean, invstd, ws, ws_bytes, stream),
+                   "onssen_bn_rows_train_f32")
+
+    def bn_rows_grad(self, x, dy, M, Cc, gamma, mean, invstd, dx, dgamma, dbeta, ws, ws_bytes, stream):
+        self.check(self.dll.onssen_bn_rows_grad_f32(x, dy, M, Cc, gamma, mean, invstd, dx, dgamma, dbeta, ws, ws_bytes, stream),
+                   "onssen_bn_rows_grad_f32")
 
     def l2norm_rows(self, x, rows, D, eps, y, stream):
         self.check(self.dll.onssen_l2norm_rows_f32(x, rows, D, eps, y, stream), "onssen_l2norm_rows_f32")

@@ -821,6 +821,47 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
   return ONSSEN_OK;
 }
 
+size_t onssen_bn_rows_workspace_bytes(int64_t M, int C) {
+  return M > 0 && C > 0 ? (size_t)((M + bnr::STRIP - 1) / bnr::STRIP) * 2 * (size_t)C * sizeof(float) : 0;
+}
+
+int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float* y,
+                             float* mean, float* invstd, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !invstd || !ws || M <= 1 || C <= 0 || M > 0x7fffffffL * bnr::STRIP) return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_bn_rows_workspace_bytes(M, C)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((M + bnr::STRIP - 1) / bnr::STRIP);
+  const dim3 gp((unsigned)nblk, (unsigned)ceil_div(C, 256));
+  hipLaunchKernelGGL((bn_rows_partial_kernel<0>), gp, dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (long)M, C, (float*)ws);
+  hipLaunchKernelGGL((bn_rows_final_kernel<0>), dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, (const float*)ws, nblk, (long)M, C,
+                     eps, mean, invstd);
+  const long nb = ((long)M * C + 255) / 256;
+  hipLaunchKernelGGL((bn_rows_apply_kernel<0>), dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, x, (const float*)nullptr,
+                     (const float*)mean, (const float*)invstd, gamma, beta, (const float*)nullptr, (long)M, C, y);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_bn_rows_grad_f32(const float* x, const float* dy, int64_t M, int C, const float* gamma, const float* mean,
+                            const float* invstd, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !gamma || !mean || !invstd || !dx || !dgamma || !dbeta || !ws || M <= 1 || C <= 0) return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_bn_rows_workspace_bytes(M, C)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((M + bnr::STRIP - 1) / bnr::STRIP);
+  const dim3 gp((unsigned)nblk, (unsigned)ceil_div(C, 256));
+  hipLaunchKernelGGL((bn_rows_partial_kernel<1>), gp, dim3(256), 0, st, x, dy, mean, invstd, (long)M, C, (float*)ws);
+  hipLaunchKernelGGL((bn_rows_final_kernel<1>), dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, (const float*)ws, nblk, (long)M, C,
+                     0.0f, dbeta, dgamma);
+  const long nb = ((long)M * C + 255) / 256;
+  hipLaunchKernelGGL((bn_rows_apply_kernel<1>), dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, x, dy, mean, invstd, gamma,
+                     (const float*)dbeta, (const float*)dgamma, (long)M, C, dx);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float* y, void* stream) {
   if (!x || !y || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
   if (!aligned16(x) || !aligned16(y)) return ONSSEN_E_ALIGN;

@@ -352,3 +352,58 @@ def l2_normalize(x, eps=1e-12):
     if x.is_cuda and x.dtype == torch.float32 and D % 4 == 0 and D <= 64 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
         return _L2NormRows.apply(x, eps)
     return Fn.normalize(x, p=2, dim=-1, eps=eps)
+
+
+class _BnRowsTrain(torch.autograd.Function):
+    """Train-mode batch normalisation of (M, C) rows on onssen_bn_rows_train_f32 / _grad_f32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x = x.contiguous()
+        M, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        ws = torch.empty(lib.bn_rows_workspace_bytes(M, C), dtype=torch.uint8, device=x.device)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        lib.bn_rows_train(x.data_ptr(), M, C, g.data_ptr(), b.data_ptr(), eps, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                          ws.data_ptr(), ws.numel(), st)
+        ctx.save_for_backward(x, g, mean, invstd)
+        ctx.mark_non_differentiable(mean, invstd)
+        return y, mean, invstd
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, _gm, _gi):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x, g, mean, invstd = ctx.saved_tensors
+        M, C = x.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+        ws = torch.empty(lib.bn_rows_workspace_bytes(M, C), dtype=torch.uint8, device=x.device)
+        lib.bn_rows_grad(x.data_ptr(), dy.data_ptr(), M, C, g.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dx.data_ptr(),
+                         dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        return dx, dgamma, dbeta, None
+
+
+def batch_norm_rows(bn, r):
+    """``bn(r.permute(0, 2, 1)).permute(0, 2, 1)`` of the reference's forward (onssen/nn/deep_clustering.py:36-38) for r (B, T, C):
+    BatchNorm1d's statistics over (B, T) per channel are the statistics over the B*T rows of r viewed as (B*T, C) -- no
+    permuted copies.  In training on a ROCm device: the HIP kernels (running statistics updated like nn.BatchNorm1d does:
+    momentum, unbiased variance); otherwise nn.BatchNorm1d itself on the 2-D view."""
+    C = r.shape[-1]
+    x2 = r.reshape(-1, C)
+    if (bn.training and r.is_cuda and r.dtype == torch.float32 and bn.affine and bn.track_running_stats and x2.shape[0] > 1
+            and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"):
+        y, mean, invstd = _BnRowsTrain.apply(x2, bn.weight, bn.bias, float(bn.eps))
+        with torch.no_grad():
+            M = x2.shape[0]
+            bn.num_batches_tracked += 1
+            m = float(bn.momentum) if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            var_unbiased = (1.0 / (invstd * invstd) - bn.eps) * (M / (M - 1.0))
+            bn.running_mean.lerp_(mean, m)
+            bn.running_var.lerp_(var_unbiased, m)
+        return y.reshape(r.shape)
+    return bn(x2).reshape(r.shape)

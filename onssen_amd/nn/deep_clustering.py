@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._train import head_linear, l2_normalize
+from ._train import batch_norm_rows, head_linear, l2_normalize
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
@@ -44,6 +44,6 @@ class deep_clustering(PackedWeightsMixin, nn.Module):
     def _autograd_forward(self, x):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
-        r = self.bn(r.reshape(-1, r.shape[-1])).reshape(r.shape)      # BatchNorm1d over (B*T, C) rows = over (B, C, T) without the two permuted copies
+        r = batch_norm_rows(self.bn, r)
         e = l2_normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1))
         return e.reshape(B, T, Fq, -1)

@@ -1,6 +1,7 @@
 import torch
 import torch.nn as nn
 
+from ._train import batch_norm_rows
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_RELU, EPI_SIGMOID, _stream, _version_key,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 from ..hip import get_lib
@@ -68,6 +69,6 @@ class enhance(PackedWeightsMixin, nn.Module):
 
     def _autograd_forward(self, x, mag_noisy):
         r = self.rnn.autograd_forward(x, self.training)
-        r = self.bn(r.reshape(-1, r.shape[-1])).reshape(r.shape)      # BatchNorm1d over (B*T, C) rows = over (B, C, T) without the two permuted copies
+        r = batch_norm_rows(self.bn, r)
         mask = torch.sigmoid(self.fc_mi(r))
         return torch.relu(self.fc_post(torch.relu(self.fc_pre(mag_noisy)) * mask))

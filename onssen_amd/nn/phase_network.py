@@ -3,6 +3,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import get_lib
+from ._train import batch_norm_rows
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
                     require_device, run_blstm, run_head, use_hip_path)
 from .chimera import chimera
@@ -64,7 +65,7 @@ class phase_net(PackedWeightsMixin, nn.Module):
         for m in (mask_A, mask_B):
             inp = torch.cat((x_mag * m, x_phase.view(B, T, -1)), 2)
             r = self.rnn.autograd_forward(inp, self.training)
-            r = self.bn(r.reshape(-1, r.shape[-1])).reshape(r.shape)      # BatchNorm1d over (B*T, C) rows = over (B, C, T) without the two permuted copies
+            r = batch_norm_rows(self.bn, r)
             p = self.fc_phase(r).reshape(B, T, Fq, -1) + x_phase
             outs.append(F.normalize(p, p=2, dim=-1))
         return [embedding, mask_A, mask_B, outs[0], outs[1]]

@@ -731,3 +731,32 @@ def test_l2norm_rows_forward_and_gradient(lib, rows, D):
     ok = np.arange(rows) != 3
     np.testing.assert_allclose(dx[ok], xt.grad.numpy()[ok], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(dx[3], g[3] / np.float32(1e-12), rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,C", [(300, 40), (129, 7)])
+def test_bn_rows_train_forward_and_gradient(lib, M, C):
+    """onssen_bn_rows_train_f32 / _grad_f32 against nn.BatchNorm1d in training mode under float64 autograd, applied the
+    reference's way -- to the (B, C, T) permutation of the same rows (onssen/nn/deep_clustering.py:36-38)."""
+    import torch
+    rng = np.random.default_rng(12)
+    x = rand(rng, M, C) * 0.7 + 0.3
+    gamma, beta, g = rand(rng, C) + 1.5, rand(rng, C), rand(rng, M, C)
+    y, dx = np.full((M, C), np.nan, np.float32), np.full((M, C), np.nan, np.float32)
+    mean, invstd, dgamma, dbeta = (np.full(C, np.nan, np.float32) for _ in range(4))
+    ws = aligned_f32(lib.bn_rows_workspace_bytes(M, C) // 4 + 64)
+    lib.bn_rows_train(P(x), M, C, P(gamma), P(beta), 1e-5, P(y), P(mean), P(invstd), P(ws), ws.nbytes, None)
+    lib.bn_rows_grad(P(x), P(g), M, C, P(gamma), P(mean), P(invstd), P(dx), P(dgamma), P(dbeta), P(ws), ws.nbytes, None)
+    bn = torch.nn.BatchNorm1d(C).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(gamma)); bn.bias.copy_(torch.from_numpy(beta))
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    B = 3 if M % 3 == 0 else 1
+    yt = bn(xt.reshape(B, M // B, C).permute(0, 2, 1)).permute(0, 2, 1).reshape(M, C)
+    (yt * torch.from_numpy(g).double()).sum().backward()
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(mean, x.astype(np.float64).mean(0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(1 / invstd ** 2 - 1e-5, x.astype(np.float64).var(0), rtol=2e-5)
+    np.testing.assert_allclose(bn.running_var.numpy(), 0.9 + 0.1 * (1 / invstd.astype(np.float64) ** 2 - 1e-5) * M / (M - 1), rtol=2e-5)
+    np.testing.assert_allclose(dbeta, bn.bias.grad.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dgamma, bn.weight.grad.numpy(), rtol=2e-5, atol=5e-5)
+    assert np.abs(dx - xt.grad.numpy()).max() <= 3e-5 * max(np.abs(xt.grad.numpy()).max(), 1e-3)

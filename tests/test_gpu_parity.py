@@ -603,6 +603,50 @@ def test_xcd_placement_independent_protocol(dev, monkeypatch, B, T, H, L):
 
 
 @pytest.mark.gpu
+def test_train_mode_batch_norm_and_normalisation_on_device(dev, monkeypatch):
+    """Training-forward glue of deep_clustering (onssen/nn/deep_clustering.py:36-41): BatchNorm1d over the frames and F.normalize
+    of the embedding on the HIP kernels (batch_norm_rows, l2_normalize) against nn.BatchNorm1d on the permuted (B, C, T) view and
+    F.normalize under float64 autograd: outputs, running statistics after two batches, all gradients."""
+    from onssen_amd.nn._train import batch_norm_rows, l2_normalize
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    torch.manual_seed(2)
+    B, T, C, D = 4, 50, 1200, 20
+    bn = torch.nn.BatchNorm1d(C).to(dev).train()
+    ref = torch.nn.BatchNorm1d(C).double().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_()
+        ref.weight.copy_(bn.weight.cpu().double()); ref.bias.copy_(bn.bias.cpu().double())
+    for it in range(2):
+        x = torch.randn(B, T, C) * 0.5 + 0.1
+        g = torch.randn(B, T, C)
+        xg = x.to(dev).requires_grad_(True)
+        y = batch_norm_rows(bn, xg)
+        (y * g.to(dev)).sum().backward()
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr.permute(0, 2, 1)).permute(0, 2, 1)
+        (yr * g.double()).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=5e-6)
+        assert (xg.grad.cpu().double() - xr.grad).abs().max() <= 3e-5 * xr.grad.abs().max()
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=2e-5)
+    assert int(bn.num_batches_tracked) == 2
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=5e-5, atol=5e-4)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=5e-5, atol=5e-4)
+    # normalisation of (B, T*F, D) rows
+    e = torch.randn(B, T * 129, D); e[0, 5] = 0.0
+    ge = torch.randn(B, T * 129, D)
+    eg = e.to(dev).requires_grad_(True)
+    n = l2_normalize(eg)
+    (n * ge.to(dev)).sum().backward()
+    er = e.double().requires_grad_(True)
+    nr = torch.nn.functional.normalize(er, p=2, dim=-1)
+    (nr * ge.double()).sum().backward()
+    np.testing.assert_allclose(n.detach().cpu().numpy(), nr.detach().numpy(), rtol=2e-6, atol=1e-7)
+    ok = torch.ones(B, T * 129, dtype=torch.bool); ok[0, 5] = False
+    assert (eg.grad.cpu().double() - er.grad)[ok].abs().max() <= 2e-5 * er.grad[ok].abs().max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hip", ["1", "0"])
 def test_loss_dc_with_gradient_on_device(dev, golden_dir, monkeypatch, hip):
     """N1: loss_dc WITH a gradient on the device -- onssen_loss_dc_f32 + onssen_loss_dc_grad_f32 behind autograd (ONSSEN_LOSS_HIP=0:
