@@ -1,5 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py tests/test_config_surface.py -m gpu -q -x -k "train or grad or dropout or robust or loss or config or recipe or batch_norm" 2>&1 | tail -3
-for i in 1 2; do timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3', r.get('ms_per_step'), r.get('last_loss'))"; done
-timeout 200 python tools/train_step_bench.py --layers 2 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L2', r.get('ms_per_step'), r.get('last_loss'))"
+timeout 400 python tools/train_soak.py --steps 400 2>&1 | tail -1 | cut -c1-300
+timeout 300 python tools/xcd_soak.py 2>&1 | tail -2 | cut -c1-300
+for i in 1 2 3; do timeout 100 python bench.py --no-cpu-baseline --steps 200 | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['roofline']['us_per_time_step'], {k:v for k,v in r['config'].items() if 'status' in k or 'abort' in k or 'protocol' in k})"; done
