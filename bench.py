@@ -389,8 +389,9 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
            "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
            "peak_note": "dense bf16 MFMA 2500 TF" if bf16_only else "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
            "bound_note": "a serial chain of T dependent time steps: each is cell update -> tagged h stores -> L2 -> polled "
-                         "fragment loads -> MFMAs -> LDS reduction, bound by that chain's latency, not by MFMA issue or HBM "
-                         "-- see DESIGN.md",
+                         "fragment loads -> MFMAs -> LDS reduction; the exchange (every member reads all of h: 576 KB per step "
+                         "and XCD at B=32) streams at the XCD's L2 -> CU bandwidth (~0.5 KB per clock), the rest is that chain's "
+                         "latency -- not MFMA issue or HBM; see DESIGN.md section 3",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
            "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
