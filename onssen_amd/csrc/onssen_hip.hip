@@ -376,29 +376,45 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   hipStream_t st = (hipStream_t)stream;
-  // tile shape: 256 x 320 or 256 x 256 (linear_x3q_kernel, LDS-DMA staging) unless ONSSEN_X3Q=0 selects the round-1 kernel
-  // (256 x 160).  One workgroup per CU: the width that needs fewer (rounds of 256 workgroups) x (tile columns) wins;
-  // the L2NORM epilogue needs whole feature groups per wave (80 columns) and stays at 320.  ONSSEN_X3Q=320 / 256 forces one.
+  // tile shape (linear_x3q_kernel, LDS-DMA staging): 256 or 128 rows x 320 or 256 columns, unless ONSSEN_X3Q=0 selects the
+  // round-1 kernel (256 x 160).  One workgroup per CU: the shape with the smallest (rounds of 256 workgroups) x (tile area)
+  // wins, half-height tiles charged 15 % for their lower MFMA : fragment-read ratio; the L2NORM epilogue needs whole feature
+  // groups per wave (80 columns) and stays at 320 columns.  ONSSEN_X3Q=320 / 256 forces the width, ONSSEN_X3Q_BM=256 / 128 the height.
   const char* env_q = getenv("ONSSEN_X3Q");   // read per call: the tests switch it
-  const int use_q = env_q ? atoi(env_q) : 1;
-  if (use_q && (long)lxq::BM * KB * 128 <= 0x7fffffffL) {
-    const long mt = ceil_div(M, lxq::BM);
-    const long c320 = ceil_div(mt * ceil_div(N, 320), 256) * 320, c256 = ceil_div(mt * ceil_div(N, 256), 256) * 256;
-    const bool narrow = mode != ONSSEN_EPI_L2NORM && (use_q == 256 || (use_q != 320 && c256 < c320));
-    const dim3 gridq((unsigned)ceil_div(N, narrow ? 256 : 320), (unsigned)mt);
-#define ONSSEN_XQ(MODE_)                                                                                        \
-  do {                                                                                                          \
-    if (narrow && bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 1, false, 256>), gridq, dim3(512), 0, st, p); \
-    else if (narrow) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 3, false, 256>), gridq, dim3(512), 0, st, p);  \
-    else if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 1>), gridq, dim3(512), 0, st, p);           \
-    else hipLaunchKernelGGL((linear_x3q_kernel<MODE_, 3>), gridq, dim3(512), 0, st, p);                          \
+  const char* env_bm = getenv("ONSSEN_X3Q_BM");
+  const int use_q = env_q ? atoi(env_q) : 1, force_bm = env_bm ? atoi(env_bm) : 0;
+  if (use_q && (long)lxq::BM_MAX * KB * 128 <= 0x7fffffffL) {
+    int bm = 256, bn = 320;
+    double best = 1e30;
+    for (int cbm = 256; cbm >= 128; cbm -= 128)
+      for (int cbn = 320; cbn >= 256; cbn -= 64) {
+        if (cbn == 256 && (mode == ONSSEN_EPI_L2NORM || use_q == 320)) continue;
+        if (cbn == 320 && use_q == 256 && mode != ONSSEN_EPI_L2NORM) continue;
+        if (force_bm && cbm != force_bm) continue;
+        const double cost = (double)ceil_div((long)ceil_div(M, cbm) * ceil_div(N, cbn), 256) * cbm * cbn * (cbm == 128 ? 1.15 : 1.0);
+        if (cost < best) { best = cost; bm = cbm; bn = cbn; }
+      }
+    const dim3 gridq((unsigned)ceil_div(N, bn), (unsigned)ceil_div(M, bm));
+#define ONSSEN_XQ2(MODE_, T_)                                                                                            \
+  do {                                                                                                                   \
+    if (bm == 256 && bn == 320) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, T_, false, 320, 256>), gridq, dim3(512), 0, st, p);      \
+    else if (bm == 256) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, T_, false, 256, 256>), gridq, dim3(512), 0, st, p); \
+    else if (bn == 320) hipLaunchKernelGGL((linear_x3q_kernel<MODE_, T_, false, 320, 128>), gridq, dim3(512), 0, st, p); \
+    else hipLaunchKernelGGL((linear_x3q_kernel<MODE_, T_, false, 256, 128>), gridq, dim3(512), 0, st, p);                \
+  } while (0)
+#define ONSSEN_XQ(MODE_)                                     \
+  do {                                                       \
+    if (bf16_only) ONSSEN_XQ2(MODE_, 1); else ONSSEN_XQ2(MODE_, 3); \
   } while (0)
     if (mode == ONSSEN_EPI_BIAS) ONSSEN_XQ(ONSSEN_EPI_BIAS);
     else if (mode == ONSSEN_EPI_L2NORM) {
-      if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 1>), gridq, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 3>), gridq, dim3(512), 0, st, p);
+      if (bm == 256) { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 1, false, 320, 256>), gridq, dim3(512), 0, st, p);
+                       else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 3, false, 320, 256>), gridq, dim3(512), 0, st, p); }
+      else { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 1, false, 320, 128>), gridq, dim3(512), 0, st, p);
+             else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 3, false, 320, 128>), gridq, dim3(512), 0, st, p); }
     } else ONSSEN_XQ(ONSSEN_EPI_SIGMOID);
 #undef ONSSEN_XQ
+#undef ONSSEN_XQ2
     ONSSEN_LAUNCH_CHECK();
     return ONSSEN_OK;
   }

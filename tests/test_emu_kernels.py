@@ -239,11 +239,12 @@ def test_linear_split_bf16(lib, mode, group, K):
 
 @pytest.mark.parametrize("mode,group,K", [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40),
                                           (_abi.EPI_L2NORM, 40, 33)])
-@pytest.mark.parametrize("tile", ["0", "256", "320"])
+@pytest.mark.parametrize("tile", ["0", "256", "320", "256/128", "320/128"])     # kernel / width[/height] of the x3q tile
 def test_linear_x3_images(lib, mode, group, K, tile, monkeypatch):
     """onssen_x3_image_f32 + onssen_linear_x3p (pre-split operands; 256x160 register-staged tile, 256x256 / 256x320
     LDS-DMA tiles; register epilogue): ragged M/N/K, strided A rows and C rows, all epilogues."""
-    monkeypatch.setenv("ONSSEN_X3Q", tile)
+    monkeypatch.setenv("ONSSEN_X3Q", tile.split("/")[0])
+    monkeypatch.setenv("ONSSEN_X3Q_BM", tile.split("/")[1] if "/" in tile else "256")
     rng = np.random.default_rng(8)
     Bb, Tt, N = 3, 91, 440           # M = 273 (2 row blocks), N = 440 (3 / 2 / 2 column blocks, the last one ragged)
     x = rand(rng, Bb, Tt, K)
