@@ -409,7 +409,7 @@ def test_blstm_xcd_eight_wave_variant():
     assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3)])
+@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4)])     # the last one: D + C = 34, two tasks per thread
 def test_loss_dc_value(lib, B, TF, D, C):
     """onssen_loss_dc_f32 against the NumPy restatement of loss_dc (Frobenius norms of the weighted affinity blocks)."""
     rng = np.random.default_rng(5)
@@ -429,7 +429,7 @@ def test_loss_dc_value(lib, B, TF, D, C):
     np.testing.assert_allclose(per_utt, ref, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,TF,D,C", [(2, 300, 20, 2), (1, 700, 6, 3)])
+@pytest.mark.parametrize("B,TF,D,C", [(2, 300, 20, 2), (1, 700, 6, 3), (1, 200, 30, 4)])
 def test_loss_dc_gradient(lib, B, TF, D, C):
     """onssen_loss_dc_grad_f32 against float64 autograd through the LITERAL form of onssen/loss/loss_dc.py:24-44 (three products,
     Frobenius norms, detached weights), for an arbitrary upstream gradient per utterance."""
