@@ -2,17 +2,19 @@
 // include/onssen_hip.h.  See DESIGN.md for the data layouts and the per-kernel rooflines.
 //
 // Kernel inventory (one translation unit, the parts are the .inc files next to this one):
-//   fft.inc             stft_logmag_kernel (K1+K2: fp64 radix-4 FFT in LDS, one wavefront per frame, fused log10(|X|+eps)),
+//   fft.inc             stft_logmag_kernel (K1+K2: fp64 radix-4 FFT in LDS, one wavefront per PAIR of frames, fused log10(|X|+eps)),
 //                       mask_istft_kernel (K10: mask-apply + fp64 inverse FFT, two speakers per transform, gather overlap-add)
-//   gemm.inc            linear_x3p_kernel (K3/K7/K8/K9 on pre-split bf16 images: 256x160 tiles, 8 waves, register epilogues
+//   gemm.inc            linear_x3q_kernel (K3/K7/K8/K9 on pre-split bf16 images: 256|128 x 320|256 tiles staged by LDS-DMA into a swizzled
+//                       layout, 8 waves, register epilogues), linear_x3p_kernel (round-1 form: 256x160 tiles; batched weight gradients;
 //                       bias | sigmoid | grouped L2-norm), linear_x3_kernel / linear_kernel (fp32-A forms, exact-fp32 MFMA),
 //                       x3_image(_t)_kernel (fp32 -> split-bf16 operand images)
 //   lstm.inc            lstm_xcd_kernel (K4, default: XCD-local persistent recurrence, ONE launch per layer, data-tagged h
 //                       exchange through the XCD's L2), lstm_step_kernel (one launch per time step: fallback and f32 mode)
 //   lstm_bwd.inc        lstm_xcd_bwd_kernel / lstm_bwd_step_kernel (training: backward recurrence)
 //   labels_cluster.inc  labels_kernel (training labels), kmeans2_* (deep-clustering back end)
-//   loss_sdr.inc        loss_dc_* / loss_mask_* (loss values), sdr_* (batch SI-SDR with best permutation, fp64 sums)
-//   pack.inc            one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold)
+//   loss_sdr.inc        loss_dc_* (value and gradient) / loss_mask_* (value), sdr_* (batch SI-SDR with best permutation, fp64 sums)
+//   pack.inc            one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold); training glue: dropout,
+//                       row-wise L2 normalisation and train-mode BatchNorm with their backward passes
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 
