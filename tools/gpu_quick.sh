@@ -1,5 +1,4 @@
 #!/bin/bash
+# Scratch wrapper for one gpurun call while iterating (edit freely).
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "loss or train" 2>&1 | tail -2
-for i in 1 2; do timeout 200 python tools/train_step_bench.py --layers 3 2>&1 | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('L3', r.get('ms_per_step'), r.get('last_loss'))"; done
-timeout 100 python tools/train_op_profile.py 2>&1 | grep -E "loss_dc|l2norm|bn_rows|dropout_kernel" | cut -c1-60,150-330 | awk '{print $1, $2, $(NF-5), $(NF-4), $NF}'
+for v in "ONSSEN_X3Q_BM=128" "ONSSEN_X3Q=256" "ONSSEN_X3Q=0"; do echo "== $v"; env $v timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or cfg or linear or gemm or e2e or separ" 2>&1 | tail -2; done
