@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 6   /* 6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 7   /* 7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -72,6 +72,9 @@ extern "C" {
                                      projections, h W_hh^T) uses the bf16 hi halves only -- one MFMA instead of
                                      three, bf16-grade results (~1e-2 relative), outside the 1e-4 parity contract.
                                      Same images, same workspace; accumulation, gates and cell state stay fp32. */
+#define ONSSEN_BLSTM_G_READY 128     /* measurement aid (bench.py times the recurrence kernel by itself): skip the input
+                                       projection of every layer -- G is what an earlier call with the same arguments left
+                                       in the workspace (L = 1 calls only make sense) */
 /* Debug flags (0 in production).  Launch-per-step form only: bits 8..11 switch off parts of the kernel for profiling
  * ablations (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA, 0x800 G/c loads; 0x1000 selects
  * libm-grade gate non-linearities.  ONSSEN_BLSTM_XCD form: 0x800 = TEST bit, rotates the exchange groups across the XCDs
@@ -325,14 +328,22 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
  * per_utt[None,:] * total_mag[:,None] (loss_dc.py:44) and its mean (utils/train.py:78-79).
  *   emb (B, TF, D), one_hot (B, TF, C) as float, mag (B, TF); D + C <= 34.
  */
-/* Mask-inference term of the chimera losses (value only): out[b] = min over the two speaker assignments of
+/* Mask-inference term of the chimera losses: out[b] = min over the two speaker assignments of
  *   sum |mask_x * mag_mix - t_1| + sum |mask_y * mag_mix - t_2|,  t_s = mag_s (MSA: cos_* = NULL) or
  *   min(mag_mix, relu(mag_s * cos_s)) (PSA).  Replaces onssen/loss/loss_chimera.py:25-29 and :53-57.
- *   mask element (b, e) at mask_* + b*m_sb + e*m_se (the strided views of the (B,T,F,2) mask buffer); maps (B, TF). */
+ *   mask element (b, e) at mask_* + b*m_sb + e*m_se (the strided views of the (B,T,F,2) mask buffer); maps (B, TF).
+ *   perm_out (B) int32 or NULL: the assignment that won (0: A->1, B->2; 1: A->2, B->1; ties -> 0) -- what the gradient follows.
+ * onssen_loss_mask_grad_f32: d out[b] / d mask_{A,B} times the incoming gradient g[b], one pass over the maps:
+ *   d_mask_A[b,e] = g[b] * mag_mix * sign(mask_A * mag_mix - t_A)  (sign(0) = 0, like torch.abs' backward), t_A the target
+ *   `perm` gives speaker A; written at d_mask_* + b*d_sb + e*d_se (e.g. the two planes of one interleaved (B,TF,2) buffer). */
 size_t onssen_loss_mask_workspace_bytes(int B);
 int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
                          const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
-                         float* out, void* ws, size_t ws_bytes, void* stream);
+                         float* out, int32_t* perm_out, void* ws, size_t ws_bytes, void* stream);
+int onssen_loss_mask_grad_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
+                              const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
+                              const float* g, const int32_t* perm, float* d_mask_a, float* d_mask_b, int64_t d_sb, int64_t d_se,
+                              void* stream);
 size_t onssen_loss_dc_workspace_bytes(int B);
 int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
                        float* per_utt, float* total_mag, void* ws, size_t ws_bytes, void* stream);
@@ -370,6 +381,17 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
 /* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
  * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */
 int onssen_debug_launch_chain(float* scratch, int n, int workgroups, void* stream);
+
+/* Co-tenant probe (not part of the separation path; tools/cotenant_probe.py): `workgroups` x `threads` threads that only
+ * hold their compute units for `ticks` ticks of the 100 MHz wall clock on `stream` -- a stand-in for RCCL's channel
+ * kernels running beside the persistent recurrences (a recurrence group needs 30 of its XCD's 32 CUs at the same time). */
+int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, void* stream);
+
+/* Bound of every wait inside the persistent kernels (ONSSEN_BLSTM_XCD forward, training forward / backward), in polling
+ * passes: default 400000 (~0.2 s), initial value from ONSSEN_XCD_SPIN_LIMIT.  new_limit >= 0 sets it (0: every wait gives
+ * up at once -- abort-path tests; data-parallel training raises it, see onssen_amd/dist.py), new_limit < 0 only queries.
+ * Returns the previous value.  Process-wide; takes effect at the next launch. */
+long long onssen_xcd_spin_limit(long long new_limit);
 
 #ifdef __cplusplus
 }

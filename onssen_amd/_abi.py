@@ -9,13 +9,14 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 6
+ABI_VERSION = 7
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
 BLSTM_FUSE_IN0 = 16
 BLSTM_FUSE_TAIL = 32
 BLSTM_BF16 = 64
+BLSTM_G_READY = 128
 LSTM_BWD_STEPS, LSTM_BWD_XCD = 0, 1
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
@@ -60,10 +61,13 @@ SIGNATURES = {
     "onssen_l2norm_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
+    "onssen_debug_cotenant_spin": (_i, [_i, _i, C.c_longlong, _vp]),
+    "onssen_xcd_spin_limit": (C.c_longlong, [C.c_longlong]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
     "onssen_loss_mask_workspace_bytes": (_sz, [_i]),
-    "onssen_loss_mask_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "onssen_loss_mask_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_loss_mask_grad_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "onssen_loss_dc_workspace_bytes": (_sz, [_i]),
     "onssen_batch_sdr_workspace_bytes": (_sz, [_i]),
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -122,9 +126,13 @@ class Lib:
     def loss_mask_workspace_bytes(self, B):
         return int(self.dll.onssen_loss_mask_workspace_bytes(B))
 
-    def loss_mask(self, ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, ws, ws_bytes, stream):
-        self.check(self.dll.onssen_loss_mask_f32(ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, ws, ws_bytes, stream),
+    def loss_mask(self, ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, ws, ws_bytes, stream, perm=None):
+        self.check(self.dll.onssen_loss_mask_f32(ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, out, perm, ws, ws_bytes, stream),
                    "onssen_loss_mask_f32")
+
+    def loss_mask_grad(self, ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, g, perm, da, db, d_sb, d_se, stream):
+        self.check(self.dll.onssen_loss_mask_grad_f32(ma, mb, m_sb, m_se, mag, s1, s2, c1, c2, B, TF, g, perm, da, db, d_sb, d_se,
+                                                      stream), "onssen_loss_mask_grad_f32")
 
     def loss_dc_workspace_bytes(self, B):
         return int(self.dll.onssen_loss_dc_workspace_bytes(B))

@@ -68,6 +68,13 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
   } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// Experiment / ablation switches exist only in builds made with -DONSSEN_DEBUG_KNOBS (tools/ab_variants.py): the product
+// library reads no environment variable for them and carries their defaults as constants.
+#ifdef ONSSEN_DEBUG_KNOBS
+#define ONSSEN_KNOB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define ONSSEN_KNOB_INT(name, dflt) (dflt)
+#endif
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device code, one translation unit (the host-side emulation compiles exactly this file too)
@@ -79,10 +86,40 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #include "fft.inc"
 #include "loss_sdr.inc"
 
+// Bounded waits of the persistent kernels: ~0.2 s of polling on the GPU by default.  A run-time setting of the library
+// (onssen_xcd_spin_limit), initialised from ONSSEN_XCD_SPIN_LIMIT: the host-side emulation -- where a 'workgroup' is a
+// process at the mercy of the OS scheduler -- and data-parallel training -- where a co-tenant RCCL kernel may hold CUs
+// while it waits for a slower rank -- raise it; 0 makes every wait give up at once (abort-path tests).
+static unsigned& xcd_spin_limit() {
+  static unsigned v = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
+  return v;
+}
+
+// Co-tenant probe (tools/cotenant_probe.py): `workgroups` workgroups of `threads` threads that do nothing but hold their
+// CU for `ticks` ticks of the 100 MHz wall clock -- a stand-in for RCCL's channel kernels next to the persistent recurrences.
+__global__ void cotenant_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (long long i = 0; i < ticks && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(32);   // (bounded by count too)
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
 extern "C" {
+
+long long onssen_xcd_spin_limit(long long new_limit) {
+  const long long old = (long long)xcd_spin_limit();
+  if (new_limit >= 0) xcd_spin_limit() = new_limit > 0xffffffffLL ? 0xffffffffu : (unsigned)new_limit;
+  return old;
+}
+
+int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, void* stream) {
+  if (workgroups <= 0 || threads <= 0 || threads > 1024 || ticks < 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(cotenant_spin_kernel, dim3((unsigned)workgroups), dim3((unsigned)threads), 0, (hipStream_t)stream, ticks);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
 
 int onssen_debug_launch_chain(float* scratch, int n, int workgroups, void* stream) {
   if (!scratch || n <= 0 || workgroups <= 0) return ONSSEN_E_ARG;
@@ -266,14 +303,14 @@ int onssen_linear_bf16x3(const float* A, int64_t a_s0, int64_t a_s1, int R, int 
   p.A = A; p.a_s0 = (long)a_s0; p.a_s1 = (long)a_s1; p.Whi = w_planes; p.Wlo = w_planes + (size_t)N * ldw;
   p.bias = bias; p.resid = resid; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.K = K; p.ldw = ldw; p.group = group; p.eps = eps;
-  static const int x3_ablate = getenv("ONSSEN_X3_ABLATE") ? atoi(getenv("ONSSEN_X3_ABLATE")) : 0;
+  static const int x3_ablate = ONSSEN_KNOB_INT("ONSSEN_X3_ABLATE", 0);
   p.ablate = x3_ablate;
-  static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
+  static const int x3_gn = ONSSEN_KNOB_INT("ONSSEN_X3_GN", 4);
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   const bool a_vec = aligned16(A) && (a_s0 % 4) == 0 && (a_s1 % 4) == 0 && (K % 4) == 0;
   // tile height: 256 rows x 1 workgroup per CU (default), or 128 rows x 2 co-resident (ONSSEN_X3_WM=2)
-  static const int wm_env = getenv("ONSSEN_X3_WM") ? atoi(getenv("ONSSEN_X3_WM")) : 0;
+  static const int wm_env = ONSSEN_KNOB_INT("ONSSEN_X3_WM", 0);
   const int wmv = wm_env == 2 ? 2 : 4;   // measured: the 256-row tile re-reads W half as often and wins end to end
   const dim3 grid((unsigned)ceil_div(N, lx3::BN), (unsigned)ceil_div(M, 64 * wmv)), block(128 * wmv);
   hipStream_t st = (hipStream_t)stream;
@@ -374,7 +411,7 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   p.KB = KB; p.group = group; p.eps = eps;
   p.a_bs = p.w_bs = p.c_bs = 0;
   p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
-  static const int x3_gn = getenv("ONSSEN_X3_GN") ? atoi(getenv("ONSSEN_X3_GN")) : 4;
+  static const int x3_gn = ONSSEN_KNOB_INT("ONSSEN_X3_GN", 4);
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   hipStream_t st = (hipStream_t)stream;
@@ -420,7 +457,7 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
     ONSSEN_LAUNCH_CHECK();
     return ONSSEN_OK;
   }
-  static const int xp_wms = getenv("ONSSEN_X3P_WAVES") && atoi(getenv("ONSSEN_X3P_WAVES")) == 4 ? 2 : 4;   // 8 waves unless =4
+  static const int xp_wms = ONSSEN_KNOB_INT("ONSSEN_X3P_WAVES", 8) == 4 ? 2 : 4;   // 8 waves unless =4
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM)), block(128 * xp_wms);
 #define ONSSEN_XP(MODE_)                                                                                       \
   do {                                                                                                         \
@@ -505,7 +542,7 @@ size_t onssen_loss_mask_workspace_bytes(int B) { return B > 0 ? (size_t)B * 32 *
 
 int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
                          const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
-                         float* out, void* ws, size_t ws_bytes, void* stream) {
+                         float* out, int32_t* perm_out, void* ws, size_t ws_bytes, void* stream) {
   if (!mask_a || !mask_b || !mag_mix || !mag_s1 || !mag_s2 || !out || !ws || B <= 0 || TF <= 0 ||
       ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
     return ONSSEN_E_ARG;
@@ -514,7 +551,23 @@ int onssen_loss_mask_f32(const float* mask_a, const float* mask_b, int64_t m_sb,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_mask_kernel, dim3(32, (unsigned)B), dim3(256), 0, st, mask_a, mask_b, (long)m_sb, (long)m_se, mag_mix,
                      mag_s1, mag_s2, cos_s1, cos_s2, TF, (float*)ws);
-  hipLaunchKernelGGL(loss_mask_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)ws, 32, out);
+  hipLaunchKernelGGL(loss_mask_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const float*)ws, 32, out, (int*)perm_out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_loss_mask_grad_f32(const float* mask_a, const float* mask_b, int64_t m_sb, int64_t m_se, const float* mag_mix,
+                              const float* mag_s1, const float* mag_s2, const float* cos_s1, const float* cos_s2, int B, int TF,
+                              const float* g, const int32_t* perm, float* d_mask_a, float* d_mask_b, int64_t d_sb, int64_t d_se,
+                              void* stream) {
+  if (!mask_a || !mask_b || !mag_mix || !mag_s1 || !mag_s2 || !g || !perm || !d_mask_a || !d_mask_b || B <= 0 || TF <= 0 ||
+      ((cos_s1 == nullptr) != (cos_s2 == nullptr)))
+    return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const int nblk = ceil_div(TF, 256) < 64 ? ceil_div(TF, 256) : 64;
+  hipLaunchKernelGGL(loss_mask_grad_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, mask_a, mask_b,
+                     (long)m_sb, (long)m_se, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, TF, g, (const int*)perm, d_mask_a, d_mask_b,
+                     (long)d_sb, (long)d_se);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -612,7 +665,9 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     const bool fuse0 = images && l == 0 && (flags & ONSSEN_BLSTM_FUSE_IN0);
     // the fused projection keeps <= 4 k-chunks of W_ih fragments in the LDS: in_dim <= 128, or 32k + 1 <= 129 with FUSE_TAIL
     if (fuse0 && !(in_dim <= 128 || (in_dim == 129 && (flags & ONSSEN_BLSTM_FUSE_TAIL)))) return ONSSEN_E_ARG;
-    if (images) {
+    if ((flags & ONSSEN_BLSTM_G_READY) && !fuse0) {
+      rc = ONSSEN_OK;              // profiling: G of this layer is what an earlier call left in the workspace
+    } else if (images) {
       const uint16_t* a_img = l == 0 ? img_x : img_ab[(L - l) % 2];   // layer l-1 wrote buffer (L-1-(l-1)) % 2
       if (l == 0) {
         rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
@@ -640,7 +695,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
       // bounded waits: ~0.2 s of polling on the GPU; ONSSEN_XCD_SPIN_LIMIT overrides (the host-side emulation, where a
       // 'workgroup' is a process at the mercy of the OS scheduler, raises it)
-      static const unsigned xcd_spin = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
+      const unsigned xcd_spin = xcd_spin_limit();
       XcdArgs xa;
       // fp32 rows only where somebody reads them (the caller's y); every layer leaves its x3 image
       xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = l == L - 1 ? y : nullptr; xa.hx = hsb; xa.sync = syncw; xa.B = B;
@@ -656,7 +711,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       xa.save_g = save_g; xa.save_c = save_c;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup (K is split over them): 8 = two per SIMD; ONSSEN_XCD_WAVES=4 keeps the one-per-SIMD form for comparison
-      static const int xcd_nw = getenv("ONSSEN_XCD_WAVES") && atoi(getenv("ONSSEN_XCD_WAVES")) == 4 ? 4 : 8;
+      static const int xcd_nw = ONSSEN_KNOB_INT("ONSSEN_XCD_WAVES", 8) == 4 ? 4 : 8;
       switch (ug) {
         case 4: rc = launch_xcd<1>(xa, xcd_nw, st); break;
         case 8: rc = launch_xcd<2>(xa, xcd_nw, st); break;
@@ -759,7 +814,7 @@ int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out
 
 static int bwd_rows_per_group(int B) {
   int rg = B <= 16 ? 4 : B <= 32 ? 8 : 16;
-  static const int rg_env = getenv("ONSSEN_XCD_RG") ? atoi(getenv("ONSSEN_XCD_RG")) : 0;
+  static const int rg_env = ONSSEN_KNOB_INT("ONSSEN_XCD_RG", 0);
   if (rg_env == 4 || rg_env == 8 || rg_env == 16) rg = rg_env;
   return rg;
 }
@@ -786,16 +841,16 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   if (form == ONSSEN_LSTM_BWD_XCD) {
     if (Hp / ug > 32 || NUB > 40) return ONSSEN_E_ARG;
-    static const unsigned xcd_spin = getenv("ONSSEN_XCD_SPIN_LIMIT") ? (unsigned)strtoul(getenv("ONSSEN_XCD_SPIN_LIMIT"), nullptr, 10) : 400000u;
-    static const int ablate_env = getenv("ONSSEN_BWD_ABLATE") ? atoi(getenv("ONSSEN_BWD_ABLATE")) : 0;
-    static const int delay_env = getenv("ONSSEN_BWD_DELAY") ? atoi(getenv("ONSSEN_BWD_DELAY")) : 0;
+    const unsigned xcd_spin = xcd_spin_limit();
+    static const int ablate_env = ONSSEN_KNOB_INT("ONSSEN_BWD_ABLATE", 0);
+    static const int delay_env = ONSSEN_KNOB_INT("ONSSEN_BWD_DELAY", 0);
     XcdBwdArgs xa;
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
     xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
     xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env; xa.db_rows = db_rows;
     // ONSSEN_XCD_PROFILE builds only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
-    static const bool dbg_env = getenv("ONSSEN_BWD_DBG") != nullptr;
+    static const bool dbg_env = ONSSEN_KNOB_INT("ONSSEN_BWD_DBG", 0) != 0;
     xa.dbg = dbg_env && ws_bytes >= onssen_lstm_train_backward_workspace_bytes(B, H, ug, form) + (size_t)T * 64
                  ? (long long*)((char*)ws + onssen_lstm_train_backward_workspace_bytes(B, H, ug, form)) : nullptr;
     ONSSEN_CLEAR_ERROR();

@@ -1,7 +1,10 @@
 """``onssen.data`` counterpart: ``wsj0_2mix_dataloader`` with the reference's call signature (onssen/data/wsj0_2mix.py:26-37).
-With a ``data_path`` that holds ``wav8k/min/<partition>/mix/*.wav`` it reads the files (``wsj0_2mix.Wsj02mixFiles``); without
-one (there is no corpus in the build image) it synthesises utterances (``synthetic_wsj0_2mix.SyntheticWsj02mix``).  Either way
-the features and labels are computed on the GPU and the yield contract is the reference's."""
+With a ``data_path`` that holds ``wav8k/min/<partition>/mix/*.wav`` it reads the files (``wsj0_2mix.Wsj02mixFiles``).  The
+synthetic corpus (``synthetic_wsj0_2mix.SyntheticWsj02mix``; there is no WSJ0 in the build image) is used only when it is ASKED
+for: ``data_path`` absent / ``None`` / ``""`` / ``"synthetic"``, or ``ONSSEN_SYNTHETIC_DATA=1`` in the environment (recipe configs
+carry the author's corpus path).  A ``data_path`` that is given but holds no files for the partition raises ``FileNotFoundError``
+like the reference's empty dataset would fail -- numbers must never come from synthetic mixtures by accident.  Either way the
+features and labels are computed on the GPU and the yield contract is the reference's."""
 import glob
 import os
 
@@ -12,9 +15,15 @@ from .wsj0_2mix import Wsj02mixFiles, read_wav, write_wav
 def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
     fo = feature_options
     path = fo.get("data_path") if isinstance(fo, dict) else getattr(fo, "data_path", None)
-    if path and glob.glob(os.path.join(path, "wav8k", "min", partition, "mix", "*.wav")):
+    if not path or path == "synthetic":
+        return SyntheticWsj02mix(model_name, feature_options, partition, device)
+    pattern = os.path.join(path, "wav8k", "min", partition, "mix", "*.wav")
+    if glob.glob(pattern):
         return Wsj02mixFiles(model_name, feature_options, partition, device)
-    return SyntheticWsj02mix(model_name, feature_options, partition, device)
+    if os.environ.get("ONSSEN_SYNTHETIC_DATA", "0") not in ("", "0"):
+        return SyntheticWsj02mix(model_name, feature_options, partition, device)
+    raise FileNotFoundError(f"wsj0_2mix_dataloader: no files match {pattern!r} (data_path is set but holds nothing for partition "
+                            f"{partition!r}); pass data_path='' / 'synthetic' or set ONSSEN_SYNTHETIC_DATA=1 for the synthetic corpus")
 
 
 __all__ = ["wsj0_2mix_dataloader", "SyntheticWsj02mix", "Wsj02mixFiles", "read_wav", "write_wav"]

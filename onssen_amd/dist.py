@@ -90,7 +90,12 @@ class GradientReducer:
         gradient tensors to ``layer_hook`` as soon as that layer's contractions are queued -- the reduce of layer l then
         runs on RCCL's stream under the backward recurrence of layer l-1 -- and collects them, averaged in place, before
         it returns them to autograd.
-    ``finish()`` (before clipping) waits for what is still in flight and writes the averages into ``p.grad``.
+    ``finish()`` (before clipping) waits for what is still in flight and writes the averages into ``p.grad``; a bucket that
+    never became complete -- some parameter of it took no part in this loss (chimera trained with ``loss_dc`` only leaves
+    ``fc_mi`` without a gradient) -- is reduced there, over the parameters that DO have a gradient, as
+    ``allreduce_gradients`` does: the autograd graph is the same on every rank, so every rank issues the same
+    collectives in the same order and replicas cannot drift apart silently.  The hooks act only between ``begin()`` and
+    ``finish()``: a backward outside ``train_step`` issues nothing.
     ``issued_in_backward`` counts the buckets issued before ``finish()`` was called -- the tests assert on it."""
 
     def __init__(self, model, world, group=None):
@@ -99,6 +104,8 @@ class GradientReducer:
         self.pending, self.layer_pending = [], []
         self.issued_in_backward = 0
         self._count = [0] * len(self.buckets)
+        self._done = [False] * len(self.buckets)
+        self._active = False
         self._handles = []
         if world > 1:
             for bi, ps in enumerate(self.buckets):
@@ -112,8 +119,10 @@ class GradientReducer:
 
     def begin(self):
         self._count = [0] * len(self.buckets)
+        self._done = [False] * len(self.buckets)
         self.pending, self.layer_pending = [], []
         self.issued_in_backward = 0
+        self._active = True
 
     def _issue(self, tensors):
         flat = torch.cat([t.reshape(-1) for t in tensors])
@@ -122,9 +131,12 @@ class GradientReducer:
         return work, flat, tensors
 
     def _ready(self, bi):
+        if not self._active:                  # a backward outside begin() .. finish(): nobody would wait for the reduce
+            return
         self._count[bi] += 1
         ps = [p for p in self.buckets[bi] if p.requires_grad]
         if self._count[bi] == len(ps):
+            self._done[bi] = True
             if any(getattr(p, "_onssen_reduced", False) for p in ps):     # reduced inside the HIP backward already
                 for p in ps:
                     p._onssen_reduced = False
@@ -150,7 +162,19 @@ class GradientReducer:
 
     def finish(self):
         issued = self.issued_in_backward
+        self._active = False
         self.layer_collect()
+        # buckets that never completed (a parameter without a gradient in this loss): reduce what exists, in bucket order
+        for bi, ps in enumerate(self.buckets):
+            if self._done[bi]:
+                continue
+            if any(getattr(p, "_onssen_reduced", False) for p in ps):     # this layer went through layer_hook
+                for p in ps:
+                    p._onssen_reduced = False
+                continue
+            grads = [p.grad for p in ps if p.requires_grad and p.grad is not None]
+            if grads:
+                self.pending.append(self._issue(grads))
         for work, flat, tensors in self.pending:
             work.wait()
             flat.div_(self.world)
@@ -172,17 +196,46 @@ def _reducer_for(model, world, group):
     return r
 
 
-def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, clip_norm=5.0):
-    """One optimizer step in the order of onssen/utils/train.py:75-86 with the data-parallel
-    exchange inserted before gradient clipping (issued bucket by bucket DURING backward, see GradientReducer).
-    Returns the local mean loss (float).  If a persistent recurrence launch of this step's forward or backward
-    aborted, the exception is raised BEFORE the optimizer step: the weights stay untouched."""
+# ---- RCCL next to the persistent recurrences ---------------------------------------------------------------------------
+# A recurrence exchange group needs 30 of its XCD's 32 CUs resident at the same time; GradientReducer
+# runs RCCL's all-reduces UNDER the backward recurrence of the layer below.  RCCL launches one workgroup per channel and
+# the dispatcher deals workgroups round-robin over the 8 XCDs, so <= 16 channels = <= 2 workgroups per XCD = the 2 spare
+# CUs, whichever of the two kernels arrives first (measured with a spinning co-tenant: profiles/r03_cotenant_probe.txt).
+RCCL_MAX_CHANNELS = 16
+# A co-tenant that holds more (or a rank that waits inside an all-reduce for a slower peer while its CUs are held) only
+# DELAYS the recurrence's start-up barrier; the bounded wait must outlast ordinary rank skew: ~4 s instead of ~0.2 s.
+TRAIN_SPIN_LIMIT = 8_000_000
+
+
+def configure_rccl(max_channels=RCCL_MAX_CHANNELS):
+    """Cap RCCL's channel count BEFORE the first communicator exists (``NCCL_MAX_NCHANNELS`` / ``NCCL_MIN_NCHANNELS``; an
+    explicit setting in the environment wins).  Called by ``init_process_group``."""
+    import os
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max_channels))
+    if int(os.environ.get("NCCL_MIN_NCHANNELS", "1")) > int(os.environ["NCCL_MAX_NCHANNELS"]):
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"]
+    return int(os.environ["NCCL_MAX_NCHANNELS"])
+
+
+def init_process_group(backend="nccl", **kwargs):
+    """``torch.distributed.init_process_group`` for this package's training loop: one process per GPU over RCCL
+    (backend "nccl" IS RCCL on ROCm), with RCCL's CU budget capped so that its kernels fit beside the persistent
+    recurrences (``configure_rccl``) and the recurrences' bounded waits raised to outlast rank skew."""
+    if backend == "nccl":
+        configure_rccl()
+    dist.init_process_group(backend, **kwargs)
+    if backend == "nccl" and torch.cuda.is_available():
+        from .hip import get_lib
+        lib = get_lib()
+        if lib.dll.onssen_xcd_spin_limit(-1) < TRAIN_SPIN_LIMIT:
+            lib.dll.onssen_xcd_spin_limit(TRAIN_SPIN_LIMIT)
+
+
+def _forward_backward(model, optimizer, loss_fn, input, label, reducer):
     from .nn import _train
-    from .nn._core import _XcdStatus
     output = model(input)
     loss_avg = torch.mean(loss_fn(output, label))
     optimizer.zero_grad()
-    reducer = _reducer_for(model, world, group) if world > 1 else None
     if reducer is not None:
         reducer.begin()
     _train.LAYER_GRAD_REDUCER[0] = reducer
@@ -192,8 +245,52 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
         _train.LAYER_GRAD_REDUCER[0] = None
     if reducer is not None:
         reducer.finish()
-    if input[0].is_cuda:
-        _XcdStatus.flush()            # aborted exchange / non-finite activations: raise here, not after the update
+    return loss_avg
+
+
+def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, clip_norm=5.0):
+    """One optimizer step in the order of onssen/utils/train.py:75-86 with the data-parallel
+    exchange inserted before gradient clipping (issued bucket by bucket DURING backward, see GradientReducer).
+    Returns the local mean loss (float).
+
+    An aborted persistent recurrence launch (forward or backward; ``nn/_core._XcdPolicy``) never reaches the weights: the
+    status words are examined BEFORE the optimizer step; with ``world > 1`` the ranks agree on "somebody aborted" through a
+    one-element MAX all-reduce (an aborted rank's garbage is already inside everybody's averaged gradients), and then EVERY
+    rank runs forward / backward / exchange again -- the rank that aborted on the ATen LSTM -- so the collectives stay
+    matched.  BatchNorm's running statistics are put back before the re-run; the persistent form stays enabled for the
+    next step.  Non-finite activations still raise."""
+    from .nn._core import XcdAborted, _XcdPolicy, _XcdStatus
+    reducer = _reducer_for(model, world, group) if world > 1 else None
+    if reducer is None and getattr(model, "_onssen_reducer", None) is not None:     # left over from a world > 1 step
+        model._onssen_reducer.close()
+        object.__setattr__(model, "_onssen_reducer", None)
+    on_gpu = input[0].is_cuda
+    bufs = [b.detach().clone() for b in model.buffers()] if on_gpu and model.training else None
+    loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+    aborted = None
+    if on_gpu:
+        try:
+            _XcdStatus.flush()        # aborted exchange / non-finite activations: examined here, not after the update
+        except XcdAborted as e:
+            aborted = e
+    any_aborted = aborted is not None
+    if world > 1 and on_gpu:
+        flag = torch.tensor([1.0 if any_aborted else 0.0], device=input[0].device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        any_aborted = bool(flag.item() > 0)
+    if any_aborted:
+        import contextlib
+        import warnings
+        _XcdPolicy.recovered += 1
+        warnings.warn(f"onssen_amd.train_step: {aborted or 'a persistent recurrence aborted on another rank'}  "
+                      "Re-running forward / backward of this step" + (" on the ATen LSTM." if aborted else "."), RuntimeWarning)
+        if bufs is not None:
+            with torch.no_grad():
+                for b, old in zip(model.buffers(), bufs):
+                    b.copy_(old)
+        with (_XcdPolicy.forced_steps() if aborted is not None else contextlib.nullcontext()):
+            loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+        _XcdStatus.flush()            # a second abort (only possible on a rank that did not abort the first time) raises
     torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return float(loss_avg.item())

@@ -53,15 +53,21 @@ class tester:
         raise NotImplementedError
 
     def eval(self):
-        from .nn._core import _XcdStatus
+        from .nn._core import _XcdStatus, recovering
         total, count = 0.0, 0
         self.model = self.model.eval()
+
+        @recovering                      # an aborted persistent recurrence: this utterance is run again, launch per step
+        def one(input, label):
+            output = self.model(input)
+            sig_est, sig_ref = self.get_est_sig(input, label, output)
+            sdr = batch_SDR_torch(sig_est, sig_ref)
+            _XcdStatus.flush()
+            return sdr
+
         with torch.no_grad():
             for input, label in self.test_loader:
-                output = self.model(input)
-                sig_est, sig_ref = self.get_est_sig(input, label, output)
-                sdr = batch_SDR_torch(sig_est, sig_ref)
-                _XcdStatus.flush()
+                sdr = one(input, label)
                 total += float(sdr.sum())
                 count += sdr.numel()
         return total / max(count, 1)

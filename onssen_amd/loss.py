@@ -1,6 +1,8 @@
 """Training losses needed by the data-parallel step.
 
-On a GPU the value comes from ``onssen_loss_dc_f32`` (one pass over the embedding builds the Gram of ``[V | Y]``) and, when
+Chimera losses (onssen/loss/loss_chimera.py): the deep-clustering term as below, the mask-inference term on
+``onssen_loss_mask_f32`` (value; the winning speaker assignment) and ``onssen_loss_mask_grad_f32`` (gradient, one pass).
+On a GPU the loss_dc value comes from ``onssen_loss_dc_f32`` (one pass over the embedding builds the Gram of ``[V | Y]``) and, when
 autograd needs it, the gradient from ``onssen_loss_dc_grad_f32`` (``dV = Z M`` from the same Gram: one more pass); on the CPU
 (tests, the gloo path) PyTorch ops with the same single-Gram forward and analytic backward.  ``ONSSEN_LOSS_HIP=0`` keeps the
 PyTorch form on the GPU.
@@ -160,6 +162,67 @@ def _no_grad_needed(*ts):
     return not (torch.is_grad_enabled() and any(t.requires_grad for t in ts))
 
 
+class _MaskTermHip(torch.autograd.Function):
+    """The mask-inference term with its gradient on the device: ``onssen_loss_mask_f32`` picks the better
+    speaker assignment per utterance in the forward pass, ``onssen_loss_mask_grad_f32`` writes d/d(mask_A, mask_B) in one pass
+    over the maps.  ``masks`` is the interleaved (B, ..., 2) buffer both mask views come from (targets carry no gradient,
+    like upstream's labels)."""
+
+    @staticmethod
+    def forward(ctx, masks, mag, s1, s2, c1, c2):
+        from .hip import get_lib
+        lib = get_lib()
+        B = mag.shape[0]
+        TF = mag[0].numel()
+        out = torch.empty(B, device=mag.device, dtype=torch.float32)
+        perm = torch.empty(B, device=mag.device, dtype=torch.int32)
+        ws = torch.empty(lib.loss_mask_workspace_bytes(B), dtype=torch.uint8, device=mag.device)
+        p = masks.data_ptr()
+        lib.loss_mask(p, p + 4, 2 * TF, 2, mag.data_ptr(), s1.data_ptr(), s2.data_ptr(),
+                      c1.data_ptr() if c1 is not None else None, c2.data_ptr() if c2 is not None else None, B, TF,
+                      out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream, perm=perm.data_ptr())
+        ctx.save_for_backward(masks, mag, s1, s2, perm, *([c1, c2] if c1 is not None else []))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .hip import get_lib
+        masks, mag, s1, s2, perm, *cs = ctx.saved_tensors
+        c1, c2 = cs if cs else (None, None)
+        B = mag.shape[0]
+        TF = mag[0].numel()
+        d = torch.empty_like(masks)
+        g = g.float().contiguous()
+        p, q = masks.data_ptr(), d.data_ptr()
+        get_lib().loss_mask_grad(p, p + 4, 2 * TF, 2, mag.data_ptr(), s1.data_ptr(), s2.data_ptr(),
+                                 c1.data_ptr() if c1 is not None else None, c2.data_ptr() if c2 is not None else None, B, TF,
+                                 g.data_ptr(), perm.data_ptr(), q, q + 4, 2 * TF, 2, torch.cuda.current_stream().cuda_stream)
+        return d, None, None, None, None, None
+
+
+def _mask_term_hip_autograd(mask_A, mask_B, mag_mix, s1, s2, c1=None, c2=None):
+    """Mask term WITH a gradient on the HIP kernels.  The network's two masks are strided views of one (B,T,F,2) buffer
+    (onssen/nn/chimera.py:42-45): the Function is applied to that buffer itself (the autograd graph runs through the root
+    tensor, not through two select views whose gradients would be scattered into zeros and added); anything else is
+    interleaved by torch.stack first."""
+    base = getattr(mask_A, "_base", None)
+    dense, acc = [], 2                              # strides of a map whose elements are 2 apart in a contiguous buffer
+    for n_i in reversed(mask_A.shape):
+        dense.insert(0, acc)
+        acc *= n_i
+    if not (base is not None and getattr(mask_B, "_base", None) is base and base.dtype == torch.float32 and base.is_contiguous()
+            and base.numel() == 2 * mask_A.numel() and mask_A.stride() == mask_B.stride() == tuple(dense)
+            and mask_A.storage_offset() == base.storage_offset() and mask_B.storage_offset() == base.storage_offset() + 1):
+        base = torch.stack([mask_A.float(), mask_B.float()], -1)
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    return _MaskTermHip.apply(base, f32(mag_mix), f32(s1), f32(s2), f32(c1), f32(c2))
+
+
+def _use_hip_mask_grad(mask_A):
+    return mask_A.is_cuda and os.environ.get("ONSSEN_LOSS_HIP", "1") == "1"
+
+
 def loss_chimera_msa(output, label):
     """onssen/loss/loss_chimera.py:6-31: 0.975 * loss_dc + 0.025 * magnitude-spectrum-approximation mask loss with the
     better of the two speaker assignments ((B,B) like loss_dc, as upstream)."""
@@ -168,6 +231,8 @@ def loss_chimera_msa(output, label):
     le = loss_dc([embedding], [one_hot, mag_mix])
     if mask_A.is_cuda and _no_grad_needed(mask_A, mask_B):
         lm = _mask_term_hip(mask_A, mask_B, mag_mix, mag_s1, mag_s2)
+    elif _use_hip_mask_grad(mask_A):
+        lm = _mask_term_hip_autograd(mask_A, mask_B, mag_mix, mag_s1, mag_s2)
     else:
         lm = _mask_term(mask_A, mask_B, mag_mix, mag_s1, mag_s2)
     return le * 0.975 + lm * 0.025
@@ -180,6 +245,8 @@ def loss_chimera_psa(output, label):
     le = loss_dc([embedding], [one_hot, mag_mix])
     if mask_A.is_cuda and _no_grad_needed(mask_A, mask_B):
         lm = _mask_term_hip(mask_A, mask_B, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2)
+    elif _use_hip_mask_grad(mask_A):
+        lm = _mask_term_hip_autograd(mask_A, mask_B, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2)
     else:
         t1 = torch.min(mag_mix, torch.relu(mag_s1 * cos_s1))
         t2 = torch.min(mag_mix, torch.relu(mag_s2 * cos_s2))

@@ -37,29 +37,83 @@ def _split_bf16():
     return precision() in ("bf16x3", "bf16")
 
 
-_XCD_DISABLED = [False]      # set when a persistent launch reported an aborted exchange
+class XcdAborted(_abi.OnssenError):
+    """A bounded wait of a persistent recurrence launch gave up: the outputs (and, in training, the gradients) of the call
+    that contained it are invalid.  ``separation.separate_*``, ``evaluate.tester.eval`` and ``dist.train_step`` catch it and
+    re-run that call on the launch-per-step / ATen recurrence (``_XcdPolicy``); a bare ``model(x)`` raises it."""
 
 
-def recurrence_plan(B, H):
-    """(ug, flags) for onssen_blstm_forward_f32.
+class _XcdPolicy:
+    """What happens after an aborted persistent launch (a co-tenant kernel held more than the 2 spare CUs of an XCD for
+    longer than the bounded wait, two persistent launches overlapped, ...): the abort is *per launch*, not a property of
+    the process, so the persistent form stays enabled --
 
-    Split-bf16 precision and H <= 640: the XCD-local persistent recurrence (one launch per layer, every
-    (direction, 16-row group) inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)).  Otherwise one
-    launch per time step with 8 hidden units per workgroup.  ONSSEN_XCD=0 forces the per-step form,
-    ONSSEN_UG overrides its unit-group size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
-    flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
-    x3 = _split_bf16() and H <= 640
-    if x3:
-        flags |= _abi.BLSTM_BF16X3
-    if x3 and os.environ.get("ONSSEN_XCD", "1") == "1" and not _XCD_DISABLED[0]:
-        if precision() == "bf16":
-            flags |= _abi.BLSTM_BF16
-        return 4 * -(-H // 128), flags | _abi.BLSTM_XCD
-    if precision() == "bf16":
-        raise RuntimeError("ONSSEN_PRECISION=bf16 exists only in the XCD-form recurrence (H <= 640, ONSSEN_XCD=1)")
-    if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
-        flags |= _abi.BLSTM_SPLIT_ROWS
-    return int(os.environ.get("ONSSEN_UG", "8")), flags
+      * the call that aborted is re-run by its owner inside ``forced_steps()`` (launch-per-step recurrence for
+        inference, the ATen LSTM for training), see ``recovering``;
+      * the next call tries the persistent form again; only consecutive aborts back off: after the k-th abort in a row
+        the next 2^(k-1) - 1 BLSTM launches (at most 63) skip it, a persistent launch that completes resets the streak.
+    Counters are for tests / bench output."""
+    skip = 0               # BLSTM stack launches that still avoid the persistent form
+    streak = 0             # aborts since the last persistent launch that completed
+    aborts = 0
+    recovered = 0          # calls re-run after an abort
+    force_steps = 0        # depth of forced_steps() scopes
+    persistent_launches = 0
+    fallback_launches = 0
+
+    @classmethod
+    def persistent_allowed(cls):
+        return cls.force_steps == 0 and cls.skip == 0
+
+    @classmethod
+    def note_launch(cls, persistent):
+        if persistent:
+            cls.persistent_launches += 1
+        else:
+            cls.fallback_launches += 1
+            if cls.force_steps == 0 and cls.skip > 0:
+                cls.skip -= 1
+
+    @classmethod
+    def on_abort(cls):
+        cls.aborts += 1
+        cls.streak += 1
+        cls.skip = min(2 ** (cls.streak - 1) - 1, 63)
+
+    @classmethod
+    def on_ok(cls):
+        cls.streak = 0
+
+    @classmethod
+    def forced_steps(cls):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            cls.force_steps += 1
+            try:
+                yield
+            finally:
+                cls.force_steps -= 1
+        return scope()
+
+
+def recovering(fn):
+    """Decorator of the entry points that end with ``_XcdStatus.flush()``: a call whose persistent recurrence aborted is
+    run again on the launch-per-step recurrence (its inputs are untouched: inference is functional), with a warning."""
+    import functools
+    import warnings
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except XcdAborted as e:
+            _XcdPolicy.recovered += 1
+            warnings.warn(f"onssen_amd: {e}  Re-running this call on the launch-per-step recurrence.", RuntimeWarning)
+            with _XcdPolicy.forced_steps():
+                return fn(*args, **kwargs)
+    return wrapper
 
 
 class _XcdStatus:
@@ -73,8 +127,9 @@ class _XcdStatus:
         interpreter exit, and after every forward when ONSSEN_CHECK=1 (tests);
       * otherwise at the next forward (never inside a graph capture), so that a plain ``model(x)`` does not pay a
         synchronisation per call.
-    On an abort the words are reset (a stale abort word would abort every later launch on that workspace) and the
-    persistent forms are disabled for the process: inference and training take the launch-per-step / ATen paths."""
+    On an abort the words are reset (a stale abort word would abort every later launch on that workspace) and
+    ``XcdAborted`` is raised; what happens next is ``_XcdPolicy``'s business (the call is re-run on the launch-per-step
+    recurrence by its owner, the persistent form stays enabled)."""
     pending = []
     safe_protocol_seen = False
 
@@ -99,14 +154,20 @@ class _XcdStatus:
                 continue
             if int(host[1]) == 1:
                 cls.safe_protocol_seen = True
+            if int(host[0]) == 0:
+                _XcdPolicy.on_ok()
             if int(host[0]) != 0 or int(host[2]) != 0:
                 wsb[1120:1132].zero_()                  # abort / non-finite words: the next launch starts clean
                 if int(host[0]) != 0:
-                    _XCD_DISABLED[0] = True
-                    err = err or _abi.OnssenError(
+                    # an aborted launch leaves the monotonic start-up state inconsistent (arrivals counted, generation not
+                    # advanced): the next persistent launch on this workspace would walk through its start-up barrier.
+                    # Nothing is in flight here (the event has fired): the owner zeroes the whole exchange header again.
+                    wsb[:_abi.BLSTM_WS_HEADER].zero_()
+                    if not isinstance(err, XcdAborted):
+                        _XcdPolicy.on_abort()           # once per reported call (its launches abort together)
+                    err = err if isinstance(err, XcdAborted) else XcdAborted(
                         f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
-                        "(and, in training, the gradients) of that call are invalid.  The launch-per-step recurrence "
-                        "(inference) and the ATen LSTM (training) are used from now on.")
+                        "(and, in training, the gradients) of that call are invalid.")
                 else:
                     err = err or _abi.OnssenError(
                         "non-finite activations inside the persistent recurrence (NaN / Inf in the input or the weights): "
@@ -170,8 +231,11 @@ class BLSTMParams(nn.Module):
         """Training path (needs autograd).  On a ROCm device with H <= 640: the HIP forward with saved state and the
         HIP backward recurrence (nn/_train.py); ONSSEN_TRAIN_HIP=0, a CPU tensor or a wider layer
         take the stock ATen LSTM op instead."""
-        if (x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"
-                and not _XCD_DISABLED[0]):
+        hip = x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"
+        allowed = hip and _XcdPolicy.persistent_allowed()
+        if hip:
+            _XcdPolicy.note_launch(allowed)
+        if allowed:
             from ._train import BLSTMTrainFunction
             if getattr(self, "_train_packed", None) is None:
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))
@@ -415,6 +479,8 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in bias], y.data_ptr() if need_y or not flags & _abi.BLSTM_XCD else None,
                       wsb.data_ptr(), wsb.numel(), flags, _stream())
+    if _split_bf16() and p.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
+        _XcdPolicy.note_launch(bool(flags & _abi.BLSTM_XCD))
     y.x3_image = None
     y.fp32_valid = bool(need_y or not flags & _abi.BLSTM_XCD)
     if flags & _abi.BLSTM_XCD:

@@ -7,16 +7,17 @@ import numpy as np
 import torch
 
 from .features import mask_istft, stft_logmag
-from .nn._core import _XcdStatus
+from .nn._core import _XcdStatus, recovering
 
 
+@recovering
 @torch.no_grad()
 def separate_chimera(model, wav, window_size=256, hop_size=64):
     """wav (B, n) cuda float32 -> (B, 2, n): masks straight from the network."""
     logmag, ri = stft_logmag(wav, window_size, hop_size)
     _, masks = model.embedding_and_masks(logmag)
     out = mask_istft(ri, masks, hop_size, wav.shape[-1])
-    _XcdStatus.flush()            # an aborted recurrence is reported by THIS call, not by the next one
+    _XcdStatus.flush()            # an aborted recurrence is caught HERE (and the call re-run, see `recovering`), not by the next call
     return out
 
 
@@ -35,6 +36,7 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
     return masks
 
 
+@recovering
 @torch.no_grad()
 def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, host_kmeans=False):
     """Deep-clustering separation, waveform in -> (B, 2, n) waveforms out, entirely on the GPU

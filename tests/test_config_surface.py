@@ -41,9 +41,15 @@ def test_modules_build_from_the_config_fixture(cfg, cls, n_params):
 
 
 @pytest.mark.gpu
-def test_recipe_flow_from_config_on_the_gpu():
+def test_recipe_flow_from_config_on_the_gpu(monkeypatch):
     """run.py's sequence on the GPU box: config -> model -> loaders -> optimizer -> one training step -> tester.eval()
-    on the evaluation loader (whole utterances, batch 1, label [Re, Im, sig_ref])."""
+    on the evaluation loader (whole utterances, batch 1, label [Re, Im, sig_ref]).  The recipe's data_path is the author's
+    corpus directory: without ONSSEN_SYNTHETIC_DATA=1 the factory refuses it (checked first)."""
+    from onssen_amd.data import wsj0_2mix_dataloader as _dl
+    monkeypatch.delenv("ONSSEN_SYNTHETIC_DATA", raising=False)
+    with pytest.raises(FileNotFoundError):
+        _dl("dc", load("config_dc.json").feature_options, "tr", "cuda:0")
+    monkeypatch.setenv("ONSSEN_SYNTHETIC_DATA", "1")
     from onssen_amd import dist as odist
     from onssen_amd.data import wsj0_2mix_dataloader
     from onssen_amd.evaluate import tester_chimera, tester_dc

@@ -65,6 +65,36 @@ def _worker(rank, world, port, out):
     w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
     ws = [torch.empty_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
+    # ---- a bucket that never completes: chimera trained with loss_dc only leaves fc_mi without a gradient, so the heads'
+    #      bucket is never "ready" during backward -- finish() must still average what exists (replicas stay identical)
+    sd = make_state_dict("chimera", 129, 16, 1, 20, 2, seed=9)
+    m3 = onn.chimera(129, 16, 1, 20, dropout=0.0)
+    m3.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m3.eval()
+    dc_only = lambda out, lab: loss_dc(out[:1], lab)
+    torch.mean(dc_only(m3(inp), lab)).backward()
+    g_local = m3.fc_dc.bias.grad.clone()
+    gl = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gl, g_local)
+    red3 = odist._reducer_for(m3, world, None)
+    red3.begin()
+    m3.zero_grad()
+    torch.mean(dc_only(m3(inp), lab)).backward()
+    in_bwd = red3.issued_in_backward
+    red3.finish()
+    partial_ok = bool(torch.allclose(m3.fc_dc.bias.grad, (gl[0] + gl[1]) / 2, rtol=1e-5, atol=1e-8)) and m3.fc_mi.weight.grad is None
+    # ... and a backward outside begin() .. finish() issues nothing (hooks stay registered on the model)
+    m3.zero_grad()
+    torch.mean(dc_only(m3(inp), lab)).backward()
+    idle_ok = red3.pending == [] and red3.layer_pending == []
+    opt3 = torch.optim.Adam(m3.parameters(), lr=1e-3)
+    odist.train_step(m3, opt3, dc_only, inp, lab, world)
+    w3 = torch.cat([p.detach().reshape(-1) for p in m3.parameters()])
+    ws3 = [torch.empty_like(w3) for _ in range(world)]
+    dist.all_gather(ws3, w3)
+    # a later single-process step removes the hooks
+    odist.train_step(m3, opt3, dc_only, inp, lab, 1)
+    closed_ok = getattr(m3, "_onssen_reducer", None) is None
     # ---- utterance-sharded inference: gather(shards) == whole batch
     n = 5
     lo, hi = odist.shard_range(n, rank, world)
@@ -73,7 +103,8 @@ def _worker(rank, world, port, out):
     if rank == 0:
         out.put(dict(local0=[g.numpy() for g in local], synced=[g.numpy() for g in synced], loss=loss,
                      same=bool(torch.equal(ws[0], ws[1])), gathered=got.numpy(), issued=issued, n_buckets=len(red.buckets),
-                     overl=[g.numpy() for g in overl]))
+                     overl=[g.numpy() for g in overl], partial_ok=partial_ok, idle_ok=idle_ok, in_bwd3=in_bwd,
+                     same3=bool(torch.equal(ws3[0], ws3[1])), closed_ok=closed_ok))
     else:
         out.put(dict(local1=[g.numpy() for g in local]))
     dist.barrier()
@@ -100,6 +131,8 @@ def test_two_rank_gloo_allreduce_and_sharding():
     assert res["issued"] == res["n_buckets"] == 1 + 2 * 2            # all buckets were in flight before backward() returned
     for o, s in zip(res["overl"], res["synced"]):
         np.testing.assert_allclose(o, s, rtol=1e-6, atol=1e-8)
+    # incomplete bucket (fc_mi unused): the LSTM buckets went out during backward, the heads' bucket in finish()
+    assert res["partial_ok"] and res["idle_ok"] and res["same3"] and res["closed_ok"] and res["in_bwd3"] == 2
     np.testing.assert_array_equal(res["gathered"], np.arange(15, dtype=np.float32).reshape(5, 3) * 2)
 
 

@@ -516,6 +516,53 @@ def test_loss_mask_term(lib, psa):
     np.testing.assert_allclose(out, ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize("psa", [False, True])
+def test_loss_mask_gradient(lib, psa):
+    """onssen_loss_mask_grad_f32 against torch autograd of the literal form (onssen/loss/loss_chimera.py:25-29 / :53-57):
+    the permutation picked by the forward kernels, sign(0) = 0, the incoming gradient per utterance, interleaved output."""
+    import torch
+    rng = np.random.default_rng(13)
+    B, TF = 3, 900
+    masks = rng.random((B, TF, 2)).astype(np.float32)
+    mag = (np.abs(rand(rng, B, TF)) + 1e-3).astype(np.float32)
+    s1, s2 = (mag * rng.random((B, TF))).astype(np.float32), (mag * rng.random((B, TF))).astype(np.float32)
+    c1, c2 = rand(rng, B, TF).clip(-1, 1), rand(rng, B, TF).clip(-1, 1)
+    tg1, tg2 = (np.minimum(mag, np.maximum(s1 * c1, 0)), np.minimum(mag, np.maximum(s2 * c2, 0))) if psa else (s1, s2)
+    # utterance 0 estimates (speaker 1, speaker 2), utterance 1 the swapped order: both assignments occur
+    masks[0, :, 0], masks[0, :, 1] = 0.8 * tg1[0] / mag[0] + 0.05, 0.8 * tg2[0] / mag[0] + 0.05
+    masks[1, :, 0], masks[1, :, 1] = 0.8 * tg2[1] / mag[1] + 0.05, 0.8 * tg1[1] / mag[1] + 0.05
+    masks[2, 5, 0] = tg1[2, 5] / mag[2, 5]                                       # a residual that may be exactly 0
+    out, perm = np.full(B, np.nan, np.float32), np.full(B, -1, np.int32)
+    ws = aligned_f32(lib.loss_mask_workspace_bytes(B) // 4 + 64)
+    cc = (P(c1), P(c2)) if psa else (None, None)
+    lib.loss_mask(P(masks), masks.ctypes.data + 4, 2 * TF, 2, P(mag), P(s1), P(s2), *cc, B, TF, P(out), P(ws), ws.nbytes, None,
+                  perm=P(perm))
+    g = rng.standard_normal(B).astype(np.float32)
+    d = np.full((B, TF, 2), np.nan, np.float32)
+    lib.loss_mask_grad(P(masks), masks.ctypes.data + 4, 2 * TF, 2, P(mag), P(s1), P(s2), *cc, B, TF, P(g), P(perm), P(d),
+                       d.ctypes.data + 4, 2 * TF, 2, None)
+    tt = lambda a: torch.from_numpy(a.astype(np.float64))
+    m = tt(masks).requires_grad_(True)
+    x, t1, t2 = tt(mag), tt(s1), tt(s2)
+    if psa:
+        t1, t2 = torch.minimum(x, torch.relu(t1 * tt(c1))), torch.minimum(x, torch.relu(t2 * tt(c2)))
+    ma, mb = m[..., 0], m[..., 1]
+    l1 = lambda a: a.abs().sum(1)
+    l_ab, l_ba = l1(ma * x - t1) + l1(mb * x - t2), l1(mb * x - t1) + l1(ma * x - t2)
+    ref = torch.min(l_ab, l_ba)
+    np.testing.assert_array_equal(perm, (l_ba < l_ab).numpy().astype(np.int32))
+    assert perm[0] == 0 and perm[1] == 1
+    (ref * tt(g)).sum().backward()
+    np.testing.assert_allclose(out, ref.detach().numpy(), rtol=1e-5)
+    ref_d = m.grad.numpy()
+    # fp32 residuals within rounding of 0 may take either sign: compare where the fp64 residual is clearly non-zero
+    ra = (ma * x - torch.where(torch.from_numpy(perm)[:, None] == 0, t1, t2)).detach().abs().numpy()
+    rb = (mb * x - torch.where(torch.from_numpy(perm)[:, None] == 0, t2, t1)).detach().abs().numpy()
+    clear = np.stack([ra, rb], -1) > 1e-6
+    np.testing.assert_allclose(d[clear], ref_d[clear], rtol=1e-6, atol=1e-12)
+    assert clear.mean() > 0.99 and np.isfinite(d).all()
+
+
 _TRAIN_CASES = [(H, ug, B, T, _abi.LSTM_BWD_XCD, "0") for H, ug, B, T in
                 [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17), (8, 4, 1, 1), (8, 4, 70, 2)]] + \
                [(24, 8, 18, 3, _abi.LSTM_BWD_XCD, "1"), (8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0")]

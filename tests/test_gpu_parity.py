@@ -767,6 +767,70 @@ def test_chimera_losses_on_device_match_reference_fixture(dev, golden_dir):
     np.testing.assert_allclose(psa.cpu().numpy(), z["psa"], rtol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["msa", "psa"])
+@pytest.mark.parametrize("views", ["network", "separate"])
+def test_chimera_losses_with_gradient_on_device(dev, golden_dir, which, views):
+    """N1: loss_chimera_msa / psa WITH a gradient on the HIP kernels (loss_dc value + gradient kernels, mask
+    term: onssen_loss_mask_f32 picks the assignment, onssen_loss_mask_grad_f32 the gradient) against float64 autograd through
+    the literal form of onssen/loss/loss_chimera.py:18-31 / :47-59 + loss_dc.py:24-44 -- value (incl. the (B,B) quirk), the
+    embedding's gradient and both masks' gradients; the masks either as the network hands them over (two strided views of one
+    (B,T,F,2) tensor: the gradient goes to that tensor in one pass) or as two unrelated tensors.  The reference-generated g7
+    fixture pins the value of the same functions (test above)."""
+    from onssen_amd.loss import loss_chimera_msa, loss_chimera_psa
+    torch.manual_seed(11)
+    B, T, F, D, C = 3, 100, 129, 20, 2
+    emb = torch.nn.functional.normalize(torch.randn(B, T, F, D), dim=-1)
+    raw = torch.rand(B, T, F, C) * 0.98 + 0.01
+    lab = torch.randint(0, C + 1, (B, T, F))
+    one_hot = torch.nn.functional.one_hot(lab, C + 1)[..., :C].double()
+    mag = torch.rand(B, T, F) + 0.05
+    s1, s2 = mag * torch.rand(B, T, F), mag * torch.rand(B, T, F)
+    c1, c2 = torch.rand(B, T, F) * 2 - 1, torch.rand(B, T, F) * 2 - 1
+    raw[1] = torch.stack([s2[1] / mag[1], s1[1] / mag[1]], -1) * 0.9 + 0.02      # utterance 1: the swapped assignment wins (MSA)
+
+    def literal(e, m):                # float64, the reference's formulas
+        V = e.reshape(B, T * F, D); Y = one_hot.reshape(B, T * F, C); mg = mag.double().reshape(B, -1)
+        tot = mg.sum(1, keepdim=True); w = torch.sqrt(mg / tot).unsqueeze(-1)
+        Vm, Ym = V * Y.sum(2, keepdim=True) * w, Y * w
+        fro = lambda x: torch.sqrt((x * x).flatten(1).sum(1))
+        le = (fro(Vm.transpose(1, 2) @ Vm) - 2 * fro(Vm.transpose(1, 2) @ Ym) + fro(Ym.transpose(1, 2) @ Ym)) * tot
+        x = mag.double()
+        t1, t2 = s1.double(), s2.double()
+        if which == "psa":
+            t1, t2 = torch.min(x, torch.relu(t1 * c1.double())), torch.min(x, torch.relu(t2 * c2.double()))
+        l1 = lambda a: a.reshape(B, -1).abs().sum(1)
+        mA, mB = m[..., 0], m[..., 1]
+        lm = torch.min(l1(mA * x - t1) + l1(mB * x - t2), l1(mB * x - t1) + l1(mA * x - t2))
+        return le * 0.975 + lm * 0.025
+    e64, m64 = emb.double().requires_grad_(True), raw.double().requires_grad_(True)
+    ref = literal(e64, m64)
+    ge_ref, gm_ref = torch.autograd.grad(ref.mean(), [e64, m64])
+
+    eg = emb.to(dev).requires_grad_(True)
+    if views == "network":
+        leaf = raw.to(dev).requires_grad_(True)
+        mg_ = (leaf * 1.0).reshape(B, T, F * C).reshape(B, T, F, C)        # a non-leaf buffer, sliced like chimera.py:43-45
+        mA, mB = mg_[:, :, :, 0], mg_[:, :, :, 1]
+        wrt = [eg, leaf]
+    else:
+        la, lb = raw[..., 0].contiguous().to(dev).requires_grad_(True), raw[..., 1].contiguous().to(dev).requires_grad_(True)
+        mA, mB = la, lb
+        wrt = [eg, la, lb]
+    label = [one_hot.to(dev), mag.to(dev), s1.to(dev), s2.to(dev)] + ([c1.to(dev), c2.to(dev)] if which == "psa" else [])
+    got = (loss_chimera_msa if which == "msa" else loss_chimera_psa)([eg, mA, mB], label)
+    assert tuple(got.shape) == (B, B)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=5e-5)
+    grads = torch.autograd.grad(got.mean(), wrt)
+    assert (grads[0].cpu().double() - ge_ref).abs().max() <= 5e-5 * ge_ref.abs().max()
+    gm = grads[1].cpu().double() if views == "network" else torch.stack([grads[1].cpu().double(), grads[2].cpu().double()], -1)
+    # |.|'s gradient is a sign: it may differ where the fp32 residual is within rounding of zero
+    x = mag.double().unsqueeze(-1)
+    far = (gm - gm_ref).abs() <= 1e-6 * gm_ref.abs().max()
+    assert far.double().mean() > 0.9995 and torch.isfinite(gm).all()
+    assert (gm.abs() <= (0.025 / B) * x * (1 + 1e-6) + 1e-12).all()
+
+
 # ---------------------------------------------------------------- training path (row N1): HIP forward + backward
 @pytest.mark.gpu
 # XCD-local persistent backward launch + split-bf16 MFMA gradient GEMMs (default) | launch per step + fp32 library GEMMs

@@ -36,31 +36,43 @@ def _run(code, **env):
     return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300, cwd=ROOT)
 
 
-_ABORT = """
-import numpy as np, torch
-from onssen_amd import nn as onn, _abi
-from onssen_amd.separation import separate_dc
-from onssen_amd.synthetic import synth_mixture
-dev = torch.device("cuda:0")
-m = onn.deep_clustering(129, 64, 2, 20).to(dev).eval()
-wav = torch.from_numpy(np.stack([synth_mixture(7 + b, 4000) for b in range(4)])).to(dev)
-try:
-    separate_dc(m, wav)
-    print("NO ERROR")
-except _abi.OnssenError as e:
-    print("RAISED", str(e)[:60])
-# the abort word was reset and the persistent form disabled: the next call works (launch per step)
-out = separate_dc(m, wav)
-print("SECOND", bool(torch.isfinite(out).all()))
-"""
-
-
-def test_abort_is_raised_by_the_call_that_caused_it(dev):
-    """with a spin limit of 0 the bounded waits of the persistent recurrence give up at once; the
-    exception must come out of THAT separate_dc call (not the next one), and the call after it must work."""
-    r = _run(_ABORT, ONSSEN_XCD_SPIN_LIMIT="0")
-    assert "RAISED XCD-local persistent recurrence aborted" in r.stdout, r.stdout + r.stderr[-2000:]
-    assert "SECOND True" in r.stdout, r.stdout + r.stderr[-2000:]
+def test_abort_is_recovered_by_the_call_that_caused_it(dev):
+    """an abort is a property of ONE launch.  With the bounded waits set to 0 the persistent recurrence
+    gives up at once: a bare forward reports it (XcdAborted at the flush), ``separate_dc`` re-runs THAT call on the
+    launch-per-step recurrence (same result as the undisturbed call, a RuntimeWarning), and the call after it is back on
+    the persistent path."""
+    import warnings
+    from onssen_amd import nn as onn
+    from onssen_amd.hip import get_lib
+    from onssen_amd.nn import _core
+    from onssen_amd.separation import separate_dc
+    lib = get_lib()
+    torch.manual_seed(1)
+    m = onn.deep_clustering(129, 64, 2, 20).to(dev).eval()
+    wav = torch.from_numpy(np.stack([synth_mixture(7 + b, 4000) for b in range(4)])).to(dev)
+    P = _core._XcdPolicy
+    ref = separate_dc(m, wav)
+    base = (P.aborts, P.recovered, P.persistent_launches)
+    old = lib.dll.onssen_xcd_spin_limit(0)
+    try:
+        with torch.no_grad(), pytest.raises(_core.XcdAborted, match="persistent recurrence aborted"):
+            m([torch.randn(4, 30, 129, device=dev)])
+            _core._XcdStatus.flush()
+        assert P.aborts == base[0] + 1 and P.skip == 0            # first abort in a row: the next call tries again
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = separate_dc(m, wav)
+        assert any("launch-per-step" in str(x.message) for x in w)
+        assert P.aborts == base[0] + 2 and P.recovered == base[1] + 1 and P.skip == 1     # second in a row: back off by one
+    finally:
+        lib.dll.onssen_xcd_spin_limit(old)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-5)       # step path vs persistent path
+    out2 = separate_dc(m, wav)                 # consumes the back-off (launch per step)
+    n_p = P.persistent_launches
+    out3 = separate_dc(m, wav)                 # ... and this one is persistent again, and completes
+    assert P.persistent_launches == n_p + 1 and P.skip == 0 and P.streak == 0 and P.aborts == base[0] + 2
+    assert torch.equal(out3, ref)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.cpu().numpy(), atol=2e-5)
 
 
 def test_nonfinite_activations_are_reported(dev, monkeypatch):
@@ -74,7 +86,7 @@ def test_nonfinite_activations_are_reported(dev, monkeypatch):
     x[1, 4, 7] = float("nan")
     with torch.no_grad(), pytest.raises(_abi.OnssenError, match="non-finite"):
         m([x])
-    assert not _core._XCD_DISABLED[0]                 # not an abort: the persistent form stays enabled
+    assert _core._XcdPolicy.persistent_allowed()      # not an abort: the persistent form stays enabled
     monkeypatch.setenv("ONSSEN_XCD", "0")
     with torch.no_grad():
         out = m([x])[0]
@@ -200,7 +212,7 @@ out.backward()                                               # ... under the per
 torch.cuda.synchronize()
 _core._XcdStatus.flush()
 same = all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
-print("ABORTED", _core._XCD_DISABLED[0], "SAME", same)
+print("ABORTS", _core._XcdPolicy.aborts, "SAME", same)
 dist.destroy_process_group()
 """
 
@@ -210,6 +222,77 @@ def test_rccl_allreduce_next_to_the_persistent_recurrence(dev):
     persistent recurrence into its bounded-wait abort path -- or if it does, the abort is reported and the fallback takes
     over.  Either way the gradients are the undisturbed ones or an exception names the abort; never silent garbage."""
     r = _run(_OVERLAP)
-    assert "ABORTED" in r.stdout or "aborted" in (r.stdout + r.stderr), r.stdout + r.stderr[-3000:]
-    if "ABORTED False" in r.stdout:
-        assert "SAME True" in r.stdout, r.stdout
+    assert "ABORTS 0 SAME True" in r.stdout, r.stdout + r.stderr[-3000:]      # no abort, bit-identical gradients
+
+
+def _train_setup(dev, H=600, B=16, T=100, seed=0):
+    from onssen_amd import nn as onn
+    torch.manual_seed(seed)
+    m = onn.deep_clustering(129, H, 2, 20, dropout=0.0).to(dev).train()
+    x = torch.randn(B, T, 129, device=dev)
+    lab = torch.randint(0, 2, (B, T, 129), device=dev)
+    label = [torch.stack([lab, 1 - lab], -1).double(), torch.rand(B, T, 129, device=dev) + 0.1]
+    return m, x, label
+
+
+def test_training_step_beside_a_16_workgroup_cotenant_is_bit_identical(dev):
+    """RCCL's CU budget next to the persistent recurrences is 2 CUs per XCD = 16 workgroups
+    (dist.RCCL_MAX_CHANNELS; tools/cotenant_probe.py measures it).  A co-tenant of exactly that size that holds its CUs
+    for the whole step -- launched first, so the recurrences must fit around it -- changes nothing: no abort, gradients
+    bit-identical to the undisturbed step."""
+    from onssen_amd import dist as odist
+    from onssen_amd.hip import get_lib
+    from onssen_amd.loss import loss_dc
+    from onssen_amd.nn import _core
+    lib = get_lib()
+    m, x, label = _train_setup(dev)
+
+    def grads():
+        m.zero_grad()
+        torch.mean(loss_dc(m([x]), label)).backward()
+        torch.cuda.synchronize()
+        _core._XcdStatus.flush()
+        return [p.grad.clone() for p in m.parameters()]
+    ref = grads()
+    P = _core._XcdPolicy
+    a0, p0 = P.aborts, P.persistent_launches
+    side = torch.cuda.Stream()
+    lib.check(lib.dll.onssen_debug_cotenant_spin(odist.RCCL_MAX_CHANNELS, 256, 100 * 30_000, side.cuda_stream), "spin")   # 30 ms
+    got = grads()
+    torch.cuda.synchronize()
+    assert P.aborts == a0 and P.persistent_launches > p0
+    assert all(torch.equal(a, b) for a, b in zip(ref, got))
+
+
+def test_aborted_training_step_is_rerun_and_the_next_one_is_persistent_again(dev):
+    """a forced abort (bounded waits set to 0) inside ``train_step``: the step is re-run on the ATen
+    LSTM BEFORE the optimizer sees anything (finite loss, weights updated once, BatchNorm statistics advanced once), and
+    the next ``train_step`` is back on the persistent forward / backward."""
+    import warnings
+    from onssen_amd import dist as odist
+    from onssen_amd.hip import get_lib
+    from onssen_amd.loss import loss_dc
+    from onssen_amd.nn import _core
+    lib = get_lib()
+    m, x, label = _train_setup(dev, H=64, B=4, T=30, seed=3)
+    m_ref, _, _ = _train_setup(dev, H=64, B=4, T=30, seed=3)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-2)          # (SGD: the update is smooth in the gradient; Adam's first step is its sign)
+    opt_ref = torch.optim.SGD(m_ref.parameters(), lr=1e-2)
+    loss_ref = odist.train_step(m_ref, opt_ref, loss_dc, [x], label)
+    P = _core._XcdPolicy
+    a0, r0 = P.aborts, P.recovered
+    old = lib.dll.onssen_xcd_spin_limit(0)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            loss = odist.train_step(m, opt, loss_dc, [x], label)
+    finally:
+        lib.dll.onssen_xcd_spin_limit(old)
+    assert P.aborts == a0 + 1 and P.recovered == r0 + 1 and any("ATen LSTM" in str(x_.message) for x_ in w)
+    assert abs(loss - loss_ref) <= 1e-3 * abs(loss_ref)
+    assert int(m.bn.num_batches_tracked) == int(m_ref.bn.num_batches_tracked) == 1
+    for a, b in zip(m.parameters(), m_ref.parameters()):          # the ATen-LSTM step and the HIP step agree
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=1e-4)
+    n_p = P.persistent_launches
+    loss2 = odist.train_step(m, opt, loss_dc, [x], label)
+    assert P.persistent_launches == n_p + 1 and P.aborts == a0 + 1 and np.isfinite(loss2)

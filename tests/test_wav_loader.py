@@ -50,12 +50,18 @@ def test_read_wav_formats(tmp_path):
     assert np.abs(y - x).max() <= 1 / 128
 
 
-def test_factory_picks_files_or_synthetic(tmp_path):
+def test_factory_picks_files_or_synthetic(tmp_path, monkeypatch):
+    monkeypatch.delenv("ONSSEN_SYNTHETIC_DATA", raising=False)
     make_corpus(str(tmp_path), "tr", [3000, 2500, 2800])
     fo = dict(FO, data_path=str(tmp_path))
     dl = wsj0_2mix_dataloader("dc", fo, "tr", device="cpu")
     assert isinstance(dl, Wsj02mixFiles) and len(dl) == 2 and len(dl.file_list) == 3
-    assert not isinstance(wsj0_2mix_dataloader("dc", fo, "cv", device="cpu"), Wsj02mixFiles)       # no cv files: synthetic
+    with pytest.raises(FileNotFoundError):                                                          # data_path given, no cv files: never
+        wsj0_2mix_dataloader("dc", fo, "cv", device="cpu")                                          # silently synthetic
+    monkeypatch.setenv("ONSSEN_SYNTHETIC_DATA", "1")
+    assert not isinstance(wsj0_2mix_dataloader("dc", fo, "cv", device="cpu"), Wsj02mixFiles)       # ... unless asked for
+    monkeypatch.delenv("ONSSEN_SYNTHETIC_DATA")
+    assert not isinstance(wsj0_2mix_dataloader("dc", dict(FO, data_path="synthetic"), "tr", device="cpu"), Wsj02mixFiles)
     assert not isinstance(wsj0_2mix_dataloader("dc", FO, "tr", device="cpu"), Wsj02mixFiles)       # no data_path
     with pytest.raises(ValueError):
         Wsj02mixFiles("conv-tasnet", fo, "tr")
