@@ -516,7 +516,9 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
             lin(yin.data_ptr(), B * 2 * Hp, 2 * Hp, K1, hp.w.data_ptr(), K1, hp.planes.data_ptr(), hp.ld3, hp.b.data_ptr(),
                 hp.N, 1, D, out.data_ptr(), hp.N, T * hp.N)
 
-    def timed(fn, reps=5):
+    def timed(fn, reps=5, inner=4):
+        """Seconds per call: `inner` calls captured back to back in ONE hipGraph (kernel boundaries like inside the step's own
+        graph; a graph launch per call would add its ~5-10 us to every short kernel), replayed `reps` times between events."""
         fn()
         torch.cuda.synchronize()
         s = torch.cuda.Stream()
@@ -526,7 +528,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         torch.cuda.current_stream().wait_stream(s)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            fn()
+            for _ in range(inner):
+                fn()
         g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -535,7 +538,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
             g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps * 1e-3
+        return e0.elapsed_time(e1) / (reps * inner) * 1e-3
 
     t_layer, t_gin, t_g0, t_head = timed(layer), timed(gemm_in), timed(gemm0), timed(head)
     t_img = timed(image_in) if images and lyr else 0.0         # (for lyr == 0 the split is part of gemm0 = gemm_in)

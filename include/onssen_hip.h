@@ -314,11 +314,20 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
  * 1 - label on active bins, 0 in both on silent bins.
  * Replaces `KMeans(n_clusters=2, random_state=0).fit_predict(emb)` + the mask fill at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:36-41 (sklearn on the host upstream).  Deterministic farthest-point
- * initialisation and `iters` Lloyd iterations; cluster numbering is arbitrary, as it is upstream.  D <= 32.
+ * initialisation and at most `iters` Lloyd iterations (an utterance whose assignment reaches its exact fixed point stops
+ * earlier); cluster numbering is arbitrary, as it is upstream.  D <= 32.
+ * Default form: the active bins are compacted once into the workspace and ALL iterations run in one persistent launch
+ * (8 workgroups per utterance that meet at a counter; every wait is bounded by onssen_xcd_spin_limit: a wait that gives up
+ * sets the u32 at ws + onssen_dc_cluster_status_offset(B, D) -- the masks of that call are then not the converged ones and
+ * the caller repeats it with ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION).  flags = ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION: two
+ * launches per iteration over the uncompacted embeddings, no inter-workgroup waits.  The owner zeroes the status word once.
+ * emb 16-byte aligned, ws 256-byte aligned.
  */
-size_t onssen_dc_cluster_workspace_bytes(int B, int D);
+#define ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION 1
+size_t onssen_dc_cluster_workspace_bytes(int B, int T, int F, int D);
+size_t onssen_dc_cluster_status_offset(int B, int D);
 int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                          int iters, float* masks, void* ws, size_t ws_bytes, void* stream);
+                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  deep-clustering loss: VALUE (onssen_loss_dc_f32) and its GRADIENT w.r.t. the embedding (onssen_loss_dc_grad_f32):
@@ -384,8 +393,9 @@ int onssen_debug_launch_chain(float* scratch, int n, int workgroups, void* strea
 
 /* Co-tenant probe (not part of the separation path; tools/cotenant_probe.py): `workgroups` x `threads` threads that only
  * hold their compute units for `ticks` ticks of the 100 MHz wall clock on `stream` -- a stand-in for RCCL's channel
- * kernels running beside the persistent recurrences (a recurrence group needs 30 of its XCD's 32 CUs at the same time). */
-int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, void* stream);
+ * kernels running beside the persistent recurrences (a recurrence group needs 30 of its XCD's 32 CUs at the same time).
+ * heavy != 0: >= 112 live VGPRs per lane and 32 KB of LDS (cannot share a CU with a recurrence workgroup). */
+int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, int heavy, void* stream);
 
 /* Bound of every wait inside the persistent kernels (ONSSEN_BLSTM_XCD forward, training forward / backward), in polling
  * passes: default 400000 (~0.2 s), initial value from ONSSEN_XCD_SPIN_LIMIT.  new_limit >= 0 sets it (0: every wait gives

@@ -18,6 +18,7 @@ BLSTM_FUSE_TAIL = 32
 BLSTM_BF16 = 64
 BLSTM_G_READY = 128
 LSTM_BWD_STEPS, LSTM_BWD_XCD = 0, 1
+DC_CLUSTER_LAUNCH_PER_ITERATION = 1
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -61,10 +62,11 @@ SIGNATURES = {
     "onssen_l2norm_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
-    "onssen_debug_cotenant_spin": (_i, [_i, _i, C.c_longlong, _vp]),
+    "onssen_debug_cotenant_spin": (_i, [_i, _i, C.c_longlong, _i, _vp]),
     "onssen_xcd_spin_limit": (C.c_longlong, [C.c_longlong]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i]),
+    "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "onssen_dc_cluster_status_offset": (_sz, [_i, _i]),
     "onssen_loss_mask_workspace_bytes": (_sz, [_i]),
     "onssen_loss_mask_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_mask_grad_f32": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
@@ -73,7 +75,7 @@ SIGNATURES = {
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
 }
 
@@ -263,6 +265,6 @@ class Lib:
         self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
                                               cos_s1, cos_s2, stream), "onssen_labels_f32")
 
-    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream):
-        self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream),
+    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0):
+        self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, flags, stream),
                    "onssen_dc_cluster_f32")

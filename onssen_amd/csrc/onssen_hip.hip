@@ -68,6 +68,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
   } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Experiment / ablation switches exist only in builds made with -DONSSEN_DEBUG_KNOBS (tools/ab_variants.py): the product
 // library reads no environment variable for them and carries their defaults as constants.
 #ifdef ONSSEN_DEBUG_KNOBS
@@ -97,9 +98,30 @@ static unsigned& xcd_spin_limit() {
 
 // Co-tenant probe (tools/cotenant_probe.py): `workgroups` workgroups of `threads` threads that do nothing but hold their
 // CU for `ticks` ticks of the 100 MHz wall clock -- a stand-in for RCCL's channel kernels next to the persistent recurrences.
-__global__ void cotenant_spin_kernel(long long ticks) {
+// NV live VGPRs per lane and LDS bytes decide whether such a workgroup can share a CU with a recurrence
+// workgroup (2 waves x ~216 VGPRs per SIMD and ~114 KB of LDS leave ~80 VGPRs per SIMD and ~46 KB): the light form can,
+// the heavy form (>= 100 VGPRs, like a collective's unrolled copy loops) needs a CU of its own.
+template <int NV, int LDS>
+__global__ __launch_bounds__(1024) void cotenant_spin_kernel(long long ticks, float* sink) {
+  __shared__ char cotenant_lds[LDS];
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = (float)(threadIdx.x + i);
   const long long t0 = wall_clock64();
-  for (long long i = 0; i < ticks && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(32);   // (bounded by count too)
+  for (long long it = 0; it < ticks && wall_clock64() - t0 < ticks; ++it) {   // (bounded by count too)
+    __builtin_amdgcn_s_sleep(32);
+#ifndef ONSSEN_HOST_EMULATION
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));                // keeps every value in a register across the loop
+#endif
+  }
+  if (sink) {                                                                    // never taken by the probe: keeps v and the LDS alive
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc += v[i];
+    cotenant_lds[threadIdx.x * 31 % LDS] = (char)acc;
+    sink[threadIdx.x] = acc + (float)cotenant_lds[(threadIdx.x + 1) * 31 % LDS];
+  }
 }
 
 // =================================================================================================
@@ -113,10 +135,15 @@ long long onssen_xcd_spin_limit(long long new_limit) {
   return old;
 }
 
-int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, void* stream) {
+int onssen_debug_cotenant_spin(int workgroups, int threads, long long ticks, int heavy, void* stream) {
   if (workgroups <= 0 || threads <= 0 || threads > 1024 || ticks < 0) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
-  hipLaunchKernelGGL(cotenant_spin_kernel, dim3((unsigned)workgroups), dim3((unsigned)threads), 0, (hipStream_t)stream, ticks);
+  if (heavy)
+    hipLaunchKernelGGL((cotenant_spin_kernel<112, 32768>), dim3((unsigned)workgroups), dim3((unsigned)threads), 0,
+                       (hipStream_t)stream, ticks, (float*)nullptr);
+  else
+    hipLaunchKernelGGL((cotenant_spin_kernel<2, 64>), dim3((unsigned)workgroups), dim3((unsigned)threads), 0,
+                       (hipStream_t)stream, ticks, (float*)nullptr);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -572,7 +599,6 @@ int onssen_loss_mask_grad_f32(const float* mask_a, const float* mask_b, int64_t 
   return ONSSEN_OK;
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // workspace layout: header | G | ybuf (L > 1) | c | h hand-off image | x3 images: layer-0 input, output A (the
 // LAST layer's), output B (L > 1) | 64 KiB debug
@@ -1000,25 +1026,35 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
   return ONSSEN_OK;
 }
 
-size_t onssen_dc_cluster_workspace_bytes(int B, int D) {
+// workspace: [B][stride] float header (feature max, centroids, partial sums, done flag) | [B][km::IW] ints + status word |
+// compacted active rows [B][T*F][D] (persistent form)
+static size_t dc_cluster_header_floats(int B, int D) { return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1) + 1); }
+size_t onssen_dc_cluster_status_offset(int B, int D) {
   if (B <= 0 || D <= 0 || D > km::DMAX) return 0;
-  return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1) + 1) * sizeof(float);   // fmax, centroids, partial sums, done flag
+  return align256(dc_cluster_header_floats(B, D) * sizeof(float)) + (size_t)B * km::IW * sizeof(int);
+}
+size_t onssen_dc_cluster_workspace_bytes(int B, int T, int F, int D) {
+  if (B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX) return 0;
+  return align256(onssen_dc_cluster_status_offset(B, D) + 256) + (size_t)B * T * F * D * sizeof(float);
 }
 
 int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                          int iters, float* masks, void* ws, size_t ws_bytes, void* stream) {
+                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream) {
   if (!emb || !feature || !masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0)
     return ONSSEN_E_ARG;
-  if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, D)) return ONSSEN_E_WORKSPACE;
+  if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
+  if (!aligned16(emb) || (reinterpret_cast<uintptr_t>(ws) & 255u)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)stream;
   const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1) + 1;
   float* w = (float*)ws;
+  int* iw = (int*)((char*)ws + align256(dc_cluster_header_floats(B, D) * sizeof(float)));
+  unsigned* status = (unsigned*)((char*)ws + onssen_dc_cluster_status_offset(B, D));
+  float* comp = (float*)((char*)ws + align256(onssen_dc_cluster_status_offset(B, D) + 256));
+  const bool persistent = !(flags & ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION);
   const dim3 sgrid(km::NBLK, (unsigned)B);
   hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
-  hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride);
-  hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
-  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, iw);
 #define ONSSEN_KM_ASSIGN(MODE_, OUT_)                                                                                      \
   do {                                                                                                                   \
     if (D == 20) hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 20>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, \
@@ -1026,9 +1062,28 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
     else hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 0>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature,  \
                             per_utt, D, db_threshold, w, stride, OUT_);                                                      \
   } while (0)
-  for (int it = 0; it < iters; ++it) {
-    ONSSEN_KM_ASSIGN(0, (float*)nullptr);
-    hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(256), 0, st, D, km::NBLK, w, stride);
+  if (persistent) {
+    // active bins compacted once (the same pass finds the second centroid), then ALL Lloyd iterations in one launch per <= 64
+    // utterances (8 workgroups each: co-resident with room to spare)
+    hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw);
+    if (D == 20) hipLaunchKernelGGL((kmeans2_compact_kernel<20>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
+    else hipLaunchKernelGGL((kmeans2_compact_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
+    hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
+    // (a wait that gives up leaves status = 1: the host sees it and runs the launch-per-iteration form)
+    const unsigned spin = xcd_spin_limit();
+    for (int u0 = 0; u0 < B && iters > 0; u0 += 64) {
+      const int nutt = B - u0 < 64 ? B - u0 : 64;
+      const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
+      if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(256), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+      else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(256), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+    }
+  } else {
+    hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
+    hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
+    for (int it = 0; it < iters; ++it) {
+      ONSSEN_KM_ASSIGN(0, (float*)nullptr);
+      hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(256), 0, st, D, km::NBLK, w, stride);
+    }
   }
   ONSSEN_KM_ASSIGN(1, masks);
 #undef ONSSEN_KM_ASSIGN

@@ -116,6 +116,29 @@ def recovering(fn):
     return wrapper
 
 
+def recurrence_plan(B, H):
+    """(ug, flags) for onssen_blstm_forward_f32.
+
+    Split-bf16 precision and H <= 640: the XCD-local persistent recurrence (one launch per layer, every
+    (direction, 16-row group) inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)).  Otherwise one
+    launch per time step with 8 hidden units per workgroup.  ONSSEN_XCD=0 forces the per-step form (so does a
+    ``_XcdPolicy.forced_steps()`` scope or a back-off after consecutive aborts), ONSSEN_UG overrides its unit-group
+    size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
+    flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
+    x3 = _split_bf16() and H <= 640
+    if x3:
+        flags |= _abi.BLSTM_BF16X3
+    if x3 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed():
+        if precision() == "bf16":
+            flags |= _abi.BLSTM_BF16
+        return 4 * -(-H // 128), flags | _abi.BLSTM_XCD
+    if precision() == "bf16":
+        raise RuntimeError("ONSSEN_PRECISION=bf16 exists only in the XCD-form recurrence (H <= 640, ONSSEN_XCD=1)")
+    if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
+        flags |= _abi.BLSTM_SPLIT_ROWS
+    return int(os.environ.get("ONSSEN_UG", "8")), flags
+
+
 class _XcdStatus:
     """The persistent kernels bound every wait and report through workspace words instead of hanging:
     [280] != 0 -> a wait gave up, the launch aborted, outputs are invalid; [281] == 1 -> some exchange group was
@@ -144,6 +167,17 @@ class _XcdStatus:
         cls.pending.append((ev, host, wsb))
 
     @classmethod
+    def post_cluster(cls, ws, offset):
+        """Status word of the persistent Lloyd kernel (separation.dc_masks): non-zero = a bounded wait gave up."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(ws[offset:offset + 4].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cls.pending.append((ev, host, (ws, offset)))
+
+    @classmethod
     def poll(cls, wait=False):
         keep, err = [], None
         for ev, host, wsb in cls.pending:
@@ -151,6 +185,16 @@ class _XcdStatus:
                 ev.synchronize()
             if not ev.query():
                 keep.append((ev, host, wsb))
+                continue
+            if isinstance(wsb, tuple):                  # clustering status word
+                if int(host[0]) != 0:
+                    ws, off = wsb
+                    ws[off:off + 4].zero_()
+                    if not isinstance(err, XcdAborted):
+                        _XcdPolicy.on_abort()
+                    err = err if isinstance(err, XcdAborted) else XcdAborted(
+                        "persistent 2-means launch gave up a bounded wait (its workgroups were not co-resident): the masks of "
+                        "that call are not the converged ones.")
                 continue
             if int(host[1]) == 1:
                 cls.safe_protocol_seen = True

@@ -21,18 +21,40 @@ def separate_chimera(model, wav, window_size=256, hop_size=64):
     return out
 
 
+_CLUSTER_WS = {}
+
+
 def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
     """Binary deep-clustering masks (B,T,F,2) on the device: threshold at max - db/20, 2-means on the active
-    bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host)."""
+    bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host).
+
+    Default: the active bins are compacted once and all Lloyd iterations run in ONE persistent launch (8 workgroups per
+    utterance meeting at a counter); its waits are bounded, and a wait that gave up is reported like an aborted recurrence
+    (``_XcdStatus``: the owning call is re-run with the launch-per-iteration form, which is also what runs inside
+    ``_XcdPolicy.forced_steps()`` and with ONSSEN_DC_PERSISTENT=0)."""
+    import os
+    from . import _abi
     from .hip import get_lib
+    from .nn._core import _XcdPolicy, _XcdStatus
     lib = get_lib()
     B, T, F, D = emb.shape
     emb, logmag = emb.contiguous(), logmag.contiguous()
-    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, D)
-    ws = torch.empty(nb, dtype=torch.uint8, device=emb.device)
+    nb = int(lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D))
+    key = (emb.device, B, T, F, D)
+    ws = _CLUSTER_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
+        if len(_CLUSTER_WS) >= 4:
+            _CLUSTER_WS.clear()
+        ws = _CLUSTER_WS[key] = torch.zeros(nb, dtype=torch.uint8, device=emb.device)     # status word starts out zero
+    persistent = os.environ.get("ONSSEN_DC_PERSISTENT", "1") == "1" and _XcdPolicy.force_steps == 0
     masks = torch.empty(B, T, F, 2, device=emb.device, dtype=torch.float32)
     lib.dc_cluster(emb.data_ptr(), logmag.data_ptr(), B, T, F, D, float(db_threshold), iters, masks.data_ptr(),
-                   ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+                   ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream,
+                   flags=0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
+    if persistent:
+        _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
 
 

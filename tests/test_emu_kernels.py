@@ -308,14 +308,16 @@ def _two_cluster_embeddings(rng, B, T, F, D, noise=0.15):
     return e.astype(np.float32), feat, lab
 
 
-def test_dc_cluster_masks(lib):
+@pytest.mark.parametrize("D", [20, 12])
+def test_dc_cluster_masks(lib, D):
+    """Launch-per-iteration form of onssen_dc_cluster_f32 (no inter-workgroup waits) against the planted clusters."""
     rng = np.random.default_rng(11)
-    B, T, F, D = 2, 20, 33, 20
+    B, T, F = 2, 20, 33
     emb, feat, lab = _two_cluster_embeddings(rng, B, T, F, D)
-    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, D)
-    ws = np.zeros(nb // 4 + 4, np.float32)
+    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D)
+    ws = aligned_f32(nb // 4 + 4)
     masks = np.full((B, T, F, 2), np.nan, np.float32)
-    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 10, P(masks), P(ws), nb, None)
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 10, P(masks), P(ws), nb, None, flags=_abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
     for b in range(B):
         act = O.dc_active_bins(feat[b])
         assert np.all(masks[b][~act] == 0) and np.all(masks[b][act].sum(-1) == 1)
@@ -330,6 +332,43 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     a = np.frombuffer(mmap.mmap(-1, max(n, 4096)), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
     a[...] = fill
     return a
+
+
+@pytest.mark.parametrize("B,T,F,D", [(2, 20, 33, 20), (3, 9, 40, 12), (9, 5, 33, 20)])
+def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D):
+    """Default form of onssen_dc_cluster_f32: count + order-preserving compaction of the active bins, then ALL Lloyd
+    iterations in one persistent launch whose 8 workgroups per utterance meet at a counter (forked workgroups over shared
+    memory here).  Against the planted clusters, against the launch-per-iteration form, and the compacted rows themselves."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    rng = np.random.default_rng(21)
+    emb0, feat0, lab = _two_cluster_embeddings(rng, B, T, F, D)
+    emb, feat = _shm(emb0.shape), _shm(feat0.shape)
+    emb[...] = emb0; feat[...] = feat0
+    nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D)
+    ws = _shm((nb // 4 + 64,))
+    masks = _shm((B, T, F, 2), fill=np.nan)
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 12, P(masks), P(ws), nb, None)
+    so = lib.dll.onssen_dc_cluster_status_offset(B, D)
+    assert ws.view(np.uint32)[so // 4] == 0
+    # the compacted copy: active rows of every utterance in bin order
+    off = (so + 256 + 255) // 256 * 256 // 4
+    comp = ws[off:off + B * T * F * D].reshape(B, T * F, D)
+    iw = ws.view(np.int32)[(so // 4) - B * 72:so // 4].reshape(B, 72)
+    for b in range(B):
+        act = O.dc_active_bins(feat0[b]).reshape(-1)
+        assert iw[b, 64] == act.sum()
+        np.testing.assert_array_equal(comp[b, :act.sum()], emb0[b].reshape(-1, D)[act])
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "0")
+    ws2 = aligned_f32(nb // 4 + 4)
+    ref = np.full((B, T, F, 2), np.nan, np.float32)
+    lib.dc_cluster(P(emb0), P(feat0), B, T, F, D, 40.0, 12, P(ref), P(ws2), nb, None, flags=_abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
+    for b in range(B):
+        act = O.dc_active_bins(feat0[b])
+        assert np.all(masks[b][~act] == 0) and np.all(masks[b][act].sum(-1) == 1)
+        agree = (masks[b][act][:, 0] == lab[b][act]).mean()
+        assert max(agree, 1 - agree) > 0.995
+        same = (masks[b] == ref[b]).all(-1).mean()
+        assert same > 0.995                      # same initialisation, same fixed point (summation orders differ)
 
 
 # fuse 2: FUSE_IN0 + FUSE_TAIL, F = 33; bf16 1: ONSSEN_BLSTM_BF16 (opt-in plain bf16 products)

@@ -257,7 +257,8 @@ def test_training_step_beside_a_16_workgroup_cotenant_is_bit_identical(dev):
     P = _core._XcdPolicy
     a0, p0 = P.aborts, P.persistent_launches
     side = torch.cuda.Stream()
-    lib.check(lib.dll.onssen_debug_cotenant_spin(odist.RCCL_MAX_CHANNELS, 256, 100 * 30_000, side.cuda_stream), "spin")   # 30 ms
+    # heavy form: >= 112 VGPRs per lane + 32 KB of LDS -- cannot share a CU with a recurrence workgroup, like a collective's kernel
+    lib.check(lib.dll.onssen_debug_cotenant_spin(odist.RCCL_MAX_CHANNELS, 256, 100 * 30_000, 1, side.cuda_stream), "spin")   # 30 ms
     got = grads()
     torch.cuda.synchronize()
     assert P.aborts == a0 and P.persistent_launches > p0

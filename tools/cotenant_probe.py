@@ -35,9 +35,12 @@ mi = onn.deep_clustering(129, 600, 2, 20).to(dev).eval()
 xi = torch.randn(32, 400, 129, device=dev)
 
 
+HEAVY = int(os.environ.get("HEAVY", "1"))      # 1: >= 112 VGPRs + 32 KB LDS per workgroup (needs a CU of its own); 0: shares CUs
+
+
 def spin(k, ms):
     if k > 0:
-        lib.check(lib.dll.onssen_debug_cotenant_spin(k, 256, int(ms * 100_000), side.cuda_stream), "spin")
+        lib.check(lib.dll.onssen_debug_cotenant_spin(k, 256, int(ms * 100_000), HEAVY, side.cuda_stream), "spin")
 
 
 def timed(fn, k, ms):
@@ -66,10 +69,10 @@ def infer():
 
 for _ in range(3):
     train(); infer()
-print("# co-tenant: k workgroups x 256 threads spinning for `ms` on a side stream, launched BEFORE the step")
+print(f"# co-tenant: k workgroups x 256 threads ({'>= 112 VGPRs + 32 KB LDS each' if HEAVY else '2 VGPRs, no LDS'}) spinning for `ms` on a side stream, launched BEFORE the step")
 print("# k   train_step_ms(20ms co-tenant)  aborts   infer_step_ms(20ms co-tenant)  aborts")
 rows = []
-for k in (0, 2, 4, 8, 12, 16, 17, 20, 24, 32, 48, 64, 128):
+for k in (0, 8, 16, 17, 24, 32, 48, 64, 96, 128, 256):
     t_ms, t_ab = min((timed(train, k, 20.0) for _ in range(2)), key=lambda r: r[0])
     i_ms, i_ab = min((timed(infer, k, 20.0) for _ in range(2)), key=lambda r: r[0])
     print(f"{k:4d}   {t_ms:8.2f}                     {t_ab}        {i_ms:8.2f}                     {i_ab}", flush=True)
@@ -79,7 +82,7 @@ fit = max(k for k, t, i in rows if t < base_t * 1.5 and i < base_i * 1.5 + 0.5)
 print(f"# largest probed k that does not delay either step: {fit}  (dist.RCCL_MAX_CHANNELS = {odist.RCCL_MAX_CHANNELS})")
 print("# a co-tenant that outlives the bounded wait (600 ms; default limit ~0.2 s): abort + recovery")
 print("# k   train_step_ms  aborts  recovered_total  persistent_again_next_step")
-for k in (16, 24, 64):
+for k in (24, 64, 256):
     r0 = P.recovered
     t_ms, t_ab = timed(train, k, 600.0)
     torch.cuda.synchronize()
