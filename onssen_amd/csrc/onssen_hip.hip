@@ -1063,19 +1063,19 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
                             per_utt, D, db_threshold, w, stride, OUT_);                                                      \
   } while (0)
   if (persistent) {
-    // active bins compacted once (the same pass finds the second centroid), then ALL Lloyd iterations in one launch per <= 64
-    // utterances (8 workgroups each: co-resident with room to spare)
+    // active bins compacted once (the same pass finds the second centroid), then ALL Lloyd iterations in one launch per <= 32
+    // utterances (km::NBP workgroups of km::LT threads each, one per CU: 256 workgroups fill the chip exactly)
     hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw);
     if (D == 20) hipLaunchKernelGGL((kmeans2_compact_kernel<20>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
     else hipLaunchKernelGGL((kmeans2_compact_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
     // (a wait that gives up leaves status = 1: the host sees it and runs the launch-per-iteration form)
     const unsigned spin = xcd_spin_limit();
-    for (int u0 = 0; u0 < B && iters > 0; u0 += 64) {
-      const int nutt = B - u0 < 64 ? B - u0 : 64;
+    for (int u0 = 0; u0 < B && iters > 0; u0 += 32) {
+      const int nutt = B - u0 < 32 ? B - u0 : 32;
       const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
-      if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(256), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
-      else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(256), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+      if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+      else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
     }
   } else {
     hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);

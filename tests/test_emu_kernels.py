@@ -334,12 +334,14 @@ def _shm(shape, fill=0.0, dtype=np.float32):
     return a
 
 
-@pytest.mark.parametrize("B,T,F,D", [(2, 20, 33, 20), (3, 9, 40, 12), (9, 5, 33, 20)])
-def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D):
+@pytest.mark.parametrize("B,T,F,D,scramble", [(2, 20, 33, 20, "0"), (3, 9, 40, 12, "0"), (9, 5, 33, 20, "0"), (2, 20, 33, 20, "1")])
+def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
     """Default form of onssen_dc_cluster_f32: count + order-preserving compaction of the active bins, then ALL Lloyd
     iterations in one persistent launch whose 8 workgroups per utterance meet at a counter (forked workgroups over shared
     memory here).  Against the planted clusters, against the launch-per-iteration form, and the compacted rows themselves."""
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)     # "1": the parts report different XCDs -> placement-independent accesses
+    lib.dll.onssen_xcd_spin_limit(40000000)   # emulated workgroups are OS processes: be patient
     rng = np.random.default_rng(21)
     emb0, feat0, lab = _two_cluster_embeddings(rng, B, T, F, D)
     emb, feat = _shm(emb0.shape), _shm(feat0.shape)
@@ -354,6 +356,7 @@ def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D):
     off = (so + 256 + 255) // 256 * 256 // 4
     comp = ws[off:off + B * T * F * D].reshape(B, T * F, D)
     iw = ws.view(np.int32)[(so // 4) - B * 72:so // 4].reshape(B, 72)
+    assert all(bool(iw[b, 66] & 0x20000) == (scramble == "1") and (iw[b, 66] & 0xffff) >= 1 for b in range(B))
     for b in range(B):
         act = O.dc_active_bins(feat0[b]).reshape(-1)
         assert iw[b, 64] == act.sum()
@@ -380,7 +383,7 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
     different XCC ids, which must select the placement-independent protocol (status word 281)."""
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
-    monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")   # emulated workgroups are OS processes: be patient
+    lib.dll.onssen_xcd_spin_limit(40000000)   # emulated workgroups are OS processes: be patient
     F, L = (33 if fuse == 2 else 9), 2
     sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
     rng = np.random.default_rng(3)
@@ -616,7 +619,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     from onssen_amd.nn._train import layer_gradients
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
-    monkeypatch.setenv("ONSSEN_XCD_SPIN_LIMIT", "40000000")
+    lib.dll.onssen_xcd_spin_limit(40000000)
     F = 9
     xcd = form == _abi.LSTM_BWD_XCD
     sd = make_state_dict("chimera", F, H, 1, 4, 2, seed=H + ug, gain=2.0)

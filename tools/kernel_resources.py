@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""Build the HIP library with -Rpass-analysis=kernel-resource-usage and print one line per kernel matching a pattern.
+"""Compile the HIP library with -Rpass-analysis=kernel-resource-usage (into a temporary file: the product .so is not touched)
+and print one line per kernel whose mangled name contains a pattern.
   python tools/kernel_resources.py lstm_xcd_kernelILi5 [extra hipcc flags...]"""
-import os, re, subprocess, sys
+import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pat = sys.argv[1] if len(sys.argv) > 1 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-shared", "-fPIC",
-       os.path.join(ROOT, "onssen_amd/csrc/onssen_hip.hip"), "-o", os.path.join(ROOT, "onssen_amd/libonssen_hip.so"),
+       os.path.join(ROOT, "onssen_amd/csrc/onssen_hip.hip"), "-o", os.path.join(tempfile.mkdtemp(prefix="onssen_res_"), "lib.so"),
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
