@@ -175,7 +175,11 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
   const long frames = (long)B * T, pairs = (frames + 1) / 2;       // one wave per pair of frames (one complex transform)
-  const dim3 grid((unsigned)((pairs + 3) / 4)), block(256);
+  // ~3 pairs per wave (the per-lane constants of the transform are built once per wave), but never fewer than 2 workgroups
+  // per CU's worth of workgroups when there is that much work
+  long nblk = (pairs + 11) / 12;
+  if (nblk < 512) nblk = (pairs + 3) / 4 < 512 ? (pairs + 3) / 4 : 512;
+  const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
     hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,

@@ -19,11 +19,28 @@ from ..hip import get_lib
 from ._core import _XcdStatus
 
 
+_CONST = {}       # small index / zero tensors that every backward pass needs again: built once per (shape, device)
+
+
+def _const(key, make):
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = make()
+    return t
+
+
 def packed_columns(H, Hp, ug, device=None):
-    """LongTensor [4H]: packed gate column (layout of G, onssen_hip.h) of nn.LSTM row n = gate*H + u."""
-    n = torch.arange(4 * H, device=device)
-    gate, u = n // H, n % H
-    return (u // ug) * (4 * ug) + (u % ug) * 4 + gate
+    """LongTensor [4H]: packed gate column (layout of G, onssen_hip.h) of nn.LSTM row n = gate*H + u.  (Cached: the five
+    element-wise kernels that build it ran once per layer and direction of every backward pass.)"""
+    def make():
+        n = torch.arange(4 * H, device=device)
+        gate, u = n // H, n % H
+        return (u // ug) * (4 * ug) + (u % ug) * 4 + gate
+    return _const(("cols", H, Hp, ug, str(device)), make)
+
+
+def _zeros(n, device):
+    return _const(("zeros", n, str(device)), lambda: torch.zeros(n, device=device, dtype=torch.float32))
 
 
 def layer_gradients(dP, x_rows, y, w_ih, H, ug):
@@ -86,7 +103,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
         lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1[d].data_ptr(), st)
         # the forward direction looks B rows back, the reverse direction B rows ahead
         lib.x3_image_t(y2[:, d * Hp:].data_ptr(), 2 * Hp, Hp, TB, -B if d == 0 else B, w1[d, Kx:].data_ptr(), st)
-    zero_bias = torch.zeros(max(N1, wih_p.shape[2]), device=dev, dtype=torch.float32)
+    zero_bias = _zeros(max(N1, wih_p.shape[2]), dev)                      # (read-only operand of the GEMMs)
     # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
     direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
     if direct:
@@ -109,19 +126,20 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
         lib.linear_x3p(a.data_ptr(), TB, 2 * NP, w2.data_ptr(), zero_bias.data_ptr(), Kp, 0, 0, 0.0, dx.data_ptr(), 1, Kp, 0, st)
     db2 = db_rows.sum(0) if db_rows is not None else dp2.sum(0)      # (B, 2*NP) row sums left by the backward kernel, or a pass over dP
     cols = packed_columns(H, Hp, ug, dev)
+    cols_d = [cols, _const(("cols+NP", H, Hp, ug, NP, str(dev)), lambda: cols + NP)]     # the bias gradient's index per direction
     if Kx == in_features:
         feat = None
     else:      # padded [fwd(Hp) | rev(Hp)] -> the reference's [fwd(H) | rev(H)]
-        feat = torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)])
+        feat = _const(("feat", H, Hp, str(dev)), lambda: torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)]))
     grads = []
     for d in range(2):
         if direct:
-            grads.append((dW_ih2[d], dW_hh2[d], db2[d * NP + cols]))
+            grads.append((dW_ih2[d], dW_hh2[d], db2[cols_d[d]]))
             continue
         rows = out1[d].index_select(0, cols)                                     # (4H, N1) in nn.LSTM row order
         dW_ih = rows[:, :Kx] if feat is None else rows[:, :Kx].index_select(1, feat)
         dW_hh = rows[:, Kx:Kx + H]
-        grads.append((dW_ih.contiguous(), dW_hh.contiguous(), db2[d * NP + cols]))
+        grads.append((dW_ih.contiguous(), dW_hh.contiguous(), db2[cols_d[d]]))
     return dx, grads
 
 
@@ -275,7 +293,7 @@ def linear_x3_backward(lib, st, dy, x2d, weight, need_dx=True):
     M, N = dy.shape
     K = x2d.shape[1]
     dev = dy.device
-    zero = torch.zeros(max(N, K), device=dev, dtype=torch.float32)
+    zero = _zeros(max(N, K), dev)
     dx = None
     if need_dx:
         wt = torch.empty(K, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)

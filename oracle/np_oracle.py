@@ -116,6 +116,34 @@ def istft(spec_tf, hop, length):
     return np.pad(y, (0, length - len(y)))
 
 
+def istft_f32_ola(spec_tf, hop, length):
+    """The same inverse transform with librosa 0.7 / 0.8's dtype rule followed LITERALLY (``istft(..., dtype=np.float32)``, the
+    default the reference's call sites take): ``numpy.fft.irfft`` yields float64 frames, ``ifft_window * irfft`` stays float64,
+    but the output buffer ``y`` and the window sum-of-squares are float32 arrays, so every ``y[s:s+n_fft] += ytmp[:, frame]`` of
+    the overlap-add rounds to float32, ``window_sumsquare(..., dtype=float32)`` accumulates ``w**2`` in float32, and the final
+    ``y[nz] /= wss[nz]`` is a float32 division.  Returns float32.  ``istft`` above is the same arithmetic with float64
+    accumulation; the two differ by a few float32 ulps of the signal scale, and the HIP kernel (float32 frames, the <= 4
+    overlapping ones added in float64) must lie within that distance of BOTH (tests/test_oracle.py, tests/test_gpu_parity.py)."""
+    spec_tf = np.asarray(spec_tf)
+    T, F = spec_tf.shape
+    n_fft = 2 * (F - 1)
+    w = hann_periodic(n_fft)
+    exp_len = n_fft + hop * (T - 1)
+    y = np.zeros(exp_len, dtype=np.float32)
+    wss = np.zeros(exp_len, dtype=np.float32)
+    frames = w[None, :] * np.fft.irfft(spec_tf.astype(np.complex64), n=n_fft, axis=1)     # float64, like numpy.fft in librosa
+    win_sq = (w * w)
+    for t in range(T):
+        y[t * hop:t * hop + n_fft] += frames[t]                  # float32 += float64 -> rounds to float32 each time
+        wss[t * hop:t * hop + n_fft] += win_sq
+    nz = wss > np.finfo(np.float32).tiny
+    y[nz] /= wss[nz]
+    y = y[n_fft // 2:]
+    if len(y) >= length:
+        return y[:length]
+    return np.pad(y, (0, length - len(y)))
+
+
 def mask_istft(stft_mix, masks, hop, length):
     """egs/wsj0-2mix/chimera/evaluate.py:34-43 (and deep_clustering/
     evaluate.py:31-45 after the masks are built): ``stft_est = stft_mix *

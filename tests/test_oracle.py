@@ -100,6 +100,23 @@ def test_istft_against_torch_and_roundtrip(n_fft, hop, n):
     assert np.abs(parts.sum(0) - y).max() < 1e-6
 
 
+@pytest.mark.parametrize("n_fft,hop,n", [(256, 64, 25536), (512, 128, 16000), (256, 100, 4000)])
+def test_istft_float32_overlap_add_variant(n_fft, hop, n):
+    """``istft_f32_ola`` follows librosa 0.7 / 0.8's dtype rule literally (float32 output buffer and window
+    sum, float64 frames): it must agree with the float64-accumulating restatement to a few float32 ulps of the signal scale --
+    the band inside which the HIP kernel's output is then required to lie (tests/test_gpu_parity.py)."""
+    sig = synth_mixture(9, n)
+    X = O.stft(sig, n_fft, hop)
+    rng = np.random.default_rng(1)
+    Xm = (X * rng.random(X.shape)).astype(np.complex64)
+    y64, y32 = O.istft(Xm, hop, n), O.istft_f32_ola(Xm, hop, n)
+    assert y32.dtype == np.float32 and y32.shape == y64.shape
+    scale = np.abs(y64).max()
+    inner = slice(n_fft, n - n_fft)            # (the edges divide by a small window sum: compare where it is ~1.5)
+    assert np.abs(y32[inner] - y64[inner]).max() <= 4 * np.finfo(np.float32).eps * scale
+    assert np.abs(y32 - y64).max() <= 1e-5 * scale
+
+
 def test_istft_longer_than_signal_pads_with_zeros():
     X = O.stft(synth_mixture(1, 2000), 256, 64)
     y = O.istft(X, 64, 2600)
