@@ -43,6 +43,13 @@ class XcdAborted(_abi.OnssenError):
     re-run that call on the launch-per-step / ATen recurrence (``_XcdPolicy``); a bare ``model(x)`` raises it."""
 
 
+class XcdNonFinite(XcdAborted):
+    """ONSSEN_NONFINITE=propagate: a NaN / Inf reached the persistent recurrence (it cannot pass the tagged exchange and was
+    replaced by 0).  Raised INSTEAD of the plain error so that the entry points that re-run aborted calls re-run this one on
+    the launch-per-step recurrence, which propagates non-finite values exactly like nn.LSTM does (the reference's
+    semantics: NaN in, NaN out).  Not an abort: no back-off."""
+
+
 class _XcdPolicy:
     """What happens after an aborted persistent launch (a co-tenant kernel held more than the 2 spare CUs of an XCD for
     longer than the bounded wait, two persistent launches overlapped, ...): the abort is *per launch*, not a property of
@@ -110,7 +117,8 @@ def recovering(fn):
             return fn(*args, **kwargs)
         except XcdAborted as e:
             _XcdPolicy.recovered += 1
-            warnings.warn(f"onssen_amd: {e}  Re-running this call on the launch-per-step recurrence.", RuntimeWarning)
+            if not isinstance(e, XcdNonFinite):
+                warnings.warn(f"onssen_amd: {e}  Re-running this call on the launch-per-step recurrence.", RuntimeWarning)
             with _XcdPolicy.forced_steps():
                 return fn(*args, **kwargs)
     return wrapper
@@ -212,11 +220,16 @@ class _XcdStatus:
                     err = err if isinstance(err, XcdAborted) else XcdAborted(
                         f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
                         "(and, in training, the gradients) of that call are invalid.")
+                elif os.environ.get("ONSSEN_NONFINITE", "raise") == "propagate":
+                    err = err or XcdNonFinite(
+                        "non-finite activations inside the persistent recurrence: re-run on the launch-per-step recurrence, "
+                        "which propagates them like nn.LSTM (ONSSEN_NONFINITE=propagate).")
                 else:
                     err = err or _abi.OnssenError(
                         "non-finite activations inside the persistent recurrence (NaN / Inf in the input or the weights): "
                         "they cannot pass its tagged exchange and were replaced by 0, so the outputs of that call are not the "
-                        "reference's NaNs.  ONSSEN_XCD=0 (launch per step) propagates them like nn.LSTM.")
+                        "reference's NaNs.  ONSSEN_XCD=0 (launch per step) propagates them like nn.LSTM; ONSSEN_NONFINITE=propagate "
+                        "makes separate_* / tester.eval / train_step re-run such a call that way by themselves.")
         cls.pending = keep
         if err is not None:
             raise err

@@ -15,12 +15,12 @@ except Exception as e:
 PY
 }
 BENCH_ARGS="" run dc_l2_bf16x3 A=1
-BENCH_ARGS="--config dc_l2 --precision f32 --no-cpu-baseline" run dc_l2_f32 A=1
-BENCH_ARGS="--config dc_l2 --no-cpu-baseline" run dc_l2_bf16x3_steps ONSSEN_XCD=0
-BENCH_ARGS="--config dc_l3 --no-cpu-baseline" run dc_l3 A=1
-BENCH_ARGS="--config chimera_l4 --no-cpu-baseline" run chimera_l4 A=1
-BENCH_ARGS="--config phase_l4 --no-cpu-baseline" run phase_l4 A=1
-BENCH_ARGS="--config dc_l2 --precision bf16 --no-cpu-baseline" run dc_l2_bf16_optin A=1
+BENCH_ARGS="--config dc_l2 --precision f32 --no-cpu-baseline --no-extra" run dc_l2_f32 A=1
+BENCH_ARGS="--config dc_l2 --no-cpu-baseline --no-extra" run dc_l2_bf16x3_steps ONSSEN_XCD=0
+BENCH_ARGS="--config dc_l3 --no-cpu-baseline --no-extra" run dc_l3 A=1
+BENCH_ARGS="--config chimera_l4 --no-cpu-baseline --no-extra" run chimera_l4 A=1
+BENCH_ARGS="--config phase_l4 --no-cpu-baseline --no-extra" run phase_l4 A=1
+BENCH_ARGS="--config dc_l2 --precision bf16 --no-cpu-baseline --no-extra" run dc_l2_bf16_optin A=1
 for cfg in "1 3" "0 3" "1 2"; do
   set -- $cfg; mode=$1; layers=$2
   ONSSEN_TRAIN_HIP=$mode timeout 300 python tools/train_step_bench.py --layers $layers --steps 10 --warmup 3 2> gpurun_out/train_${mode}_l$layers.err < /dev/null | tail -1 > gpurun_out/train_hip${mode}_l$layers.json
@@ -32,5 +32,7 @@ timeout 200 python tools/xcd_soak.py 2>&1 < /dev/null | tail -2 | cut -c1-400 | 
 cd /tmp; timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_train -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --layers 3 --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_train.log 2>&1 < /dev/null; cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f gpurun_out/train_kernel_stats.csv; fi
 find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
+HEAVY=1 timeout 200 python tools/cotenant_probe.py > gpurun_out/cotenant_probe.txt 2>/dev/null; tail -12 gpurun_out/cotenant_probe.txt
+timeout 100 python tools/cluster_probe.py 2>/dev/null | head -3 | cut -c1-200 | tee gpurun_out/cluster_probe.txt
 bash tools/profile_round.sh $tag > gpurun_out/profile_round.log 2>&1
 head -9 gpurun_out/prof_$tag/kernel_stats.csv | cut -c1-170

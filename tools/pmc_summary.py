@@ -12,7 +12,7 @@ for fn in glob.glob(f"{root}/pmc_*/**/*counter_collection.csv", recursive=True):
         name = r.get("Kernel_Name", "")[:40]
         acc[name][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
 for name, cs in sorted(acc.items()):
-    if not any(k in name for k in ("lstm", "linear", "stft", "istft")):
+    if not any(k in name for k in ("lstm", "linear", "stft", "istft", "kmeans")):
         continue
     print(name)
     for c, v in sorted(cs.items()):

@@ -6,9 +6,9 @@ root=$PWD/gpurun_out/prof_$tag
 mkdir -p $root
 export TMPDIR=/tmp
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-extra"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/stats -- $B > $root/stats.log 2>&1
-P="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline"
+P="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-extra"
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   i=$((i+1))
