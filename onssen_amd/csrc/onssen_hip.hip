@@ -925,7 +925,7 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
 }
 
 size_t onssen_bn_rows_workspace_bytes(int64_t M, int C) {
-  return M > 0 && C > 0 ? (size_t)((M + bnr::STRIP - 1) / bnr::STRIP) * 2 * (size_t)C * sizeof(float) : 0;
+  return M > 0 && C > 0 ? (size_t)((M + bnr::STRIP - 1) / bnr::STRIP) * 3 * (size_t)C * sizeof(float) : 0;   // (count-free strip sums + shift)
 }
 
 int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float* y,

@@ -46,7 +46,9 @@ class SyntheticWsj02mix:
             mix, s1, s2 = synth_mixture(self.seed + it, n, self.sampling_rate, return_sources=True)
             gap = 32 - n % 32                                                          # get_sigs (wsj0_2mix.py:216-228)
             pad = lambda a: np.pad(a, (0, gap))
-            wav = torch.from_numpy(pad(mix)[None]).to(self.device)
+            # the STFT of the file AS IT IS (get_stft(fn), wsj0_2mix.py:231-233); only the reference signals are padded to a
+            # multiple of 32 samples (get_sigs, :216-228) -- the estimate is then istft(..., length = padded length)
+            wav = torch.from_numpy(np.ascontiguousarray(mix)[None]).to(self.device)
             logmag, ri = stft_logmag(wav, self.window_size, self.hop_size)
             sig_ref = torch.from_numpy(np.stack([pad(s1), pad(s2)])[None]).to(self.device)
             yield [logmag], [ri[..., 0].contiguous(), ri[..., 1].contiguous(), sig_ref]

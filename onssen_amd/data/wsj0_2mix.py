@@ -103,7 +103,9 @@ class Wsj02mixFiles:
             mix, s1, s2 = (_load(f, self.sampling_rate) for f in self._sources(fn))
             gap = 32 - len(mix) % 32
             pad = lambda a: np.pad(a, (0, gap))
-            wav = torch.from_numpy(pad(mix)[None]).to(self.device)
+            # the STFT of the file AS IT IS (get_stft(fn), wsj0_2mix.py:231-233); only the reference signals are padded to a
+            # multiple of 32 samples (get_sigs, :216-228) -- the estimate is then istft(..., length = padded length)
+            wav = torch.from_numpy(np.ascontiguousarray(mix)[None]).to(self.device)
             logmag, ri = stft_logmag(wav, self.window_size, self.hop_size)
             sig_ref = torch.from_numpy(np.stack([pad(s1), pad(s2)])[None]).to(self.device)
             yield [logmag], [ri[..., 0].contiguous(), ri[..., 1].contiguous(), sig_ref]

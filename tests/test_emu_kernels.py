@@ -850,3 +850,9 @@ def test_bn_rows_train_forward_and_gradient(lib, M, C):
     np.testing.assert_allclose(dbeta, bn.bias.grad.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(dgamma, bn.weight.grad.numpy(), rtol=2e-5, atol=5e-5)
     assert np.abs(dx - xt.grad.numpy()).max() <= 3e-5 * max(np.abs(xt.grad.numpy()).max(), 1e-3)
+    # channels whose |mean| is far larger than their spread -- E[x^2] - mean^2 in fp32 cancels (relative error
+    # ~1e-7 * mean^2 / var = 1e-1 here); the shifted strip sums merged with Chan's formula do not
+    x2 = (rand(rng, M, C) * 1e-2 + 10.0 + np.arange(C, dtype=np.float32)[None, :]).astype(np.float32)
+    lib.bn_rows_train(P(x2), M, C, P(gamma), P(beta), 0.0, P(y), P(mean), P(invstd), P(ws), ws.nbytes, None)
+    np.testing.assert_allclose(mean, x2.astype(np.float64).mean(0), rtol=1e-6)
+    np.testing.assert_allclose(1 / invstd.astype(np.float64) ** 2, x2.astype(np.float64).var(0), rtol=2e-4)
