@@ -436,7 +436,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     x3 = bool(flags & 2)
     bf16_only = bool(flags & _abi.BLSTM_BF16)          # opt-in plain bf16 products
     ebf = _abi.EPI_BF16 if bf16_only else 0
-    wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if x3 else pk.wih
+    images = bool(flags & _abi.BLSTM_XCD) and x3   # activations travel as x3 images, GEMMs run on pre-split operands
+    wih = pk.wih_img if images else pk.wih_x3 if x3 else pk.wih
     whh = pk.whh_x3 if x3 else pk.whh
 
     def lin(A, a_s0, a_s1, K, Wf, ldf, W3, ld3, bias, N, mode, group, out_ptr, c_s0, c_s1):
@@ -452,7 +453,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     st = _stream   # evaluated at call time: under graph capture the current stream is the capture stream
     lyr = 1 if L > 1 else 0          # time a layer with the steady-state shape (in = 2H) when there is one
     # XCD form: like the stack, the layer leaves only its x3 image (no fp32 rows: the heads read the image)
-    y_ptr = None if flags & _abi.BLSTM_XCD else y.data_ptr()
+    y_ptr = None if images else y.data_ptr()
 
     def layer():
         if lyr == 0:
@@ -467,7 +468,6 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     gbuf = ws[_abi.BLSTM_WS_HEADER:]
     F4, F32 = (F + 3) // 4 * 4, (F + 31) // 32 * 32
     K1, K132 = 2 * Hp, (2 * Hp + 31) // 32 * 32
-    images = bool(flags & _abi.BLSTM_XCD)   # activations travel as x3 images, GEMMs run on pre-split operands
     hd = model._head_dc if kind == "chimera" else model._head
     hp = hd.get(Hp)
     out = torch.empty(B, T, hp.N, device=dev)
@@ -542,7 +542,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
 
     t_layer, t_gin, t_g0, t_head = timed(layer), timed(gemm_in), timed(gemm0), timed(head)
     t_img = timed(image_in) if images and lyr else 0.0         # (for lyr == 0 the split is part of gemm0 = gemm_in)
-    if images:
+    if flags & _abi.BLSTM_XCD:
         # the recurrence kernel BY ITSELF: the same call with ONSSEN_BLSTM_G_READY -- G is what `layer` left in the workspace,
         # no split, no GEMM.  (Rounds 1-2 reported t_layer - t_gin - t_img, which overstated the kernel by ~6 %.)
         def rec_only():
@@ -593,7 +593,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
                           "fc_dc_l2norm": t_head * 1e3},
            "share_of_step_ms": (t_g0 + (L - 1) * t_gin * (1 if lyr else 0) + t_head) * 1e3}
     rec["other_kernels"] = gem
-    rec["recurrence_timing"] = "direct (ONSSEN_BLSTM_G_READY call, HIP events around hipGraph replays)" if images else "by difference"
+    rec["recurrence_timing"] = "direct (ONSSEN_BLSTM_G_READY call, HIP events around hipGraph replays)" if xcd else "by difference"
     rec["layer_call_ms"] = t_layer * 1e3
     rec["hbm_kernels"] = {
         "stft_logmag_kernel": {"ms": t_stft * 1e3, "algorithmic_bytes": stft_bytes, "achieved_GBs": stft_bytes / t_stft / 1e9,

@@ -60,7 +60,12 @@ extern "C" {
                                      onssen_linear_x3p) written by the recurrence epilogue: wih_p_host[l] must be the
                                      x3 image (onssen_x3_image_f32) of the packed [2*NP][K_l] input-projection
                                      matrix, and the last layer's output image stays in the workspace for the
-                                     heads (onssen_blstm_y_image). */
+                                     heads (onssen_blstm_y_image).
+                                     WITHOUT ONSSEN_BLSTM_BF16X3 (round 3): the same persistent launch in EXACT fp32
+                                     (v_mfma_f32_16x16x4_f32; h exchanged as tagged fp32 words): wih_p_host / whh_p_host /
+                                     bias_p_host are the fp32 arrays of onssen_lstm_pack_f32 (as for the launch-per-step
+                                     form), G comes from the exact-fp32 GEMM, the layers hand fp32 rows to each other,
+                                     y must not be NULL; same limits (H <= 640, ug <= 20). */
 #define ONSSEN_BLSTM_FUSE_IN0 16   /* (with XCD, in_dim <= 128, or = 129 with FUSE_TAIL) the first layer's input projection is computed inside its
                                      recurrence launch: wih_p_host[0] must be the B-fragment image made by
                                      onssen_lstm_pack_wih_bf16x3 of the layer's two W_ih, back to back; no G is

@@ -722,14 +722,16 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     }
     if (rc != ONSSEN_OK) return rc;
     if (flags & ONSSEN_BLSTM_XCD) {
-      if (!x3 || ug > 20 || Hp / ug > 32 || KQ2 > 20) return ONSSEN_E_ARG;
+      // without ONSSEN_BLSTM_BF16X3: the exact-fp32 instantiation (whh_p_host[l] = the fp32 fragment image of
+      // onssen_lstm_pack_f32, G from the exact-fp32 GEMM above, fp32 rows between the layers)
+      if (ug > 20 || Hp / ug > 32 || KQ2 > 20 || (!x3 && (save_g || save_c))) return ONSSEN_E_ARG;
       // bounded waits: ~0.2 s of polling on the GPU; ONSSEN_XCD_SPIN_LIMIT overrides (the host-side emulation, where a
       // 'workgroup' is a process at the mercy of the OS scheduler, raises it)
       const unsigned xcd_spin = xcd_spin_limit();
       XcdArgs xa;
       // fp32 rows only where somebody reads them (the caller's y); every layer leaves its x3 image
-      xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = l == L - 1 ? y : nullptr; xa.hx = hsb; xa.sync = syncw; xa.B = B;
-      xa.yimg = img_ab[(L - 1 - l) % 2]; xa.KBI = ceil_div(2 * Hp, 32);
+      xa.G = G; xa.whh = (const unsigned short*)whh_p_host[l]; xa.y = x3 ? (l == L - 1 ? y : nullptr) : yout; xa.hx = hsb; xa.sync = syncw; xa.B = B;
+      xa.yimg = x3 ? img_ab[(L - 1 - l) % 2] : nullptr; xa.KBI = ceil_div(2 * Hp, 32);
       xa.wih0 = fuse0 ? (const unsigned short*)wih_p_host[0] : nullptr; xa.ximg = img_x; xa.bias0 = bias_p_host[0];
       xa.KC0 = fuse0 ? ceil_div(in_dim, 32) : 0;
       // in_dim = 32k + 1 (F = 129): the lone last column goes to the VALU; its weights follow the bias (FUSE_TAIL)
@@ -737,7 +739,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       xa.KCM = vtail ? xa.KC0 - 1 : xa.KC0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
       xa.wtail = vtail ? bias_p_host[0] + 2 * NP : nullptr;
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 8;
-      xa.terms = bf16_only ? 1 : 3;
+      xa.terms = !x3 ? 0 : bf16_only ? 1 : 3;
       xa.save_g = save_g; xa.save_c = save_c;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup (K is split over them): 8 = two per SIMD; ONSSEN_XCD_WAVES=4 keeps the one-per-SIMD form for comparison

@@ -127,8 +127,9 @@ def recovering(fn):
 def recurrence_plan(B, H):
     """(ug, flags) for onssen_blstm_forward_f32.
 
-    Split-bf16 precision and H <= 640: the XCD-local persistent recurrence (one launch per layer, every
-    (direction, 16-row group) inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)).  Otherwise one
+    H <= 640: the XCD-local persistent recurrence (one launch per layer, every (direction, 4 / 8 / 16-row group)
+    inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)) -- split-bf16 / bf16 products on x3 images, or
+    (precision f32, round 3) exact-fp32 MFMAs on fp32 images.  Otherwise one
     launch per time step with 8 hidden units per workgroup.  ONSSEN_XCD=0 forces the per-step form (so does a
     ``_XcdPolicy.forced_steps()`` scope or a back-off after consecutive aborts), ONSSEN_UG overrides its unit-group
     size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
@@ -136,7 +137,8 @@ def recurrence_plan(B, H):
     x3 = _split_bf16() and H <= 640
     if x3:
         flags |= _abi.BLSTM_BF16X3
-    if x3 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed():
+    if H <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed():
+        # (precision f32: the same persistent launch in exact fp32 -- flags carry BLSTM_XCD without BLSTM_BF16X3)
         if precision() == "bf16":
             flags |= _abi.BLSTM_BF16
         return 4 * -(-H // 128), flags | _abi.BLSTM_XCD
@@ -500,7 +502,8 @@ def heads_take_image(B, H, groups=()):
     """True when this forward's heads can all read the recurrence's x3 output image (XCD form, no residual, L2-norm
     groups of 20 / 40 / 80): the caller may then pass ``need_y=False`` and the fp32 rows are never written."""
     _, flags = recurrence_plan(B, H)
-    return bool(flags & _abi.BLSTM_XCD) and all(g % 4 == 0 and 80 % g == 0 and 80 // g <= 4 for g in groups)
+    return (bool(flags & _abi.BLSTM_XCD) and bool(flags & _abi.BLSTM_BF16X3)
+            and all(g % 4 == 0 and 80 % g == 0 and 80 // g <= 4 for g in groups))
 
 
 def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
@@ -520,12 +523,13 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     nbytes = lib.blstm_workspace_bytes(B, T, In, p.hidden_size, p.num_layers, pk.ug)
     wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
-    wih = pk.wih_img if flags & _abi.BLSTM_XCD else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
+    images = bool(flags & _abi.BLSTM_XCD) and bool(flags & _abi.BLSTM_BF16X3)     # activations travel as x3 images
+    wih = pk.wih_img if images else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
     bias = pk.bias
     # measured (dc / chimera, H=600): +2.7 % at B=64, +0.7 % at B=32, -3 % at B=16 -- the fused MFMAs cost every
     # time step the same, the GEMM they replace shrinks with the batch
     fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
-    if flags & _abi.BLSTM_XCD and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 32)):
+    if images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 32)):
         flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
         wih = [pk.wih_frag0] + list(wih[1:])
         if pk.bias0_tail is not None:
@@ -534,16 +538,17 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
-                      [t.data_ptr() for t in bias], y.data_ptr() if need_y or not flags & _abi.BLSTM_XCD else None,
+                      [t.data_ptr() for t in bias], y.data_ptr() if need_y or not images else None,
                       wsb.data_ptr(), wsb.numel(), flags, _stream())
-    if _split_bf16() and p.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
+    if p.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
         _XcdPolicy.note_launch(bool(flags & _abi.BLSTM_XCD))
     y.x3_image = None
-    y.fp32_valid = bool(need_y or not flags & _abi.BLSTM_XCD)
-    if flags & _abi.BLSTM_XCD:
+    y.fp32_valid = bool(need_y or not images)
+    if images:
         # the last layer's output also sits in the workspace as an x3 image: the heads' GEMM operand
         off, _ = lib.blstm_y_image(B, T, In, p.hidden_size, p.num_layers, pk.ug)
         y.x3_image = (wsb, off)                        # keeps the workspace alive with y
+    if flags & _abi.BLSTM_XCD:
         _XcdStatus.post(wsb)
         if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
             _XcdStatus.flush()

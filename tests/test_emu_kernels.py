@@ -440,6 +440,45 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
+@pytest.mark.parametrize("H,ug,B,T,scramble", [(8, 4, 3, 4, "0"), (24, 8, 17, 3, "0"), (40, 20, 5, 5, "0"), (24, 8, 6, 3, "1")])
+def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
+    """ONSSEN_BLSTM_XCD WITHOUT ONSSEN_BLSTM_BF16X3 (round 3): the persistent recurrence in exact fp32 -- fp32 fragment
+    images of onssen_lstm_pack_f32, v_mfma_f32_16x16x4_f32, h handed on as fp32 words tagged in bit 30, fp32 rows between
+    the layers -- against the oracle at fp32 tolerance; scrambled XCC ids select the placement-independent accesses."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
+    lib.dll.onssen_xcd_spin_limit(40000000)
+    F, L = 9, 2
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug + 1, gain=2.0)
+    rng = np.random.default_rng(4)
+    x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    wih, whh, bias = [], [], []
+    for l in range(L):
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a, b, c = _shm((2, NP, Kp)), _shm((2, we)), _shm((2, NP))
+        for d, sfx in enumerate(("", "_reverse")):
+            srcs = []
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                v = sd[f"rnn.{n}_l{l}{sfx}"]
+                sv = _shm(v.shape); sv[...] = v
+                srcs.append(sv)
+            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
+                          P(a[d]), P(b[d]), P(c[d]), None)
+        wih.append(a), whh.append(b), bias.append(c)
+    ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
+    y = _shm((T, B, 2, Hp), fill=np.nan)
+    lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh], [P(a) for a in bias],
+                      P(y), P(ws), ws.nbytes, _abi.BLSTM_XCD, None)
+    status = ws.view(np.uint32)
+    assert status[280] == 0, f"launch aborted (code {status[280]})"
+    assert status[281] == (1 if scramble == "1" else 0) and status[282] == 0
+    ref = O.blstm_stack(np.array(x), sd, "rnn.", L)
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    assert np.abs(got - ref).max() < 3e-6
+    assert np.all(np.array(y)[:, :, :, H:] == 0)
+
+
 def test_blstm_xcd_eight_wave_variant():
     """ONSSEN_XCD_WAVES=8 (two waves per SIMD, 256 flags per group) is read once per process: run the persistent-
     recurrence test in a child interpreter with it set."""

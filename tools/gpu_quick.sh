@@ -1,9 +1,5 @@
 #!/bin/bash
 # Scratch wrapper for one gpurun call while iterating (edit freely).
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "stft or istft or e2e or separ or smoke or cfg5 or loader" 2>&1 | tail -3
-timeout 300 python bench.py --no-cpu-baseline --no-extra > gpurun_out/bench_fft.json 2>/dev/null; python - <<'PY'
-import json
-r=json.loads(open('gpurun_out/bench_fft.json').read().strip().splitlines()[-1])
-print("headline", r["ms_per_step"], r["roofline"]["hbm_kernels"], r["roofline"]["legs_sum_ms"])
-PY
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -6 gpurun_out/pytest_gpu.log
+for p in f32; do for x in 1 0; do echo "precision=$p XCD=$x"; ONSSEN_XCD=$x timeout 200 python bench.py --precision $p --no-cpu-baseline --no-extra --steps 20 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'], r['roofline']['us_per_time_step'], r['roofline']['frac'], r['config']['recurrence'], r['roofline']['legs_ms'])"; done; done
