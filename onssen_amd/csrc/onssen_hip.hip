@@ -175,9 +175,10 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
   const long frames = (long)B * T, pairs = (frames + 1) / 2;       // one wave per pair of frames (one complex transform)
-  // ~3 pairs per wave (the per-lane constants of the transform are built once per wave), but never fewer than 2 workgroups
+  // ~4 pairs per wave (the per-lane constants of the transform are built once per wave), but never fewer than 2 workgroups
   // per CU's worth of workgroups when there is that much work
-  long nblk = (pairs + 11) / 12;
+  static const int ppw = ONSSEN_KNOB_INT("ONSSEN_STFT_PPW", 4);      // pairs per wave (debug builds: tools/ab_variants.py)
+  long nblk = (pairs + 4 * ppw - 1) / (4 * ppw);
   if (nblk < 512) nblk = (pairs + 3) / 4 < 512 ? (pairs + 3) / 4 : 512;
   const dim3 grid((unsigned)nblk), block(256);
   hipStream_t st = (hipStream_t)stream;
