@@ -1078,8 +1078,16 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
     // (a wait that gives up leaves status = 1: the host sees it and runs the launch-per-iteration form)
     const unsigned spin = xcd_spin_limit();
-    for (int u0 = 0; u0 < B && iters > 0; u0 += 32) {
-      const int nutt = B - u0 < 32 ? B - u0 : 32;
+    // one workgroup per CU: as many utterances per launch as the device has CUs / NBP (32 on a whole MI355X; fewer in a
+    // partitioned mode -- a launch that cannot be co-resident would only be caught by its bounded waits)
+    static const int lloyd_utts = [] {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+      const int n = cus / km::NBP;
+      return n < 1 ? 1 : n > 32 ? 32 : n;
+    }();
+    for (int u0 = 0; u0 < B && iters > 0; u0 += lloyd_utts) {
+      const int nutt = B - u0 < lloyd_utts ? B - u0 : lloyd_utts;
       const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
       if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
       else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
