@@ -11,13 +11,19 @@ OUT = os.path.join(ROOT, "tests", "emu", "libonssen_emu.so")
 
 
 def build_emu():
+    # ONSSEN_EMU_CXXFLAGS="-D..." builds an experiment variant of the same source into its own file
+    global OUT
+    extra = os.environ.get("ONSSEN_EMU_CXXFLAGS", "").split()
+    if extra:
+        import hashlib
+        OUT = os.path.join(ROOT, "tests", "emu", "libonssen_emu_%s.so" % hashlib.md5(" ".join(extra).encode()).hexdigest()[:8])
     csrc = os.path.dirname(SRC)
     parts = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]   # one TU, several files
     newest = max(os.path.getmtime(f) for f in parts + HDRS)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-I",
                                os.path.join(ROOT, "tests", "emu", "include"), "-pthread", "-shared", "-fPIC",
-                               SRC, "-o", OUT])
+                               SRC, "-o", OUT] + extra)
     return OUT
 
 
