@@ -9,10 +9,13 @@
 //                       bias | sigmoid | grouped L2-norm), linear_x3_kernel / linear_kernel (fp32-A forms, exact-fp32 MFMA),
 //                       x3_image(_t)_kernel (fp32 -> split-bf16 operand images)
 //   lstm.inc            lstm_xcd_kernel (K4, default: XCD-local persistent recurrence, ONE launch per layer, data-tagged h
-//                       exchange through the XCD's L2), lstm_step_kernel (one launch per time step: fallback and f32 mode)
+//                       exchange through the XCD's L2; split-bf16 / bf16 / exact-fp32 instantiations), lstm_step_kernel (one
+//                       launch per time step: H > 640 and the re-run of an aborted call)
 //   lstm_bwd.inc        lstm_xcd_bwd_kernel / lstm_bwd_step_kernel (training: backward recurrence)
-//   labels_cluster.inc  labels_kernel (training labels), kmeans2_* (deep-clustering back end)
-//   loss_sdr.inc        loss_dc_* (value and gradient) / loss_mask_* (value), sdr_* (batch SI-SDR with best permutation, fp64 sums)
+//   labels_cluster.inc  labels_kernel (training labels), kmeans2_* (deep-clustering back end: compaction of the active bins, all
+//                       Lloyd iterations in one persistent launch with register-resident rows; launch-per-iteration fallback)
+//   loss_sdr.inc        loss_dc_* (value and gradient) / loss_mask_* (chimera mask term: value, winning assignment, gradient),
+//                       sdr_* (batch SI-SDR with best permutation, fp64 sums)
 //   pack.inc            one-off weight re-layout (gate permutation, MFMA fragment order, BatchNorm fold); training glue: dropout,
 //                       row-wise L2 normalisation and train-mode BatchNorm with their backward passes
 #include <hip/hip_runtime.h>
