@@ -553,6 +553,19 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         t_rec = timed(rec_only)
     else:
         t_rec = t_layer - t_gin - t_img                        # launch-per-step forms: by difference
+    # does the step fuse the first layer's projection into its recurrence launch (run_blstm's rule)?  Then layer 0 is ONE call:
+    # the feature split + the fused recurrence, and the layer-0 GEMM below is not part of the step
+    fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
+    fused0 = bool(images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)))
+    t_l0f = None
+    if fused0:
+        fl = flags | _abi.BLSTM_FUSE_IN0 | (_abi.BLSTM_FUSE_TAIL if pk.bias0_tail is not None else 0)
+        b0 = pk.bias0_tail if pk.bias0_tail is not None else pk.bias[0]
+
+        def layer0_fused():
+            lib.blstm_forward(xin.data_ptr(), xin.stride(0), xin.stride(1), B, T, F, H, 1, ug, [pk.wih_frag0.data_ptr()],
+                              [whh[0].data_ptr()], [b0.data_ptr()], y_ptr, ws.data_ptr(), ws.numel(), fl, st())
+        t_l0f = timed(layer0_fused)
     # front / back end by themselves (HBM-bound rows of SURVEY 8d)
     from onssen_amd.features import mask_istft
     lm_ri = stft_logmag(wav, NFFT, HOP)
@@ -584,7 +597,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
                          "latency -- not MFMA issue or HBM; see DESIGN.md section 3",
            "us_per_launch": t_rec / launches * 1e6, "us_per_time_step": t_rec / T * 1e6,
            "launches_per_step": launches * L, "algorithmic_flop_per_launch": flop_rec / launches,
-           "unit_group": ug, "share_of_step_ms": t_rec * L * 1e3}
+           "unit_group": ug, "share_of_step_ms": (t_rec * (L - 1) + t_l0f if fused0 and lyr else t_rec * L) * 1e3}
     gem = {"kernel": "linear_x3q_kernel (onssen_linear_x3p; 256x320 / 256x256 tiles, LDS-DMA staging)" if images else "linear_x3_kernel" if x3 else "linear_kernel", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
            "achieved_by_call": {"input_proj_l0": 2.0 * B * T * 8 * H * F / t_g0 / 1e12,
                                 "input_proj_l1": (flop_gin / t_gin / 1e12) if lyr else None,
@@ -601,7 +614,16 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         "mask_istft_kernel": {"ms": t_istft * 1e3, "algorithmic_bytes": istft_bytes, "achieved_GBs": istft_bytes / t_istft / 1e9,
                               "frac_of_hbm_peak": istft_bytes / t_istft / 1e9 / HBM_PEAK_GBS}}
     # every leg of the step, each timed by itself: they must sum to <= the step they decompose
-    if kind == "deep_clustering":
+    if kind == "deep_clustering" and fused0:
+        rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "layer0_split_plus_fused_recurrence": t_l0f * 1e3,
+                          "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0,
+                          "recurrence_deeper_layers": (L - 1) * t_rec * 1e3 if lyr else 0.0,
+                          "fc_dc_l2norm": t_head * 1e3, "mask_istft": t_istft * 1e3}
+        rec["first_layer"] = {"fused_input_projection": True, "ms": t_l0f * 1e3, "us_per_time_step": t_l0f / T * 1e6,
+                              "note": "x W_ih^T inside the recurrence launch (no G, no layer-0 GEMM); includes the 7 us feature split; "
+                                      "the unfused alternative would be input_proj_l0 + one plain recurrence launch = "
+                                      f"{(t_g0 + t_rec) * 1e3:.3f} ms"}
+    elif kind == "deep_clustering":
         rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "input_proj_l0_with_split": t_g0 * 1e3,
                           "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0, "recurrence_all_layers": L * t_rec * 1e3,
                           "fc_dc_l2norm": t_head * 1e3, "mask_istft": t_istft * 1e3}

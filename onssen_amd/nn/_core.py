@@ -526,10 +526,11 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     images = bool(flags & _abi.BLSTM_XCD) and bool(flags & _abi.BLSTM_BF16X3)     # activations travel as x3 images
     wih = pk.wih_img if images else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
     bias = pk.bias
-    # measured (dc / chimera, H=600): +2.7 % at B=64, +0.7 % at B=32, -3 % at B=16 -- the fused MFMAs cost every
-    # time step the same, the GEMM they replace shrinks with the batch
+    # measured (dc / chimera, H=600; round 3, with the x products formed in the window after the barrier): fused is 1.7 %
+    # faster at B=64, 1.0 % at B=32 (it lost 2.4 % there before), 1.6 % SLOWER at B=16 -- the fused MFMAs cost every
+    # time step the same, the GEMM (and the 246 MB of G) they replace shrink with the batch
     fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
-    if images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 32)):
+    if images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)):
         flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
         wih = [pk.wih_frag0] + list(wih[1:])
         if pk.bias0_tail is not None:
