@@ -35,6 +35,9 @@ for fused in (0, 1):
     print(f"fused={fused} B={B}: cycles/step {per:.0f} | relative to the barrier: wave 0 hand-off store issued {m(19,3):.0f} | wave 1 done {m(13,3):.0f} | "
           f"last wave starts waiting for the done counter {m(12,3):.0f} | last wave requests chunks {m(9,3):.0f} | wave 0 requests chunks {m(5,3):.0f} | "
           f"next step: last wave has all chunks {nx(10):.0f} | wave 0 starts {nx(0):.0f} has all chunks {nx(8):.0f} | next barrier {nx(3):.0f}")
+    if os.environ.get("CELL") == "1":      # build with -DONSSEN_XCD_PROFILE=0xF0009: the cell update of wave 0 in pieces
+        print(f"   cell update of wave 0: barrier -> sums in registers {m(16,3):.0f} | gates + cell + h {m(17,16):.0f} | split + quad gather {m(18,17):.0f} | "
+              f"hand-off store issued {m(19,18):.0f} | step period {per:.0f}")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5): layer(fused, 0)
