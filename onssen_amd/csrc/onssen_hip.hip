@@ -177,23 +177,25 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   if (!wav || !logmag || B <= 0 || hop <= 0 || n_samples <= n_fft / 2) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
-  const long frames = (long)B * T, pairs = (frames + 1) / 2;       // one wave per pair of frames (one complex transform)
-  // ~4 pairs per wave (the per-lane constants of the transform are built once per wave), but never fewer than 2 workgroups
-  // per CU's worth of workgroups when there is that much work
-  static const int ppw = ONSSEN_KNOB_INT("ONSSEN_STFT_PPW", 4);      // pairs per wave (debug builds: tools/ab_variants.py)
-  long nblk = (pairs + 4 * ppw - 1) / (4 * ppw);
-  if (nblk < 512) nblk = (pairs + 3) / 4 < 512 ? (pairs + 3) / 4 : 512;
-  const dim3 grid((unsigned)nblk), block(256);
+  if (stft_ri && (reinterpret_cast<uintptr_t>(stft_ri) & 7u)) return ONSSEN_E_ALIGN;     // (re, im) pairs are stored as one 8-byte word
+  // one wave per PAIR of consecutive frames of an utterance (one complex transform), `ppw` consecutive pairs per wave: the
+  // per-lane constants of the transform are built once per wave and the next pair's samples are fetched under this pair's
+  // butterflies; fewer pairs per wave when that leaves CUs without a workgroup
+  static const int ppw_knob = ONSSEN_KNOB_INT("ONSSEN_STFT_PPW", 4);      // debug builds: tools/ab_variants.py
+  const int npair = (T + 1) / 2;
+  int ppw = ppw_knob < 1 ? 1 : ppw_knob;
+  while (ppw > 1 && (long)B * ceil_div(npair, 4 * ppw) < 512) --ppw;
+  const dim3 grid((unsigned)((long)B * ceil_div(npair, 4 * ppw))), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
-    hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
-                       eps, logmag, stft_ri);
+    hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
+                       logmag, stft_ri);
   else if (n_fft == 512)
-    hipLaunchKernelGGL((stft_logmag_kernel<512>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop, T,
-                       eps, logmag, stft_ri);
+    hipLaunchKernelGGL((stft_logmag_kernel<512>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
+                       logmag, stft_ri);
   else if (n_fft == 1024)
-    hipLaunchKernelGGL((stft_logmag_kernel<1024>), grid, block, 0, st, wav, B, n_samples, (long)wav_stride, hop,
-                       T, eps, logmag, stft_ri);
+    hipLaunchKernelGGL((stft_logmag_kernel<1024>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
+                       logmag, stft_ri);
   else
     return ONSSEN_E_ARG;
   ONSSEN_LAUNCH_CHECK();
@@ -1113,6 +1115,7 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
                           int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
                           void* stream) {
   if (!stft_ri || !out || B <= 0 || C <= 0 || T <= 0 || hop <= 0 || length <= 0 || hop > n_fft) return ONSSEN_E_ARG;
+  if (reinterpret_cast<uintptr_t>(stft_ri) & 7u) return ONSSEN_E_ALIGN;               // (re, im) pairs are read as one 8-byte word
   // a chunk of FR hops of output needs FR + ceil(n_fft/hop) - 1 frames (one more when the chunk
   // origin n_fft/2 is not hop-aligned); FB frames fit in LDS
   // speakers go through the inverse FFT in pairs (one complex transform for two real frames) when there are at least
@@ -1125,6 +1128,21 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
     pair = false;
     FB = 16;
   }
+  // the wsj0-2mix transform (256, two speakers) exists with 8, 12 and 16 frames per workgroup.  A grid that fits the chip in one
+  // go (3 workgroups per CU) is latency-bound -- its time is the rounds of ONE workgroup, so the fewest frames per workgroup
+  // win (one utterance of 1 000 frames: 7.7 / 9.5 / 11.4 us with 8 / 12 / 16); a larger grid is throughput-bound and the
+  // halo frames that every chunk transforms again cost more than the shorter workgroups save (32 x 400: 35.1 / 31.6 / 28.4 us)
+  static const int fb_knob = ONSSEN_KNOB_INT("ONSSEN_ISTFT_FB", 0);      // debug builds: tools/ab_variants.py
+  if (pair && n_fft == 256 && FB - halo > 0) {
+    if (fb_knob == 8 || fb_knob == 12 || fb_knob == 16) {
+      if (fb_knob - halo > 0) FB = fb_knob;
+    } else {
+      for (int fb = 8; fb < 16; fb += 4) {
+        if (fb - halo <= 0) continue;
+        if ((long)ceil_div(length, (fb - halo) * hop) * ceil_div(C, 2) * B <= 256L * 3) { FB = fb; break; }
+      }
+    }
+  }
   const int FR = FB - halo;
   if (FR <= 0) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
@@ -1133,7 +1151,12 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
 #define ONSSEN_ISTFT(N_, FB_, PAIR_)                                                                                    \
   hipLaunchKernelGGL((mask_istft_kernel<N_, FB_, PAIR_>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc, \
                      (long)m_st, (long)m_sf, C, T, hop, length, FR, out)
-  if (n_fft == 256) { if (pair) ONSSEN_ISTFT(256, 16, true); else ONSSEN_ISTFT(256, 16, false); }
+  if (n_fft == 256) {
+    if (!pair) ONSSEN_ISTFT(256, 16, false);
+    else if (FB == 8) ONSSEN_ISTFT(256, 8, true);
+    else if (FB == 12) ONSSEN_ISTFT(256, 12, true);
+    else ONSSEN_ISTFT(256, 16, true);
+  }
   else if (n_fft == 512) { if (pair) ONSSEN_ISTFT(512, 8, true); else ONSSEN_ISTFT(512, 16, false); }
   else if (n_fft == 1024) ONSSEN_ISTFT(1024, 8, false);
   else

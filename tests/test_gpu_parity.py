@@ -388,6 +388,28 @@ def test_mask_istft_and_roundtrip(dev, n_fft, hop, n, length):
     np.testing.assert_allclose(y[:, :k], wav[:, :k], atol=2e-6)
 
 
+@pytest.mark.parametrize("B,T", [(32, 400), (12, 400), (1, 1000), (5, 401)])
+def test_front_and_back_end_at_every_launch_shape(dev, B, T):
+    """The host picks pairs-of-frames per wave (STFT) and frames per workgroup (iSTFT: 8 / 12 / 16) from the grid size: the
+    headline batch, a medium one, one long utterance and an odd frame count all give the oracle's numbers."""
+    from onssen_amd.features import mask_istft, stft_logmag
+    n = (T - 1) * 64
+    wav = np.stack([synth_mixture(70 + b, n) for b in range(B)])
+    lm, ri = stft_logmag(torch.from_numpy(wav).to(dev), 256, 64)
+    assert lm.shape == (B, T, 129)
+    rng = np.random.default_rng(B)
+    m0 = rng.random((B, T, 129)).astype(np.float32)
+    out = mask_istft(ri, torch.from_numpy(np.stack([m0, 1 - m0], -1)).to(dev), 64, n).cpu().numpy()
+    lm, ri = lm.cpu().numpy(), ri.cpu().numpy()
+    for b in sorted({0, B // 2, B - 1}):
+        X = O.stft(wav[b], 256, 64)
+        got = ri[b, ..., 0] + 1j * ri[b, ..., 1]
+        assert np.abs(got - X).max() <= 2e-7 * np.abs(X).max() + 1e-9
+        big = np.abs(X) > 1e-3
+        np.testing.assert_allclose(lm[b][big], O.log_magnitude(X)[big], atol=2e-6)
+        np.testing.assert_allclose(out[b], O.mask_istft(X, np.stack([m0[b], 1 - m0[b]]), 64, n), atol=2e-6)
+
+
 def cfg5_inputs(seed, B, n_samples=16000, n_fft=512, hop=128):
     """The input recipe of tools/gen_golden_cfg5.py (seeded synthetic 16 kHz mixtures -> log-magnitude, (Re, Im))."""
     mags, phs = [], []
