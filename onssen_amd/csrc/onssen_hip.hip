@@ -1111,6 +1111,12 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   return ONSSEN_OK;
 }
 
+#ifdef ONSSEN_FFT_PROFILE
+int onssen_debug_fft_stamps(long long* host_out, int n) {      // profile builds only; not part of the ABI
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fft_stamps), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
                           int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
                           void* stream) {
