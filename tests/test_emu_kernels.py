@@ -479,17 +479,6 @@ def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
-def test_blstm_xcd_eight_wave_variant():
-    """ONSSEN_XCD_WAVES=8 (two waves per SIMD, 256 flags per group) is read once per process: run the persistent-
-    recurrence test in a child interpreter with it set."""
-    import subprocess
-    import sys
-    env = dict(os.environ, ONSSEN_XCD_WAVES="8")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k", "test_blstm_xcd_local_persistent and 24-8-17-3 and 0-0-0"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4)])     # the last one: D + C = 34, two tasks per thread
 def test_loss_dc_value(lib, B, TF, D, C):
     """onssen_loss_dc_f32 against the NumPy restatement of loss_dc (Frobenius norms of the weighted affinity blocks)."""
