@@ -52,24 +52,60 @@ class tester:
     def get_est_sig(self, input, label, output):
         raise NotImplementedError
 
-    def eval(self):
-        from .nn._core import _XcdStatus, recovering
+    def eval(self, window=16):
+        """Mean SI-SDR over the loader.  Upstream synchronises on every utterance (``.item()``); here ``window`` utterances
+        are queued back to back -- the host launches utterance i+1 while the device works on utterance i -- and the status
+        words of their persistent recurrences are examined once per window.  An aborted launch in a window re-runs that
+        window on the launch-per-step recurrence (inference is functional: same inputs, same outputs)."""
+        import warnings
+        from .nn._core import XcdAborted, XcdNonFinite, _XcdPolicy, _XcdStatus
         total, count = 0.0, 0
         self.model = self.model.eval()
 
-        @recovering                      # an aborted persistent recurrence: this utterance is run again, launch per step
         def one(input, label):
             output = self.model(input)
             sig_est, sig_ref = self.get_est_sig(input, label, output)
-            sdr = batch_SDR_torch(sig_est, sig_ref)
-            _XcdStatus.flush()
-            return sdr
+            return batch_SDR_torch(sig_est, sig_ref)
+
+        def rerun(pend, e):
+            _XcdPolicy.recovered += 1
+            if not isinstance(e, XcdNonFinite):
+                warnings.warn(f"onssen_amd: {e}  Re-running {len(pend)} utterance(s) on the launch-per-step recurrence.", RuntimeWarning)
+            try:
+                _XcdStatus.flush()               # the window's other launches ran into the same abort word: drain their reports
+            except XcdAborted:
+                pass
+            with _XcdPolicy.forced_steps():
+                sdrs = [one(input, label) for input, label, _ in pend]
+                _XcdStatus.flush()
+            return sdrs
+
+        def close(pend):
+            sdrs = [sdr for _, _, sdr in pend]
+            try:
+                _XcdStatus.flush()
+            except XcdAborted as e:
+                sdrs = rerun(pend, e)
+            return float(torch.cat([x.reshape(-1) for x in sdrs]).double().sum()), sum(x.numel() for x in sdrs)
 
         with torch.no_grad():
+            pend = []
             for input, label in self.test_loader:
-                sdr = one(input, label)
-                total += float(sdr.sum())
-                count += sdr.numel()
+                try:
+                    pend.append((input, label, one(input, label)))
+                except XcdAborted as e:          # reported by this forward's look at the statuses of the launches before it
+                    pend.append((input, label, None))
+                    sdrs = rerun(pend, e)
+                    total += float(torch.cat([x.reshape(-1) for x in sdrs]).double().sum())
+                    count += sum(x.numel() for x in sdrs)
+                    pend = []
+                    continue
+                if len(pend) >= max(1, int(window)):
+                    t, c = close(pend)
+                    total, count, pend = total + t, count + c, []
+            if pend:
+                t, c = close(pend)
+                total, count = total + t, count + c
         return total / max(count, 1)
 
 

@@ -307,3 +307,46 @@ def test_aborted_training_step_is_rerun_and_the_next_one_is_persistent_again(dev
     n_p = P.persistent_launches
     loss2 = odist.train_step(m, opt, loss_dc, [x], label)
     assert P.persistent_launches == n_p + 1 and P.aborts == a0 + 1 and np.isfinite(loss2)
+
+
+def test_windowed_evaluation_loop_matches_per_utterance_and_survives_an_abort(dev):
+    """``tester.eval`` queues ``window`` utterances between two looks at the status words: the mean SI-SDR is the one the
+    per-utterance loop (window = 1, upstream's rhythm) gives, and a window whose persistent launches abort (bounded waits
+    set to 0) is re-run on the launch-per-step recurrence -- same number, a RuntimeWarning, the policy back to normal."""
+    import warnings
+    from onssen_amd import nn as onn
+    from onssen_amd.evaluate import tester_dc
+    from onssen_amd.features import stft_logmag
+    from onssen_amd.hip import get_lib
+    from onssen_amd.nn import _core
+    lib = get_lib()
+    torch.manual_seed(4)
+    m = onn.deep_clustering(129, 64, 2, 20).to(dev).eval()
+    items = []
+    for it in range(5):
+        n = 64 * (60 + 7 * it) + 3 * it
+        mix, s1, s2 = synth_mixture(90 + it, n, return_sources=True)
+        lm, ri = stft_logmag(torch.from_numpy(mix[None]).to(dev), 256, 64)
+        gap = 32 - n % 32
+        ref = torch.from_numpy(np.stack([np.pad(s1, (0, gap)), np.pad(s2, (0, gap))])[None]).to(dev)
+        items.append(([lm], [ri[..., 0].contiguous(), ri[..., 1].contiguous(), ref]))
+    t = tester_dc({"model": m, "model_name": "dc", "test_loader": items, "device": str(dev)})
+    one_by_one = t.eval(window=1)
+    assert abs(t.eval(window=16) - one_by_one) <= 1e-5 * max(1.0, abs(one_by_one))
+    assert abs(t.eval(window=2) - one_by_one) <= 1e-5 * max(1.0, abs(one_by_one))
+    P = _core._XcdPolicy
+    r0 = P.recovered
+    old = lib.dll.onssen_xcd_spin_limit(0)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = t.eval(window=16)
+    finally:
+        lib.dll.onssen_xcd_spin_limit(old)
+    assert P.recovered >= r0 + 1 and any("launch-per-step" in str(x.message) for x in w)
+    assert abs(got - one_by_one) <= 2e-3 * max(1.0, abs(one_by_one))        # step path vs persistent path: masks may flip a bin
+    while P.skip:                                 # consume the back-off
+        t.eval(window=16)
+    n_p = P.persistent_launches
+    t.eval(window=16)
+    assert P.persistent_launches > n_p and P.skip == 0

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""GPU box: the evaluation loop the reference actually runs (onssen/utils/test.py:29-41 -- whole utterances, batch 1):
+tester_dc.eval() / tester_chimera.eval() over the synthetic evaluation loader.  Reports wall time per utterance, audio
+seconds per wall second, and how much of the wall time the GPU was busy (events around every utterance's work)."""
+import json, os, sys, time
+import torch
+os.environ.setdefault("ONSSEN_SYNTHETIC_DATA", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from onssen_amd import nn as onn
+from onssen_amd.data import wsj0_2mix_dataloader
+from onssen_amd.evaluate import tester_chimera, tester_dc
+from onssen_amd.utils import AttrDict
+
+
+def load(name):
+    with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", name)) as f:
+        return AttrDict(json.load(f))
+
+
+for cfg, cls, tcls in (("config_dc.json", "deep_clustering", tester_dc), ("config_chimera_psa.json", "chimera", tester_chimera)):
+    args = load(cfg)
+    dev = torch.device("cuda:0")
+    args.model = getattr(onn, cls)(**args["model_options"]).to(dev)
+    args.checkpoint_path = None
+    args.test_loader = list(wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", dev)) * 4    # resident: the loop itself is what is timed
+    t = tcls(args)
+    t.eval()                                   # warm-up: weight packing, workspaces
+    torch.cuda.synchronize()
+    secs = sum(float(lab[2].shape[-1]) / 8000.0 * lab[2].shape[0] for _, lab in args.test_loader)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sdr = t.eval()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = sum(1 for _ in args.test_loader)
+    print(f"{cls:16s} {n} utterances, {secs:.1f} s of audio: eval() {dt * 1e3:.1f} ms = {dt / n * 1e3:.2f} ms per utterance = {secs / dt:.0f} x real time (SI-SDR {sdr:.2f})", flush=True)
