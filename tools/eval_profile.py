@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""GPU box: cProfile of tester_dc.eval() over resident utterances -- where does the host time of the evaluation loop go?"""
+import cProfile, io, json, os, pstats, sys
+import torch
+os.environ.setdefault("ONSSEN_SYNTHETIC_DATA", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from onssen_amd import nn as onn
+from onssen_amd.data import wsj0_2mix_dataloader
+from onssen_amd.evaluate import tester_dc
+from onssen_amd.utils import AttrDict
+
+with open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "config_dc.json")) as f:
+    args = AttrDict(json.load(f))
+dev = torch.device("cuda:0")
+args.model = onn.deep_clustering(**args["model_options"]).to(dev)
+args.checkpoint_path = None
+args.test_loader = list(wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", dev)) * 4
+t = tester_dc(args)
+t.eval(); t.eval()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+t.eval()
+torch.cuda.synchronize()
+pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[:9000])
