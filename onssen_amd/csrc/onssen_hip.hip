@@ -682,9 +682,9 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
   const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 4) * KQ2 * 2048;   // split-bf16 images of all groups; >= the fp32 image (2*KQ2 >= KQ)
   wsp += align256(hs_bytes);
   long long* dbg = ((flags >> 8) & 32) && T * 8 * sizeof(long long) <= 65536 ? (long long*)((char*)ws + wl.total - 65536) : nullptr;
-  {   // padded rows / K tail of the hand-off image are never written by the kernels: keep them zero
-    hipError_t e = hipMemsetAsync(hsb, 0, hs_bytes, st);
-    if (e != hipSuccess) return (int)e;
+  if (!(flags & ONSSEN_BLSTM_XCD)) {   // launch-per-step form: h_{-1} = 0 and the K padding of the hand-off images come from here
+    hipError_t e = hipMemsetAsync(hsb, 0, hs_bytes, st);      // (the persistent kernels clear their own slots, K padding included,
+    if (e != hipSuccess) return (int)e;                        //  before their start-up barrier: one launch less per call)
   }
   const int mt = (B > 16 && !(flags & ONSSEN_BLSTM_SPLIT_ROWS)) ? 2 : 1;
   // XCD form: activations travel between the layers (and on to the heads) as x3 images written by the recurrence

@@ -374,6 +374,16 @@ def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
         assert same > 0.995                      # same initialisation, same fixed point (summation orders differ)
 
 
+def _poison_handoff(ws, B, T, Hp, NP, L):
+    """NaNs with the exchange's tag bits set in the h hand-off area of a BLSTM workspace (header | G | ybuf | c | HERE:
+    onssen_hip.hip, blstm_ws_layout): the persistent kernels clear their slots -- K padding included -- themselves, no host
+    memset stands behind them."""
+    a256 = lambda n: (n + 255) // 256 * 256
+    off = _abi.BLSTM_WS_HEADER + a256(T * B * 2 * NP * 4) + (a256(T * B * 2 * Hp * 4) if L > 1 else 0) + a256(2 * B * Hp * 4)
+    n = a256(2 * 2 * ((B + 3) // 4) * ((Hp + 31) // 32) * 2048)
+    ws.view(np.uint32)[off // 4:(off + n) // 4] = 0x7fc07fc0
+
+
 # fuse 2: FUSE_IN0 + FUSE_TAIL, F = 33; bf16 1: ONSSEN_BLSTM_BF16 (opt-in plain bf16 products)
 @pytest.mark.parametrize("scramble,fuse,bf16", [("0", 0, 0), ("1", 0, 0), ("0", 1, 0), ("0", 2, 0), ("0", 0, 1), ("0", 1, 1)])
 @pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3), (32, 4, 2, 6)])
@@ -418,6 +428,7 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
                 c = ct
         wih3.append(pl), whh3.append(b3), bias.append(c)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
+    _poison_handoff(ws, B, T, Hp, NP, L)
     y = _shm((T, B, 2, Hp), fill=np.nan)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3],
                       [P(a) for a in bias], P(y), P(ws), ws.nbytes,
@@ -467,6 +478,7 @@ def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
                           P(a[d]), P(b[d]), P(c[d]), None)
         wih.append(a), whh.append(b), bias.append(c)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
+    _poison_handoff(ws, B, T, Hp, NP, L)
     y = _shm((T, B, 2, Hp), fill=np.nan)
     lib.blstm_forward(P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih], [P(a) for a in whh], [P(a) for a in bias],
                       P(y), P(ws), ws.nbytes, _abi.BLSTM_XCD, None)
