@@ -215,7 +215,9 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
  *             it is allocated and never again.  Its first ONSSEN_BLSTM_WS_HEADER_BYTES hold the exchange state
  *             of the ONSSEN_BLSTM_XCD form (flags, generations, status words): everything in there is monotonic,
  *             and no call memsets it (so a hipGraph replay does not depend on a memset node reaching the kernel's
- *             L2); the k padding of the x3 images further back is never written and must read as zero.  u32 word
+ *             L2); the k padding of the x3 images further back is never written and must read as zero (the h hand-off
+ *             area needs nothing: the ONSSEN_BLSTM_XCD kernels clear their slots at start-up, the launch-per-step form
+ *             memsets it).  u32 word
  *             [280] != 0: a launch gave up waiting (outputs invalid); word [281] = 1: some launch used the
  *             placement-independent accesses; word [282] = 1: a non-finite activation was replaced by 0 (see
  *             ONSSEN_BLSTM_XCD).  The host resets [280] and [282] after reporting them.
