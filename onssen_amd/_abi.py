@@ -9,7 +9,7 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 7
+ABI_VERSION = 8
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -40,6 +40,7 @@ SIGNATURES = {
     "onssen_linear_bf16x3": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_x3_image_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_linear_x3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp]),
+    "onssen_linear_x3p_resid": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _i, _i64, _i64, _i, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
@@ -188,6 +189,10 @@ class Lib:
     def linear_x3p(self, a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream):
         self.check(self.dll.onssen_linear_x3p(a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream),
                    "onssen_linear_x3p")
+
+    def linear_x3p_resid(self, a_img, M, K, w_img, bias, N, group, eps, resid, resid_mod, Cp, R, c_s0, c_s1, bf16_only, stream):
+        self.check(self.dll.onssen_linear_x3p_resid(a_img, M, K, w_img, bias, N, group, eps, resid, resid_mod, Cp, R, c_s0, c_s1,
+                                                    int(bool(bf16_only)), stream), "onssen_linear_x3p_resid")
 
     def blstm_forward(self, x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_ptrs, whh_ptrs, bias_ptrs, y, ws, ws_bytes,
                       flags, stream):

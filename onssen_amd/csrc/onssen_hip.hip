@@ -409,6 +409,7 @@ static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, i
   p.c_vec = !C2 && aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0 && (c_bs % 4) == 0;
   p.a_bs = (long)a_bs; p.w_bs = (long)w_bs; p.c_bs = (long)c_bs;
   p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = (long)c2_bs; p.n_split = n_split;
+  p.resid = nullptr; p.r_mod = 1;
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM), (unsigned)batch);
   hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS, 4, 3, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   ONSSEN_LAUNCH_CHECK();
@@ -429,23 +430,28 @@ int onssen_linear_x3p_batched_split(const uint16_t* a_img, int64_t a_bs, int M, 
                                  batch, stream);
 }
 
-int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
-                      int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream) {
+static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
+                           int group, float eps, const float* resid, int resid_mod, float* C, int R, int64_t c_s0,
+                           int64_t c_s1, void* stream) {
   if (!a_img || !w_img || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0) return ONSSEN_E_ARG;
   if (!aligned16(a_img) || !aligned16(w_img)) return ONSSEN_E_ALIGN;
   const int KB = ceil_div(K, 32);
   if ((long)lxp::BM * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
   const bool bf16_only = (mode & ONSSEN_EPI_BF16) != 0;   // plain bf16 products: hi halves only
   mode &= ~ONSSEN_EPI_BF16;
+  // pairs (group 2) and the residual exist in the 256/128 x 320 kernel only (onssen_linear_x3p_resid)
+  const bool pairs = mode == ONSSEN_EPI_L2NORM && group == 2;
   if (mode == ONSSEN_EPI_L2NORM) {
-    if (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4 || (N % group) != 0) return ONSSEN_E_ARG;
+    if (!pairs && (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4)) return ONSSEN_E_ARG;
+    if ((N % group) != 0) return ONSSEN_E_ARG;
   } else if (mode != ONSSEN_EPI_BIAS && mode != ONSSEN_EPI_SIGMOID) {
     return ONSSEN_E_ARG;
   }
+  if (resid && (mode != ONSSEN_EPI_L2NORM || resid_mod <= 0)) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   LinearXpArgs p;
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
-  p.KB = KB; p.group = group; p.eps = eps;
+  p.KB = KB; p.group = group; p.eps = eps; p.resid = resid; p.r_mod = resid ? resid_mod : 1;
   p.a_bs = p.w_bs = p.c_bs = 0;
   p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
   static const int x3_gn = ONSSEN_KNOB_INT("ONSSEN_X3_GN", 4);
@@ -458,7 +464,8 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   // groups per wave (80 columns) and stays at 320 columns.  ONSSEN_X3Q=320 / 256 forces the width, ONSSEN_X3Q_BM=256 / 128 the height.
   const char* env_q = getenv("ONSSEN_X3Q");   // read per call: the tests switch it
   const char* env_bm = getenv("ONSSEN_X3Q_BM");
-  const int use_q = env_q ? atoi(env_q) : 1, force_bm = env_bm ? atoi(env_bm) : 0;
+  const int use_q = (pairs || resid) ? 1 : env_q ? atoi(env_q) : 1, force_bm = env_bm ? atoi(env_bm) : 0;
+  if ((pairs || resid) && (long)lxq::BM_MAX * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
   if (use_q && (long)lxq::BM_MAX * KB * 128 <= 0x7fffffffL) {
     int bm = 256, bn = 320;
     double best = 1e30;
@@ -514,6 +521,21 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
 
 size_t onssen_loss_dc_workspace_bytes(int B) {   // partial Grams + (gradient pass) one M matrix and sum(mag) per utterance
   return B > 0 ? (size_t)B * (lossdc::NBLK + 1) * (lossdc::ZMAX * lossdc::ZMAX + 1) * sizeof(float) : 0;
+}
+
+
+int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
+                      int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream) {
+  if ((mode & ~ONSSEN_EPI_BF16) == ONSSEN_EPI_L2NORM && group == 2) return ONSSEN_E_ARG;      // pairs: onssen_linear_x3p_resid
+  return linear_x3p_impl(a_img, M, K, w_img, bias, N, mode, group, eps, nullptr, 0, C, R, c_s0, c_s1, stream);
+}
+
+int onssen_linear_x3p_resid(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
+                            float eps, const float* resid, int resid_mod, float* C, int R, int64_t c_s0, int64_t c_s1,
+                            int bf16_only, void* stream) {
+  if (group != 2 && (group <= 0 || (group % 4) != 0)) return ONSSEN_E_ARG;
+  return linear_x3p_impl(a_img, M, K, w_img, bias, N, ONSSEN_EPI_L2NORM | (bf16_only ? ONSSEN_EPI_BF16 : 0), group, eps, resid,
+                         resid_mod, C, R, c_s0, c_s1, stream);
 }
 
 int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,

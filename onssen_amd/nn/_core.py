@@ -556,9 +556,10 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     return y
 
 
-def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_off=0, b_total=None):
+def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_off=0, b_total=None, resid_mod=None):
     """y (T, Btot, 2, Hp) time-major -> (B, T, N) batch-major with the fused
-    epilogue.  ``b_off``/``b_total`` select a batch slice of y (phase net)."""
+    epilogue.  ``b_off``/``b_total`` select a batch slice of y (phase net); ``resid_mod`` = R: batch row b adds residual row
+    b % R (phase net, both speakers in one launch: ``resid`` is (R, T, N))."""
     lib = get_lib()
     Btot = y.shape[1] if b_total is None else b_total
     Hp = y.shape[3]
@@ -567,6 +568,14 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
     a_ptr = y.data_ptr() + b_off * 2 * Hp * 4
     rp = resid.data_ptr() if resid is not None else None
     img = getattr(y, "x3_image", None)
+    if (img is not None and mode == EPI_L2NORM and resid is not None and resid_mod is not None and b_off == 0 and Btot == B
+            and (group == 2 or group % 4 == 0) and hd.N % group == 0):
+        wsb, off = img                               # pre-split activations, residual + pair / group normalisation in the epilogue
+        lib.linear_x3p_resid(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, group, eps, rp,
+                             resid_mod, out.data_ptr(), B, hd.N, T * hd.N, precision() == "bf16", _stream())
+        return out
+    if resid_mod is not None:
+        raise RuntimeError("run_head: resid_mod needs the x3 image of the recurrence output (XCD form)")
     if (img is not None and resid is None and b_off == 0 and Btot == B
             and (mode != EPI_L2NORM or (group % 4 == 0 and 80 % group == 0 and 80 // group <= 4))):
         wsb, off = img                               # pre-split activations straight from the recurrence epilogue

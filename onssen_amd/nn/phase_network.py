@@ -5,7 +5,7 @@ import torch.nn.functional as F
 from ..hip import get_lib
 from ._train import batch_norm_rows
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
-                    require_device, run_blstm, run_head, use_hip_path)
+                    heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 from .chimera import chimera
 
 
@@ -49,8 +49,13 @@ class phase_net(PackedWeightsMixin, nn.Module):
         inp = torch.empty(C * B, T, 3 * Fq, device=x_mag.device, dtype=torch.float32)
         get_lib().phase_input(x_mag.data_ptr(), masks.data_ptr(), masks.stride(0), masks.stride(3), masks.stride(1),
                               masks.stride(2), x_phase.data_ptr(), B, C, T, Fq, inp.data_ptr(), _stream())
-        y = run_blstm(self._packed, self._ws, inp, tag="phase")
+        # (the head reads the recurrence's x3 output image where there is one: the fp32 rows are then never written)
+        y = run_blstm(self._packed, self._ws, inp, tag="phase", need_y=not (C == 2 and heads_take_image(C * B, self.hidden_dim)))
         resid = x_phase.view(B, T, 2 * Fq)
+        if getattr(y, "x3_image", None) is not None and C == 2:
+            # both speakers in ONE launch of the pre-split-operand GEMM: rows b and b + B add the same mixture phase
+            p = run_head(self._head, y, C * B, T, EPI_L2NORM, group=2, eps=1e-12, resid=resid, resid_mod=B)
+            return [embedding, mask_A, mask_B, p[:B].view(B, T, Fq, 2), p[B:].view(B, T, Fq, 2)]
         outs = []
         for s in range(2):
             p = run_head(self._head, y, B, T, EPI_L2NORM, group=2, eps=1e-12, resid=resid, b_off=s * B,

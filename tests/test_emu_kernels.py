@@ -275,6 +275,37 @@ def test_linear_x3_images(lib, mode, group, K, tile, monkeypatch):
     np.testing.assert_allclose(out, ref, atol=3e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("group,N,tile", [(2, 514, "256"), (2, 38, "128"), (20, 440, "256")])
+def test_linear_x3_images_with_residual(lib, group, N, tile, monkeypatch):
+    """onssen_linear_x3p_resid: phase_net's head epilogue (onssen/nn/phase_network.py:58-66) on the pre-split-operand GEMM --
+    (A W^T + b + residual) normalised over pairs (re, im) or wider groups; rows b and b + R of a time step add the SAME
+    residual row (both speakers of the shared phase BLSTM in one launch); ragged N (514 = 2 F), strided C rows."""
+    monkeypatch.setenv("ONSSEN_X3Q_BM", tile)
+    rng = np.random.default_rng(9)
+    R, Tt, K = 3, 47, 75              # 2 R = 6 batch rows per time step: M = 282 (two 256-row blocks / three 128-row ones)
+    Bb = 2 * R
+    x = rand(rng, Bb, Tt, K)
+    W, bias = rand(rng, N, K), rand(rng, N)
+    resid = rand(rng, R, Tt, N)
+    KB, M = (K + 31) // 32, Bb * Tt
+    a_img, w_img = np.zeros((M, KB, 2, 32), np.uint16), np.zeros((N, KB, 2, 32), np.uint16)
+    lib.x3_image(P(x), K, Tt * K, Bb, M, K, P(a_img), None)          # rows m = t*Bb + b, like the recurrence's output image
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    out = np.full((Bb, Tt, N), np.nan, np.float32)
+    lib.linear_x3p_resid(P(a_img), M, K, P(w_img), P(bias), N, group, 1e-12, P(resid), R, P(out), Bb, N, Tt * N, False, None)
+    ref = x.astype(np.float64) @ W.T.astype(np.float64) + bias + np.concatenate([resid, resid], 0)
+    r = ref.reshape(Bb, Tt, N // group, group)
+    nrm = np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), 1e-12)
+    assert not np.isnan(out).any()
+    # a direction is only as well defined as its vector is long: the GEMM's own error (3e-4 on values of order 10) over the norm
+    err = np.abs(out.reshape(r.shape) - r / nrm) * nrm
+    assert err.max() <= 3e-4, err.max()
+    np.testing.assert_allclose(np.linalg.norm(out.reshape(Bb, Tt, N // group, group), axis=-1), 1.0, atol=1e-5)
+    # the plain entry keeps refusing pairs (they exist in the residual entry's kernel only)
+    assert lib.dll.onssen_linear_x3p(P(a_img), M, K, P(w_img), P(bias), N, _abi.EPI_L2NORM, 2, 1e-12, P(out), Bb, N, Tt * N, None) != 0 \
+        if group == 2 else True
+
+
 def test_label_features_match_oracle(lib):
     B, n = 2, 1500
     trips = [synth_mixture(60 + b, n, return_sources=True) for b in range(B)]
