@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 8   /* 8: onssen_linear_x3p_resid.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 8   /* 8: onssen_linear_x3p_resid, onssen_linear_x3p_pair.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -200,6 +200,15 @@ int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shif
 int onssen_x3_image_f32(const float* src, int64_t s0, int64_t s1, int R, int rows, int K, uint16_t* img, void* stream);
 int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
                       int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, void* stream);
+/* TWO heads over the same activations in one launch (onssen/nn/chimera.py:37-45: fc_dc + F.normalize and fc_mi + sigmoid
+ * both read the BLSTM output): w_img / bias hold the N rows of both layers, rows [0, n_split) are normalised over `group`
+ * consecutive outputs (a multiple of 4 dividing 80; n_split % group == 0) and go to C, rows [n_split, N) pass through the
+ * logistic and go to columns n - n_split of C2 (row m at C2 + (m / R)*c2_s0 + (m % R)*c2_s1).  The embedding's last
+ * 320-column tile is mostly padding (2 580 = 8 x 320 + 20): the second head's columns fill it, its own launch disappears. */
+int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int n_split,
+                           int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, float* C2, int64_t c2_s0,
+                           int64_t c2_s1, int bf16_only, void* stream);
+
 /* The same GEMM with phase_net's head epilogue (onssen/nn/phase_network.py:58-66: fc_phase(bn(rnn)) + mix phase, then
  * F.normalize over (re, im)): C = normalise_group(a_img . w_img^T + bias + resid), group = 2 (pairs of consecutive
  * outputs, N even) or a multiple of 4 dividing 80.  resid has C's row addressing with the row-in-block index taken

@@ -41,6 +41,7 @@ SIGNATURES = {
     "onssen_x3_image_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_linear_x3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp]),
     "onssen_linear_x3p_resid": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _i, _i64, _i64, _i, _vp]),
+    "onssen_linear_x3p_pair": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp, _i64, _i64, _i, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
@@ -189,6 +190,10 @@ class Lib:
     def linear_x3p(self, a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream):
         self.check(self.dll.onssen_linear_x3p(a_img, M, K, w_img, bias, N, mode, group, eps, Cp, R, c_s0, c_s1, stream),
                    "onssen_linear_x3p")
+
+    def linear_x3p_pair(self, a_img, M, K, w_img, bias, N, n_split, group, eps, Cp, R, c_s0, c_s1, C2p, c2_s0, c2_s1, bf16_only, stream):
+        self.check(self.dll.onssen_linear_x3p_pair(a_img, M, K, w_img, bias, N, n_split, group, eps, Cp, R, c_s0, c_s1, C2p, c2_s0,
+                                                   c2_s1, int(bool(bf16_only)), stream), "onssen_linear_x3p_pair")
 
     def linear_x3p_resid(self, a_img, M, K, w_img, bias, N, group, eps, resid, resid_mod, Cp, R, c_s0, c_s1, bf16_only, stream):
         self.check(self.dll.onssen_linear_x3p_resid(a_img, M, K, w_img, bias, N, group, eps, resid, resid_mod, Cp, R, c_s0, c_s1,

@@ -530,6 +530,36 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   return linear_x3p_impl(a_img, M, K, w_img, bias, N, mode, group, eps, nullptr, 0, C, R, c_s0, c_s1, stream);
 }
 
+int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int n_split,
+                           int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, float* C2, int64_t c2_s0,
+                           int64_t c2_s1, int bf16_only, void* stream) {
+  if (!a_img || !w_img || !bias || !C || !C2 || R <= 0 || M <= 0 || K <= 0 || N <= 0) return ONSSEN_E_ARG;
+  if (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4) return ONSSEN_E_ARG;
+  if (n_split <= 0 || n_split >= N || (n_split % group) != 0) return ONSSEN_E_ARG;
+  if (!aligned16(a_img) || !aligned16(w_img)) return ONSSEN_E_ALIGN;
+  const int KB = ceil_div(K, 32);
+  if ((long)lxq::BM_MAX * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  LinearXpArgs p;
+  p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
+  p.KB = KB; p.group = group; p.eps = eps; p.resid = nullptr; p.r_mod = 1;
+  p.a_bs = p.w_bs = p.c_bs = 0;
+  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = 0; p.n_split = n_split;
+  p.tile_group = 4;
+  p.c_vec = aligned16(C) && (n_split % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
+  // half-height tiles where 256-row tiles would leave CUs idle (the cost model of onssen_linear_x3p)
+  const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 320), t128 = (long)ceil_div(M, 128) * ceil_div(N, 320);
+  const int bm = (double)ceil_div(t128, 256L) * 128 * 1.15 < (double)ceil_div(t256, 256L) * 256 ? 128 : 256;
+  const dim3 gridq((unsigned)ceil_div(N, 320), (unsigned)ceil_div(M, bm));
+  hipStream_t st = (hipStream_t)stream;
+  if (bm == 256) { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 1, false, 320, 256>), gridq, dim3(512), 0, st, p);
+                   else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 3, false, 320, 256>), gridq, dim3(512), 0, st, p); }
+  else { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 1, false, 320, 128>), gridq, dim3(512), 0, st, p);
+         else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 3, false, 320, 128>), gridq, dim3(512), 0, st, p); }
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_linear_x3p_resid(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
                             float eps, const float* resid, int resid_mod, float* C, int R, int64_t c_s0, int64_t c_s1,
                             int bf16_only, void* stream) {

@@ -594,6 +594,32 @@ def run_head(head: PackedHead, y, B, T, mode, group=0, eps=1e-12, resid=None, b_
     return out
 
 
+def run_head_pair(head_a: PackedHead, head_b: PackedHead, y, B, T, group, eps=1e-12):
+    """Two heads over the same recurrence output in ONE launch (chimera: fc_dc + L2 norm over ``group`` | fc_mi + sigmoid):
+    returns ((B, T, Na), (B, T, Nb)), or None when this forward cannot take the pre-split-operand GEMM (no x3 image, a group
+    the register epilogue does not hold) -- the caller then runs the heads one by one."""
+    img = getattr(y, "x3_image", None)
+    if img is None or not (group % 4 == 0 and 80 % group == 0 and 80 // group <= 4):
+        return None
+    lib = get_lib()
+    Hp = y.shape[3]
+    ha, hb = head_a.get(Hp), head_b.get(Hp)
+    if ha.N % group != 0 or y.shape[1] != B:
+        return None
+    key = (ha.key, hb.key)
+    if getattr(head_a, "_pair_key", None) != key:
+        head_a._pair_img = torch.cat([ha.img, hb.img], 0).contiguous()          # rows of both layers: one B operand
+        head_a._pair_b = torch.cat([ha.b, hb.b]).contiguous()
+        head_a._pair_key = key
+    out_a = torch.empty(B, T, ha.N, device=y.device, dtype=torch.float32)
+    out_b = torch.empty(B, T, hb.N, device=y.device, dtype=torch.float32)
+    wsb, off = img
+    lib.linear_x3p_pair(wsb.data_ptr() + off, T * B, 2 * Hp, head_a._pair_img.data_ptr(), head_a._pair_b.data_ptr(), ha.N + hb.N,
+                        ha.N, group, eps, out_a.data_ptr(), B, ha.N, T * ha.N, out_b.data_ptr(), hb.N, T * hb.N,
+                        precision() == "bf16", _stream())
+    return out_a, out_b
+
+
 def use_hip_path(module):
     """Inference (eval mode, no autograd graph needed) -> HIP kernels.
     Anything that needs autograd or train-mode BatchNorm/dropout takes the

@@ -4,7 +4,7 @@ import torch.nn.functional as F
 
 from ._train import head_linear, l2_normalize
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
-                    heads_take_image, require_device, run_blstm, run_head, use_hip_path)
+                    heads_take_image, require_device, run_blstm, run_head, run_head_pair, use_hip_path)
 
 
 class chimera(PackedWeightsMixin, nn.Module):
@@ -44,8 +44,13 @@ class chimera(PackedWeightsMixin, nn.Module):
         require_device(x, "chimera")
         y = run_blstm(self._packed, self._ws, x,
                       need_y=not heads_take_image(batch_size, self.hidden_dim, (self.embedding_dim,)))
-        emb = run_head(self._head_dc, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
-        masks = run_head(self._head_mi, y, batch_size, frame, EPI_SIGMOID)
+        # both heads in one launch where the recurrence left its x3 image: fc_mi's columns ride in fc_dc's last, mostly empty tile
+        pair = run_head_pair(self._head_dc, self._head_mi, y, batch_size, frame, self.embedding_dim)
+        if pair is not None:
+            emb, masks = pair
+        else:
+            emb = run_head(self._head_dc, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
+            masks = run_head(self._head_mi, y, batch_size, frame, EPI_SIGMOID)
         return emb.view(batch_size, frame, frequency, -1), masks.view(batch_size, frame, frequency, -1)
 
     def _autograd_forward(self, x):

@@ -306,6 +306,36 @@ def test_linear_x3_images_with_residual(lib, group, N, tile, monkeypatch):
         if group == 2 else True
 
 
+@pytest.mark.parametrize("tile_rows", [60, 300])
+def test_linear_x3_images_two_heads_in_one_launch(lib, tile_rows):
+    """onssen_linear_x3p_pair (chimera: fc_dc + L2 norm over D | fc_mi + sigmoid, onssen/nn/chimera.py:37-45): the rows of both
+    layers form ONE B operand; columns < n_split are normalised per group into C, the rest pass through the logistic into
+    C2 -- bit for bit what the two separate launches give."""
+    rng = np.random.default_rng(10)
+    Bb, Tt, K, group = 2, tile_rows // 2, 75, 20
+    Na, Nb = 13 * group, 26                       # 260 + 26 = 286 columns: one 320-wide tile, the split inside its first wave tile
+    x = rand(rng, Bb, Tt, K)
+    Wa, Wb, ba, bb = rand(rng, Na, K), rand(rng, Nb, K), rand(rng, Na), rand(rng, Nb)
+    KB, M = (K + 31) // 32, Bb * Tt
+    a_img = np.zeros((M, KB, 2, 32), np.uint16)
+    lib.x3_image(P(x), K, Tt * K, Bb, M, K, P(a_img), None)
+    wa_img, wb_img = np.zeros((Na, KB, 2, 32), np.uint16), np.zeros((Nb, KB, 2, 32), np.uint16)
+    lib.x3_image(P(Wa), K, 0, 1, Na, K, P(wa_img), None)
+    lib.x3_image(P(Wb), K, 0, 1, Nb, K, P(wb_img), None)
+    w_img, bias = np.ascontiguousarray(np.concatenate([wa_img, wb_img], 0)), np.concatenate([ba, bb])
+    out_a, out_b = np.full((Bb, Tt, Na), np.nan, np.float32), np.full((Bb, Tt, Nb), np.nan, np.float32)
+    lib.linear_x3p_pair(P(a_img), M, K, P(w_img), P(bias), Na + Nb, Na, group, 1e-12, P(out_a), Bb, Na, Tt * Na, P(out_b), Nb, Tt * Nb,
+                        False, None)
+    ref_a, ref_b = np.full_like(out_a, np.nan), np.full_like(out_b, np.nan)
+    lib.linear_x3p(P(a_img), M, K, P(wa_img), P(ba), Na, _abi.EPI_L2NORM, group, 1e-12, P(ref_a), Bb, Na, Tt * Na, None)
+    lib.linear_x3p(P(a_img), M, K, P(wb_img), P(bb), Nb, _abi.EPI_SIGMOID, 0, 0.0, P(ref_b), Bb, Nb, Tt * Nb, None)
+    assert not np.isnan(out_a).any() and not np.isnan(out_b).any()
+    np.testing.assert_array_equal(out_a, ref_a)
+    np.testing.assert_array_equal(out_b, ref_b)
+    full = x.astype(np.float64) @ Wb.T.astype(np.float64) + bb
+    np.testing.assert_allclose(out_b, 1 / (1 + np.exp(-full)), atol=1e-4)
+
+
 def test_label_features_match_oracle(lib):
     B, n = 2, 1500
     trips = [synth_mixture(60 + b, n, return_sources=True) for b in range(B)]
