@@ -306,8 +306,8 @@ def test_linear_x3_images_with_residual(lib, group, N, tile, monkeypatch):
         if group == 2 else True
 
 
-@pytest.mark.parametrize("tile_rows", [60, 300])
-def test_linear_x3_images_two_heads_in_one_launch(lib, tile_rows):
+@pytest.mark.parametrize("tile_rows,bf16", [(60, False), (300, False), (60, True)])
+def test_linear_x3_images_two_heads_in_one_launch(lib, tile_rows, bf16):
     """onssen_linear_x3p_pair (chimera: fc_dc + L2 norm over D | fc_mi + sigmoid, onssen/nn/chimera.py:37-45): the rows of both
     layers form ONE B operand; columns < n_split are normalised per group into C, the rest pass through the logistic into
     C2 -- bit for bit what the two separate launches give."""
@@ -325,15 +325,16 @@ def test_linear_x3_images_two_heads_in_one_launch(lib, tile_rows):
     w_img, bias = np.ascontiguousarray(np.concatenate([wa_img, wb_img], 0)), np.concatenate([ba, bb])
     out_a, out_b = np.full((Bb, Tt, Na), np.nan, np.float32), np.full((Bb, Tt, Nb), np.nan, np.float32)
     lib.linear_x3p_pair(P(a_img), M, K, P(w_img), P(bias), Na + Nb, Na, group, 1e-12, P(out_a), Bb, Na, Tt * Na, P(out_b), Nb, Tt * Nb,
-                        False, None)
+                        bf16, None)
     ref_a, ref_b = np.full_like(out_a, np.nan), np.full_like(out_b, np.nan)
-    lib.linear_x3p(P(a_img), M, K, P(wa_img), P(ba), Na, _abi.EPI_L2NORM, group, 1e-12, P(ref_a), Bb, Na, Tt * Na, None)
-    lib.linear_x3p(P(a_img), M, K, P(wb_img), P(bb), Nb, _abi.EPI_SIGMOID, 0, 0.0, P(ref_b), Bb, Nb, Tt * Nb, None)
+    fl = _abi.EPI_BF16 if bf16 else 0              # (opt-in plain-bf16 products: the hi halves of the images only)
+    lib.linear_x3p(P(a_img), M, K, P(wa_img), P(ba), Na, _abi.EPI_L2NORM | fl, group, 1e-12, P(ref_a), Bb, Na, Tt * Na, None)
+    lib.linear_x3p(P(a_img), M, K, P(wb_img), P(bb), Nb, _abi.EPI_SIGMOID | fl, 0, 0.0, P(ref_b), Bb, Nb, Tt * Nb, None)
     assert not np.isnan(out_a).any() and not np.isnan(out_b).any()
     np.testing.assert_array_equal(out_a, ref_a)
     np.testing.assert_array_equal(out_b, ref_b)
     full = x.astype(np.float64) @ Wb.T.astype(np.float64) + bb
-    np.testing.assert_allclose(out_b, 1 / (1 + np.exp(-full)), atol=1e-4)
+    np.testing.assert_allclose(out_b, 1 / (1 + np.exp(-full)), atol=2e-2 if bf16 else 1e-4)
 
 
 def test_label_features_match_oracle(lib):
