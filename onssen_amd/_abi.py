@@ -49,6 +49,7 @@ SIGNATURES = {
     "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
                                              _i, _vp]),
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "onssen_x3_image_both_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
     "onssen_lstm_pack_whhT_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -219,6 +220,9 @@ class Lib:
 
     def x3_image_t(self, src, ld, M, K, k_shift, img, stream):
         self.check(self.dll.onssen_x3_image_t_f32(src, ld, M, K, k_shift, img, stream), "onssen_x3_image_t_f32")
+
+    def x3_image_both(self, src, ld, M, K, img_rows, img_t, stream):
+        self.check(self.dll.onssen_x3_image_both_f32(src, ld, M, K, img_rows, img_t, stream), "onssen_x3_image_both_f32")
 
     def lstm_train_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates, cs, ws, ws_bytes, stream):
         self.check(self.dll.onssen_lstm_train_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates,

@@ -96,7 +96,12 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     dp2 = dP.view(TB, 2 * NP)
     # operands contracted over the T*B rows: transposed images straight from the row-major activations
     a_t = torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
-    lib.x3_image_t(dp2.data_ptr(), 2 * NP, 2 * NP, TB, 0, a_t.data_ptr(), st)
+    a_rows = None
+    if need_dx:       # dP is the operand of both gradient GEMMs: its row-major and its transposed image from ONE pass over it
+        a_rows = torch.empty(TB, (2 * NP + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_both(dp2.data_ptr(), 2 * NP, 2 * NP, TB, a_rows.data_ptr(), a_t.data_ptr(), st)
+    else:
+        lib.x3_image_t(dp2.data_ptr(), 2 * NP, 2 * NP, TB, 0, a_t.data_ptr(), st)
     w1 = torch.empty(2, N1, KB, 2, 32, device=dev, dtype=torch.int16)           # per direction: [x | h of the step before]
     y2 = y.view(TB, 2 * Hp)
     for d in range(2):
@@ -119,7 +124,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     dx = None
     if need_dx:
         Kp = wih_p.shape[2]
-        a = _x3_image(lib, st, dp2)
+        a = a_rows
         w2 = torch.empty(Kp, (2 * NP + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
         lib.x3_image_t(wih_p.data_ptr(), Kp, Kp, 2 * NP, 0, w2.data_ptr(), st)     # image of W_ih(packed)^T
         dx = torch.empty(TB, Kp, device=dev, dtype=torch.float32)

@@ -337,6 +337,23 @@ def test_linear_x3_images_two_heads_in_one_launch(lib, tile_rows, bf16):
     np.testing.assert_allclose(out_b, 1 / (1 + np.exp(-full)), atol=2e-2 if bf16 else 1e-4)
 
 
+@pytest.mark.parametrize("K,M", [(70, 150), (64, 64), (33, 97)])
+def test_x3_image_both_equals_the_two_single_image_kernels(lib, K, M):
+    """onssen_x3_image_both_f32: the row-major and the transposed x3 image of a [K][M] matrix from one pass -- the same bits as
+    onssen_x3_image_f32 and onssen_x3_image_t_f32 (k_shift 0), padding included."""
+    rng = np.random.default_rng(K + M)
+    ld = M + 3
+    src = rand(rng, K, ld)
+    KB, MB = (K + 31) // 32, (M + 31) // 32
+    rows_a, t_a = np.full((K, MB, 2, 32), 0x7fc0, np.uint16), np.full((M, KB, 2, 32), 0x7fc0, np.uint16)
+    rows_b, t_b = np.full_like(rows_a, 0x7fc0), np.full_like(t_a, 0x7fc0)
+    lib.x3_image_both(P(src), ld, M, K, P(rows_a), P(t_a), None)
+    lib.x3_image(P(src), ld, 0, 1, K, M, P(rows_b), None)
+    lib.x3_image_t(P(src), ld, M, K, 0, P(t_b), None)
+    np.testing.assert_array_equal(rows_a, rows_b)
+    np.testing.assert_array_equal(t_a, t_b)
+
+
 def test_label_features_match_oracle(lib):
     B, n = 2, 1500
     trips = [synth_mixture(60 + b, n, return_sources=True) for b in range(B)]
