@@ -300,15 +300,17 @@ def linear_x3_backward(lib, st, dy, x2d, weight, need_dx=True):
     dev = dy.device
     zero = _zeros(max(N, K), dev)
     dx = None
+    KB = (M + 31) // 32
+    dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
     if need_dx:
         wt = torch.empty(K, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
         lib.x3_image_t(weight.data_ptr(), K, K, N, 0, wt.data_ptr(), st)                     # image of W^T: rows k, contraction over n
         dx = torch.empty(M, K, device=dev, dtype=torch.float32)
-        a = _x3_image(lib, st, dy)
+        a = torch.empty(M, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_both(dy.data_ptr(), N, N, M, a.data_ptr(), dyt.data_ptr(), st)          # dy feeds both products: one pass over it
         lib.linear_x3p(a.data_ptr(), M, N, wt.data_ptr(), zero.data_ptr(), K, 0, 0, 0.0, dx.data_ptr(), 1, K, 0, st)
-    KB = (M + 31) // 32
-    dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
-    lib.x3_image_t(dy.data_ptr(), N, N, M, 0, dyt.data_ptr(), st)
+    else:
+        lib.x3_image_t(dy.data_ptr(), N, N, M, 0, dyt.data_ptr(), st)
     xt = torch.empty(K, KB, 2, 32, device=dev, dtype=torch.int16)
     lib.x3_image_t(x2d.data_ptr(), K, K, M, 0, xt.data_ptr(), st)
     dW = torch.empty(N, K, device=dev, dtype=torch.float32)
