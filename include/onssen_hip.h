@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 8   /* 8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 9   /* 9: ragged batches of whole utterances (onssen_*_ragged_f32).  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -415,6 +415,44 @@ int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, 
 int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
                           int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ragged batches (round 4): the reference evaluates WHOLE utterances one at a time (onssen/utils/test.py:29-41 with the
+ * batch-1 loader of onssen/data/wsj0_2mix.py:231-245), a shape that leaves most of the chip idle.  These entry points
+ * run K utterances of different lengths in one launch sequence: every buffer keeps the padded batch shape (T = the longest
+ * utterance's frames, n = the longest sample count) and a device array gives each row's own extent.  Row b's results
+ * inside its own extent are bit-identical to what the uniform entry point returns for that utterance alone (B = 1,
+ * T = frames[b]); outside it they are defined as stated below.
+ *
+ * onssen_stft_logmag_ragged_f32: n_per_utt[b] samples of row b are valid (n_fft/2 < n_per_utt[b] <= n_max; the reflect
+ *   padding mirrors about the row's own last sample); T = 1 + n_max/hop frames are written per row, the frames past
+ *   1 + n_per_utt[b]/hop as the transform of silence (log-magnitude log10(eps), spectrum 0 -- to rounding, ~1e-16).
+ * onssen_blstm_forward_ragged_f32: frames[b] <= T live frames of row b; at t >= frames[b] the row holds h = c = 0 in both
+ *   directions (the reverse direction therefore starts from zero state at the row's own last frame) and its output rows are
+ *   0 -- whatever the input holds there (a NaN of the padding does not spread).  ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3
+ *   without ONSSEN_BLSTM_FUSE_IN0 / ONSSEN_BLSTM_BF16 runs the persistent form; the launch-per-step form takes ragged
+ *   batches in both precisions; other flag combinations return ONSSEN_E_ARG.
+ * onssen_dc_cluster_ragged_f32: utterance b owns the first frames[b]*F bins of its slab; its padding is never active
+ *   (masks 0) and takes no part in the maximum, the initialisation or the sums.
+ * onssen_mask_istft_ragged_f32: frames[b] frames and lengths[b] <= length output samples per row (librosa.istft(...,
+ *   length = lengths[b]) semantics); out (B, C, length), zeros past lengths[b].
+ * onssen_batch_sdr_ragged_f32: row b holds lengths[b] <= n samples (est, org, mask keep the row stride n).
+ */
+int onssen_stft_logmag_ragged_f32(const float* wav, int B, int n_max, int64_t wav_stride, const int32_t* n_per_utt, int n_fft,
+                                  int hop, float eps, float* logmag, float* stft_ri, void* stream);
+int onssen_blstm_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, const int32_t* frames,
+                                    int in_dim, int H, int L, int ug, const float* const* wih_p_host,
+                                    const float* const* whh_p_host, const float* const* bias_p_host, float* y, void* ws,
+                                    size_t ws_bytes, int flags, void* stream);
+int onssen_dc_cluster_ragged_f32(const float* emb, const float* feature, int B, int T, const int32_t* frames, int F, int D,
+                                 float db_threshold, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                 void* stream);
+int onssen_mask_istft_ragged_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                                 int64_t m_sf, int B, int C, int T, const int32_t* frames, int n_fft, int hop, int length,
+                                 const int32_t* lengths, float* out, void* stream);
+int onssen_batch_sdr_ragged_f32(const float* est, const float* org, const float* mask, int B, int C, int n,
+                                const int32_t* lengths, float* sdr_out, int* perm_out, void* ws, size_t ws_bytes,
+                                void* stream);
 
 /* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
  * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */

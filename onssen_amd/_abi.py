@@ -9,7 +9,7 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 8
+ABI_VERSION = 9
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -80,6 +80,12 @@ SIGNATURES = {
     "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    # ragged batches of whole utterances (round 4)
+    "onssen_stft_logmag_ragged_f32": (_i, [_vp, _i, _i, _i64, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "onssen_blstm_forward_ragged_f32": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_dc_cluster_ragged_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
+    "onssen_mask_istft_ragged_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "onssen_batch_sdr_ragged_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
@@ -124,7 +130,11 @@ class Lib:
     def batch_sdr_workspace_bytes(self, B):
         return int(self.dll.onssen_batch_sdr_workspace_bytes(B))
 
-    def batch_sdr(self, est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream):
+    def batch_sdr(self, est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream, lengths=None):
+        if lengths is not None:      # ragged batch: row b holds lengths[b] <= n samples
+            self.check(self.dll.onssen_batch_sdr_ragged_f32(est, org, mask, B, Cn, n, lengths, sdr_out, perm_out, ws, ws_bytes,
+                                                            stream), "onssen_batch_sdr_ragged_f32")
+            return
         self.check(self.dll.onssen_batch_sdr_f32(est, org, mask, B, Cn, n, sdr_out, perm_out, ws, ws_bytes, stream),
                    "onssen_batch_sdr_f32")
 
@@ -160,7 +170,11 @@ class Lib:
         return int(off.value), int(kb.value)
 
     # ---- kernels (pointers are ints) --------------------------------------
-    def stft_logmag(self, wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream):
+    def stft_logmag(self, wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream, n_per_utt=None):
+        if n_per_utt is not None:    # ragged batch: n = the longest row, n_per_utt[b] the valid samples of row b
+            self.check(self.dll.onssen_stft_logmag_ragged_f32(wav, B, n, stride, n_per_utt, n_fft, hop, eps, logmag, stft_ri, stream),
+                       "onssen_stft_logmag_ragged_f32")
+            return
         self.check(self.dll.onssen_stft_logmag_f32(wav, B, n, stride, n_fft, hop, eps, logmag, stft_ri, stream),
                    "onssen_stft_logmag_f32")
 
@@ -201,8 +215,13 @@ class Lib:
                                                     int(bool(bf16_only)), stream), "onssen_linear_x3p_resid")
 
     def blstm_forward(self, x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_ptrs, whh_ptrs, bias_ptrs, y, ws, ws_bytes,
-                      flags, stream):
+                      flags, stream, frames=None):
         arr = C.c_void_p * L
+        if frames is not None:       # ragged batch: frames[b] <= T live frames of row b
+            self.check(self.dll.onssen_blstm_forward_ragged_f32(x, xs_b, xs_t, B, T, frames, in_dim, H, L, ug, arr(*wih_ptrs),
+                                                                arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, flags, stream),
+                       "onssen_blstm_forward_ragged_f32")
+            return
         self.check(self.dll.onssen_blstm_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, L, ug, arr(*wih_ptrs),
                                                      arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, flags, stream),
                    "onssen_blstm_forward_f32")
@@ -267,7 +286,12 @@ class Lib:
     def dropout(self, x, n, p, seed, out, stream):
         self.check(self.dll.onssen_dropout_f32(x, n, p, seed, out, stream), "onssen_dropout_f32")
 
-    def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream):
+    def mask_istft(self, stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop, length, out, stream, frames=None,
+                   lengths=None):
+        if frames is not None:       # ragged batch: frames[b] frames in, lengths[b] <= length samples out per row
+            self.check(self.dll.onssen_mask_istft_ragged_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, frames, n_fft, hop,
+                                                             length, lengths, out, stream), "onssen_mask_istft_ragged_f32")
+            return
         self.check(self.dll.onssen_mask_istft_f32(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, Cn, T, n_fft, hop,
                                                   length, out, stream), "onssen_mask_istft_f32")
 
@@ -279,6 +303,10 @@ class Lib:
         self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
                                               cos_s1, cos_s2, stream), "onssen_labels_f32")
 
-    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0):
+    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0, frames=None):
+        if frames is not None:       # ragged batch: utterance b owns frames[b] * F bins
+            self.check(self.dll.onssen_dc_cluster_ragged_f32(emb, feat, B, T, frames, F, D, db, iters, masks, ws, ws_bytes, flags,
+                                                             stream), "onssen_dc_cluster_ragged_f32")
+            return
         self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, flags, stream),
                    "onssen_dc_cluster_f32")

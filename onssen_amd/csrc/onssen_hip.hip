@@ -172,8 +172,8 @@ const char* onssen_error_string(int code) {
   }
 }
 
-int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop, float eps,
-                           float* logmag, float* stft_ri, void* stream) {
+static int stft_logmag_impl(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop, float eps,
+                            float* logmag, float* stft_ri, void* stream, const int32_t* n_per_utt) {
   if (!wav || !logmag || B <= 0 || hop <= 0 || n_samples <= n_fft / 2) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   const int T = 1 + n_samples / hop;
@@ -189,17 +189,28 @@ int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_s
   hipStream_t st = (hipStream_t)stream;
   if (n_fft == 256)
     hipLaunchKernelGGL((stft_logmag_kernel<256>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
-                       logmag, stft_ri);
+                       logmag, stft_ri, n_per_utt);
   else if (n_fft == 512)
     hipLaunchKernelGGL((stft_logmag_kernel<512>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
-                       logmag, stft_ri);
+                       logmag, stft_ri, n_per_utt);
   else if (n_fft == 1024)
     hipLaunchKernelGGL((stft_logmag_kernel<1024>), grid, block, 0, st, wav, n_samples, (long)wav_stride, hop, T, eps, ppw,
-                       logmag, stft_ri);
+                       logmag, stft_ri, n_per_utt);
   else
     return ONSSEN_E_ARG;
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
+}
+
+int onssen_stft_logmag_f32(const float* wav, int B, int n_samples, int64_t wav_stride, int n_fft, int hop, float eps,
+                           float* logmag, float* stft_ri, void* stream) {
+  return stft_logmag_impl(wav, B, n_samples, wav_stride, n_fft, hop, eps, logmag, stft_ri, stream, nullptr);
+}
+
+int onssen_stft_logmag_ragged_f32(const float* wav, int B, int n_max, int64_t wav_stride, const int32_t* n_per_utt, int n_fft,
+                                  int hop, float eps, float* logmag, float* stft_ri, void* stream) {
+  if (!n_per_utt) return ONSSEN_E_ARG;
+  return stft_logmag_impl(wav, B, n_max, wav_stride, n_fft, hop, eps, logmag, stft_ri, stream, n_per_utt);
 }
 
 int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_elems) {
@@ -619,8 +630,8 @@ size_t onssen_batch_sdr_workspace_bytes(int B) {
   return B > 0 ? ((size_t)B * sdr::NBLK * sdr::PSTRIDE + (size_t)B * sdr::SMAX) * sizeof(double) : 0;
 }
 
-int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
-                         int* perm_out, void* ws, size_t ws_bytes, void* stream) {
+static int batch_sdr_impl(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
+                          int* perm_out, void* ws, size_t ws_bytes, void* stream, const int32_t* lengths) {
   if (!est || !org || !sdr_out || !ws || B <= 0 || C <= 0 || C > sdr::CMAX || n <= C) return ONSSEN_E_ARG;
   if (ws_bytes < onssen_batch_sdr_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
@@ -629,14 +640,26 @@ int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, 
   double* partial = (double*)ws;      // fp64 sums: see loss_sdr.inc
   double* means = partial + (size_t)B * sdr::NBLK * sdr::PSTRIDE;
   const dim3 grid(sdr::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((sdr_partial_kernel<0>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)nullptr, partial);
-  hipLaunchKernelGGL(sdr_means_kernel, dim3((unsigned)B), dim3(64), 0, st, (const double*)partial, C, n, means);
-  hipLaunchKernelGGL((sdr_partial_kernel<1>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)means, partial);
+  hipLaunchKernelGGL((sdr_partial_kernel<0>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)nullptr, partial, lengths);
+  hipLaunchKernelGGL(sdr_means_kernel, dim3((unsigned)B), dim3(64), 0, st, (const double*)partial, C, n, means, lengths);
+  hipLaunchKernelGGL((sdr_partial_kernel<1>), grid, dim3(256), 0, st, est, org, mask, C, n, (const double*)means, partial, lengths);
   hipLaunchKernelGGL(sdr_final_kernel, dim3((unsigned)B), dim3(64), 0, st, (const double*)partial, C, sdr_out, perm_out);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
 
+
+int onssen_batch_sdr_f32(const float* est, const float* org, const float* mask, int B, int C, int n, float* sdr_out,
+                         int* perm_out, void* ws, size_t ws_bytes, void* stream) {
+  return batch_sdr_impl(est, org, mask, B, C, n, sdr_out, perm_out, ws, ws_bytes, stream, nullptr);
+}
+
+int onssen_batch_sdr_ragged_f32(const float* est, const float* org, const float* mask, int B, int C, int n,
+                                const int32_t* lengths, float* sdr_out, int* perm_out, void* ws, size_t ws_bytes,
+                                void* stream) {
+  if (!lengths) return ONSSEN_E_ARG;
+  return batch_sdr_impl(est, org, mask, B, C, n, sdr_out, perm_out, ws, ws_bytes, stream, lengths);
+}
 
 size_t onssen_loss_mask_workspace_bytes(int B) { return B > 0 ? (size_t)B * 32 * 4 * sizeof(float) : 0; }
 
@@ -712,7 +735,7 @@ int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t*
 static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                               int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                               const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
-                              void* stream, float* save_g, float* save_c) {
+                              void* stream, float* save_g, float* save_c, const int32_t* frames = nullptr) {
   int Hp, NP, KQ;
   int64_t we;
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, &KQ, &we) != ONSSEN_OK) return ONSSEN_E_ARG;
@@ -720,6 +743,11 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     return ONSSEN_E_ARG;
   // y may be NULL only in the XCD form, whose consumers can take the x3 image of the output instead
   if (!y && !((flags & ONSSEN_BLSTM_XCD) && (flags & ONSSEN_BLSTM_BF16X3))) return ONSSEN_E_ARG;
+  // ragged batches: the persistent form exists for the plain split-bf16 inference recurrence (no fused first layer, no
+  // bf16-only products, no saved state); the launch-per-step form takes them in both precisions
+  if (frames && (flags & ONSSEN_BLSTM_XCD) &&
+      (!(flags & ONSSEN_BLSTM_BF16X3) || (flags & (ONSSEN_BLSTM_FUSE_IN0 | ONSSEN_BLSTM_BF16)) || save_g || save_c))
+    return ONSSEN_E_ARG;
   BlstmWs wl;
   if (!blstm_ws_layout(B, T, in_dim, H, L, ug, &wl)) return ONSSEN_E_ARG;
   if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
@@ -810,6 +838,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin; xa.dbg = dbg; xa.ablate = (flags >> 8) & 8;
       xa.terms = !x3 ? 0 : bf16_only ? 1 : 3;
       xa.save_g = save_g; xa.save_c = save_c;
+      xa.frames = frames;
       ONSSEN_CLEAR_ERROR();
       // waves per workgroup (K is split over them): 8 = two per SIMD; ONSSEN_XCD_WAVES=4 keeps the one-per-SIMD form for comparison
       static const int xcd_nw = ONSSEN_KNOB_INT("ONSSEN_XCD_WAVES", 8) == 4 ? 4 : 8;
@@ -826,7 +855,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     StepArgs sp;
     sp.G = G; sp.whh = x3 ? nullptr : whh_p_host[l]; sp.whh_x3 = x3 ? (const unsigned short*)whh_p_host[l] : nullptr;
     sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.dbg = dbg; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
-    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 63;
+    sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 63; sp.frames = frames;
 #define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, (char*)ws, T, x3, st)
     if (mt == 1) {
       switch (ug) {
@@ -857,6 +886,15 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              void* stream) {
   return blstm_forward_impl(x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_p_host, whh_p_host, bias_p_host, y, ws, ws_bytes,
                             flags, stream, nullptr, nullptr);
+}
+
+int onssen_blstm_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, const int32_t* frames,
+                                    int in_dim, int H, int L, int ug, const float* const* wih_p_host,
+                                    const float* const* whh_p_host, const float* const* bias_p_host, float* y, void* ws,
+                                    size_t ws_bytes, int flags, void* stream) {
+  if (!frames) return ONSSEN_E_ARG;
+  return blstm_forward_impl(x, xs_b, xs_t, B, T, in_dim, H, L, ug, wih_p_host, whh_p_host, bias_p_host, y, ws, ws_bytes,
+                            flags, stream, nullptr, nullptr, frames);
 }
 
 // ---- training: one layer forward with saved state, and its backward recurrence ----------------
@@ -1113,8 +1151,8 @@ size_t onssen_dc_cluster_workspace_bytes(int B, int T, int F, int D) {
   return align256(onssen_dc_cluster_status_offset(B, D) + 256) + (size_t)B * T * F * D * sizeof(float);
 }
 
-int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream) {
+static int dc_cluster_impl(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
+                           int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream, const int32_t* frames) {
   if (!emb || !feature || !masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0)
     return ONSSEN_E_ARG;
   if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
@@ -1128,21 +1166,21 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   float* comp = (float*)((char*)ws + align256(onssen_dc_cluster_status_offset(B, D) + 256));
   const bool persistent = !(flags & ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION);
   const dim3 sgrid(km::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
+  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, frames, F);
   hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, iw);
 #define ONSSEN_KM_ASSIGN(MODE_, OUT_)                                                                                      \
   do {                                                                                                                   \
     if (D == 20) hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 20>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, \
-                                    feature, per_utt, D, db_threshold, w, stride, OUT_);                                    \
+                                    feature, per_utt, D, db_threshold, w, stride, OUT_, frames, F);                         \
     else hipLaunchKernelGGL((kmeans2_assign_kernel<MODE_, 0>), dim3(km::NBLK, (unsigned)B), dim3(256), 0, st, emb, feature,  \
-                            per_utt, D, db_threshold, w, stride, OUT_);                                                      \
+                            per_utt, D, db_threshold, w, stride, OUT_, frames, F);                                           \
   } while (0)
   if (persistent) {
     // active bins compacted once (the same pass finds the second centroid), then ALL Lloyd iterations in one launch per <= 32
     // utterances (km::NBP workgroups of km::LT threads each, one per CU: 256 workgroups fill the chip exactly)
-    hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw);
-    if (D == 20) hipLaunchKernelGGL((kmeans2_compact_kernel<20>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
-    else hipLaunchKernelGGL((kmeans2_compact_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp);
+    hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, frames, F);
+    if (D == 20) hipLaunchKernelGGL((kmeans2_compact_kernel<20>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp, frames, F);
+    else hipLaunchKernelGGL((kmeans2_compact_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp, frames, F);
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
     // (a wait that gives up leaves status = 1: the host sees it and runs the launch-per-iteration form)
     const unsigned spin = xcd_spin_limit();
@@ -1161,7 +1199,7 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
       else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
     }
   } else {
-    hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride);
+    hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, frames, F);
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
     for (int it = 0; it < iters; ++it) {
       ONSSEN_KM_ASSIGN(0, (float*)nullptr);
@@ -1174,15 +1212,27 @@ int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, 
   return ONSSEN_OK;
 }
 
+int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
+                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream) {
+  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, masks, ws, ws_bytes, flags, stream, nullptr);
+}
+
+int onssen_dc_cluster_ragged_f32(const float* emb, const float* feature, int B, int T, const int32_t* frames, int F, int D,
+                                 float db_threshold, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                 void* stream) {
+  if (!frames) return ONSSEN_E_ARG;
+  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, masks, ws, ws_bytes, flags, stream, frames);
+}
+
 #ifdef ONSSEN_FFT_PROFILE
 int onssen_debug_fft_stamps(long long* host_out, int n) {      // profile builds only; not part of the ABI
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fft_stamps), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
 }
 #endif
 
-int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
-                          int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
-                          void* stream) {
+static int mask_istft_impl(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                           int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
+                           void* stream, const int32_t* frames, const int32_t* lengths) {
   if (!stft_ri || !out || B <= 0 || C <= 0 || T <= 0 || hop <= 0 || length <= 0 || hop > n_fft) return ONSSEN_E_ARG;
   if (reinterpret_cast<uintptr_t>(stft_ri) & 7u) return ONSSEN_E_ALIGN;               // (re, im) pairs are read as one 8-byte word
   // a chunk of FR hops of output needs FR + ceil(n_fft/hop) - 1 frames (one more when the chunk
@@ -1219,7 +1269,7 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
   hipStream_t st = (hipStream_t)stream;
 #define ONSSEN_ISTFT(N_, FB_, PAIR_)                                                                                    \
   hipLaunchKernelGGL((mask_istft_kernel<N_, FB_, PAIR_>), grid, block, 0, st, stft_ri, mask, (long)m_sb, (long)m_sc, \
-                     (long)m_st, (long)m_sf, C, T, hop, length, FR, out)
+                     (long)m_st, (long)m_sf, C, T, hop, length, FR, out, frames, lengths)
   if (n_fft == 256) {
     if (!pair) ONSSEN_ISTFT(256, 16, false);
     else if (FB == 8) ONSSEN_ISTFT(256, 8, true);
@@ -1232,6 +1282,19 @@ int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb,
     return ONSSEN_E_ARG;
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
+}
+
+int onssen_mask_istft_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                          int64_t m_sf, int B, int C, int T, int n_fft, int hop, int length, float* out,
+                          void* stream) {
+  return mask_istft_impl(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, C, T, n_fft, hop, length, out, stream, nullptr, nullptr);
+}
+
+int onssen_mask_istft_ragged_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
+                                 int64_t m_sf, int B, int C, int T, const int32_t* frames, int n_fft, int hop, int length,
+                                 const int32_t* lengths, float* out, void* stream) {
+  if (!frames || !lengths) return ONSSEN_E_ARG;
+  return mask_istft_impl(stft_ri, mask, m_sb, m_sc, m_st, m_sf, B, C, T, n_fft, hop, length, out, stream, frames, lengths);
 }
 
 }  // extern "C"

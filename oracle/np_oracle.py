@@ -187,17 +187,24 @@ def bf16_round(a):
     return r.view(np.float32)
 
 
-def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse, rnd=None):
+def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse, rnd=None, exact_tail=False):
     """One direction of one nn.LSTM layer (batch_first, zero initial state).
     Gate row order in the 4H axis is i, f, g, o; the two bias vectors add.
     x: (B, T, In) -> (B, T, H).  (onssen/nn/deep_clustering.py:15-22,35.)
-    ``rnd`` (default None = the reference's arithmetic) rounds the operands of the two matrix products."""
+    ``rnd`` (default None = the reference's arithmetic) rounds the operands of the two matrix products
+    (``exact_tail``: all input columns but the last)."""
     B, T, _ = x.shape
     H = w_hh.shape[1]
     dt = x.dtype
-    if rnd is not None:
-        x, w_ih, w_hh = rnd(x), rnd(w_ih), rnd(w_hh)
-    gx = x @ w_ih.T + (b_ih + b_hh)
+    if rnd is not None and exact_tail:
+        # the product's fused first layer (in_dim = 32k + 1, B > 16) forms the lone last input column as an fp32 rank-1
+        # update outside the matrix cores: that column is NOT rounded
+        gx = rnd(x[..., :-1]) @ rnd(w_ih[:, :-1]).T + x[..., -1:] * w_ih[:, -1] + (b_ih + b_hh)
+        w_hh = rnd(w_hh)
+    else:
+        if rnd is not None:
+            x, w_ih, w_hh = rnd(x), rnd(w_ih), rnd(w_hh)
+        gx = x @ w_ih.T + (b_ih + b_hh)
     h = np.zeros((B, H), dtype=dt)
     c = np.zeros((B, H), dtype=dt)
     out = np.empty((B, T, H), dtype=dt)
@@ -214,7 +221,7 @@ def lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse, rnd=None):
     return out
 
 
-def blstm_stack(x, sd, prefix, num_layers, collect=None, rnd=None):
+def blstm_stack(x, sd, prefix, num_layers, collect=None, rnd=None, exact_tail0=False):
     """nn.LSTM(bidirectional=True, batch_first=True) in eval mode (inter-layer
     dropout inactive): layer output = [forward | reverse] on the last axis,
     which feeds the next layer.  ``sd`` is a reference-layout state_dict of
@@ -225,7 +232,8 @@ def blstm_stack(x, sd, prefix, num_layers, collect=None, rnd=None):
             outs.append(lstm_direction(
                 x,
                 sd[f"{prefix}weight_ih_l{k}{sfx}"], sd[f"{prefix}weight_hh_l{k}{sfx}"],
-                sd[f"{prefix}bias_ih_l{k}{sfx}"], sd[f"{prefix}bias_hh_l{k}{sfx}"], rev, rnd))
+                sd[f"{prefix}bias_ih_l{k}{sfx}"], sd[f"{prefix}bias_hh_l{k}{sfx}"], rev, rnd,
+                exact_tail=exact_tail0 and k == 0))
         x = np.concatenate(outs, axis=-1)
         if collect is not None:
             collect.append(x)
@@ -265,6 +273,25 @@ def deep_clustering_forward(sd, x, dtype=np.float32, collect=None):
     if collect is not None:
         collect.append(r)
     e = r @ sd["fc_dc.weight"].T + sd["fc_dc.bias"]
+    e = l2_normalize(e.reshape(B, T * F, -1))
+    return e.reshape(B, T, F, -1)
+
+
+def deep_clustering_forward_rounded(sd, x, rnd=bf16_round, exact_tail0=False, eps=1e-5):
+    """The SAME network (onssen/nn/deep_clustering.py:29-43, eval mode) in the arithmetic of the product's opt-in
+    ``ONSSEN_PRECISION=bf16`` mode (BASELINE cfg2's literal dtype): the operands of every matrix product -- layer inputs,
+    h_{t-1}, W_ih, W_hh, the head's input and weights -- are rounded with ``rnd``; accumulation, biases, gates, cell
+    state and the normalisation stay fp32.  Eval-mode BatchNorm is folded into fc_dc in fp32 BEFORE the rounding
+    (W' = W diag(s), b' = b + W (beta - mu s), s = gamma / sqrt(var + eps)), as the product packs it.  Not a reference
+    function: it restates that mode so that its tests can pin it (rnd = identity gives deep_clustering_forward)."""
+    sd = {k: np.asarray(v, dtype=np.float32) for k, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    x = np.asarray(x, dtype=np.float32)
+    B, T, F = x.shape
+    r = blstm_stack(x, sd, "rnn.", num_layers_of(sd), rnd=rnd, exact_tail0=exact_tail0)
+    s = sd["bn.weight"] / np.sqrt(sd["bn.running_var"] + np.float32(eps))
+    w = sd["fc_dc.weight"] * s
+    b = sd["fc_dc.bias"] + sd["fc_dc.weight"] @ (sd["bn.bias"] - sd["bn.running_mean"] * s)
+    e = rnd(r) @ rnd(w).T + b
     e = l2_normalize(e.reshape(B, T * F, -1))
     return e.reshape(B, T, F, -1)
 

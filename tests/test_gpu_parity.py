@@ -259,6 +259,33 @@ def test_optin_bf16_mode_ragged_fused(dev, monkeypatch):
     assert 1e-4 < rl2.max() < 1.5e-2
 
 
+@pytest.mark.parametrize("B,T", [(32, 400), (16, 150), (64, 150)])
+def test_cfg2_literal_bf16_pinned_to_rounded_oracle(dev, monkeypatch, B, T):
+    """BASELINE cfg2 in its literal dtype at its own batch (DC 2 x BLSTM-600, 32 x 400 frames; also the 4-row-group and
+    16-row-group forms): ``ONSSEN_PRECISION=bf16`` against (i) the fp32 oracle inside the mode's own 1.5e-2 rel-L2 budget
+    and (ii) the oracle's restatement of THAT arithmetic (``deep_clustering_forward_rounded``: bf16-rounded operands, fp32
+    everything else) at a tight tolerance, so that the mode is pinned and not only banded.  (ii) cannot be bit-exact: the
+    kernel and NumPy accumulate in different orders, and a 1e-7 difference in an h that sits on a bf16 rounding boundary
+    moves that operand by one bf16 ulp (2^-8 relative) -- per-vector rel-L2 <= 2e-4 mean, <= 1e-3 max."""
+    monkeypatch.setenv("ONSSEN_PRECISION", "bf16")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    cfg = dict(F=129, H=600, L=2, D=20, C=2, seed=21, gain=1.0)
+    m, sd = build("deep_clustering", cfg, dev)
+    x = logmag_input(5, B, T)
+    with torch.no_grad():
+        emb, = m([torch.from_numpy(x).to(dev)])
+    emb = emb.cpu().numpy()
+    ref32 = O.deep_clustering_forward(sd, x)
+    # B > 16: the first layer's projection runs inside the recurrence launch and its 129th input column stays fp32
+    refbf = O.deep_clustering_forward_rounded(sd, x, exact_tail0=B > 16)
+    band, pin = rel_l2(emb, ref32), rel_l2(emb, refbf)
+    print(f"[bf16 B={B} T={T}] vs fp32 oracle: rel-L2 mean {band.mean():.3e} max {band.max():.3e}; "
+          f"vs bf16-rounded oracle: mean {pin.mean():.3e} max {pin.max():.3e}")
+    assert 1e-4 < band.max() < 1.5e-2
+    assert pin.mean() < 2e-4 and pin.max() < 1e-3
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=-1), 1.0, atol=1e-5)
+
+
 # ---------------------------------------------------------------- oracle at other shapes / edge cases
 @pytest.mark.parametrize("B,T,H,L", [(1, 400, 600, 2), (5, 37, 600, 2), (33, 21, 300, 3), (17, 1, 64, 2), (2, 50, 30, 1),
                                      (70, 9, 128, 2)])
@@ -908,6 +935,50 @@ def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L
     assert not bad, "; ".join(bad)
     from onssen_amd.nn._core import _XcdStatus
     _XcdStatus.poll(wait=True)       # raises if a persistent launch (forward or backward) aborted
+
+
+@pytest.mark.gpu
+def test_cfg4_full_shape_gradients_match_fp64_autograd(dev, monkeypatch):
+    """BASELINE cfg4's training shape as shipped -- 16 chunks x 400 frames, 3 x BLSTM-600, dropout off -- through the
+    default HIP training path (persistent forward with saved state, persistent backward recurrence, split-bf16 gradient
+    GEMMs) against nn.LSTM autograd in float64 on the CPU: EVERY gradient tensor by per-tensor rel-L2 (a small tensor
+    cannot hide behind another's largest entry) and by the max-norm bound of the short-sequence tests.  400 dependent
+    steps of split-bf16 products (~1e-5 relative each) in both directions of time; the measured errors are printed and
+    recorded in DESIGN.md."""
+    from onssen_amd.nn._core import BLSTMParams, _XcdStatus
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    B, T, F, H, L = 16, 400, 129, 600, 3
+    torch.manual_seed(404)
+    ref = torch.nn.LSTM(F, H, L, batch_first=True, bidirectional=True).double()
+    rnn = BLSTMParams(F, H, L, dropout=0.0)
+    rnn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    rnn = rnn.to(dev)
+    x = torch.randn(B, T, F, dtype=torch.float64)
+    R = torch.randn(B, T, 2 * H, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    (yr * R).sum().backward()
+    xg = x.float().to(dev).requires_grad_(True)
+    yg = rnn.autograd_forward(xg, True)
+    (yg * R.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    _XcdStatus.poll(wait=True)
+    assert (yg.detach().cpu().double() - yr.detach()).abs().max() < 2e-5
+    rows, bad = [], []
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        rl2 = ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+        mx = ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+        rows.append(f"{what}: rel-L2 {rl2:.2e}, max-norm-relative {mx:.2e}")
+        if not (rl2 <= 1e-4 and mx <= 3e-4):
+            bad.append(rows[-1])
+    close(xg.grad, xr.grad, "dx")
+    for name, p in rnn.named_parameters():
+        close(p.grad, getattr(ref, name).grad, name)
+    print("[cfg4 16x400 L3 H600]\n  " + "\n  ".join(rows))
+    assert not bad, "; ".join(bad)
 
 
 @pytest.mark.gpu

@@ -34,6 +34,21 @@ def test_dc_tiny_matches_reference(golden_dir, name):
     assert rel_l2(emb, z["out_embedding"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("name", ["g1_deep_clustering_H8_L1", "g1_deep_clustering_H32_L2"])
+def test_rounded_restatement_is_the_same_network(golden_dir, name):
+    """``deep_clustering_forward_rounded`` (the restatement of the opt-in bf16 mode the GPU tests pin that mode with) with an
+    identity rounding IS the reference network -- BatchNorm folded, the lone-column form of the first layer included --,
+    and with bf16 rounding it is bf16-grade close to the reference's golden vectors."""
+    z, sd = load_case(f"{golden_dir}/{name}.npz")
+    for tail in (False, True):
+        emb = O.deep_clustering_forward_rounded(sd, z["x"], rnd=lambda v: v, exact_tail0=tail)
+        np.testing.assert_allclose(emb, z["out_embedding"], atol=3e-6, rtol=0)
+    emb = O.deep_clustering_forward_rounded(sd, z["x"])
+    assert 1e-4 < rel_l2(emb, z["out_embedding"]).max() < 1e-1      # bf16-grade (tiny configs with over-scaled weights)
+    r = O.bf16_round(np.float32([1.0 + 2.0 ** -9, 1.0 + 3 * 2.0 ** -9, -3.1415927, 1e-30]))
+    assert r[0] == 1.0 and r[1] == np.float32(1.0 + 2.0 ** -7) and (r.view(np.uint32) & 0xFFFF == 0).all()   # ties to even
+
+
 def test_chimera_tiny_matches_reference(golden_dir):
     z, sd = load_case(f"{golden_dir}/g1_chimera_H32_L2.npz")
     e, a, b = O.chimera_forward(sd, z["x"])
