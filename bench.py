@@ -7,9 +7,11 @@ One "step" = one pass of the hot path over one batch of synthetic 8 kHz
 2-speaker mixtures that is already resident in HBM:
     K1+K2  framed STFT 256/64 + log-magnitude
     K3-K8  deep-clustering network (BASELINE configs[1]: 2 x BLSTM-600, fc_dc + per-bin L2 normalise)
-    K10    mask-apply + iSTFT overlap-add for 2 speakers (binary masks resident in HBM; the same step
-           with the device-side threshold + 2-means back end in front of K10 is reported next to the headline as
-           "separate_dc_with_device_kmeans")
+    N2     threshold at max - 40 dB + 2-means on the active bins' embeddings -> binary masks, on the device (what
+           egs/wsj0-2mix/deep_clustering/evaluate.py:36-41 does with sklearn on the host)
+    K10    mask-apply + iSTFT overlap-add for 2 speakers
+(round 4: the headline IS the real separation; the step with resident random masks instead of the clustering -- the headline of
+rounds 1-3 -- is reported next to it as "resident_mask_step")
 captured once in a hipGraph and replayed.  N>1: one process per GPU (launched by
 torch.distributed.run), every rank separates its own batch -- utterances are independent, so
 there is no data-path collective ("scaling": "weak").
@@ -85,6 +87,13 @@ def build_workload(config, B, dev, rank=0, T=None):
     m0 = (torch.rand(B, Tn, F, generator=gen) > 0.5).float()
     bin_masks = torch.stack([m0, 1 - m0], -1).to(dev)   # stand-in for the K-means assignment
 
+    from onssen_amd.separation import dc_masks
+
+    def step_resident_masks():       # rounds 1-3's headline: the network's embedding is computed, the masks are a resident stand-in
+        logmag, ri = stft_logmag(wav, nfft, hop)
+        emb, = model([logmag])
+        return emb, mask_istft(ri, bin_masks, hop, n)
+
     def step():
         logmag, ri = stft_logmag(wav, nfft, hop)
         if kind == "phase_net":
@@ -93,12 +102,12 @@ def build_workload(config, B, dev, rank=0, T=None):
         elif kind == "chimera":
             emb, masks = model.embedding_and_masks(logmag)
             sig = mask_istft(ri, masks, hop, n)
-        else:
+        else:                          # deep clustering: the real separation (threshold + 2-means -> binary masks)
             emb, = model([logmag])
-            sig = mask_istft(ri, bin_masks, hop, n)
+            sig = mask_istft(ri, dc_masks(emb, logmag), hop, n)
         return emb, sig
     return dict(kind=kind, H=H, L=L, B=B, F=F, D=D, SR=sr, NFFT=nfft, HOP=hop, T=Tn, N=n, model=model, wav=wav, wav_np=wav_np,
-                bin_masks=bin_masks, sd=sd, step=step)
+                bin_masks=bin_masks, sd=sd, step=step, step_resident_masks=step_resident_masks)
 
 
 def capture(step, use_graph=True):
@@ -168,6 +177,10 @@ def extra_configs(dev):
     leg("b1_utterance_T400", "dc_l2", 1, T=400, reps=10)
     leg("b1_utterance_T1000", "dc_l2", 1, T=1000, reps=10)
     leg("b1_utterance_T1000_dc_l3", "dc_l3", 1, T=1000, reps=10)
+    try:
+        out["b16_ragged_utterances"] = ragged_leg(dev)
+    except Exception as e:
+        out["b16_ragged_utterances"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     for k in ("b1_utterance_T400", "b1_utterance_T1000", "b1_utterance_T1000_dc_l3"):
         if "ms_per_step" in out.get(k, {}):
             out[k]["latency_ms"] = out[k]["ms_per_step"]
@@ -176,6 +189,51 @@ def extra_configs(dev):
     except Exception as e:
         out["cfg4_training_step_dc_l3_b16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
+
+
+def ragged_leg(dev, K=16, batches=6):
+    """The reference's evaluation shape (whole utterances of different lengths, onssen/utils/test.py:29-41) K at a time:
+    ``separate_dc(model, wav, lengths=...)`` -- STFT, DC 2xBLSTM-600, threshold + 2-means, mask-apply + iSTFT, every stage told
+    each row's own extent -- on batches of K synthetic utterances of 3-8 s, eager launches (every batch has its own longest
+    utterance: nothing to capture).  Real time is counted on the utterances' OWN durations, not on the padded batch."""
+    from onssen_amd import nn as onn
+    from onssen_amd.nn._core import _XcdStatus
+    from onssen_amd.separation import separate_dc
+    from onssen_amd.synthetic import make_state_dict, synth_batch
+    F, H, L, D = 129, 600, 2, 20
+    sd = make_state_dict("deep_clustering", F, H, L, D, 2, seed=0)
+    model = onn.deep_clustering(F, H, L, D)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    rng = np.random.default_rng(7)
+    sets = []
+    for i in range(batches):
+        ns = [int(v) for v in rng.integers(3 * 8000, 8 * 8000, K)]
+        base = synth_batch(50 + i, 8, max(ns), 8000)
+        wav = torch.from_numpy(np.concatenate([base, base[::-1]])[:K].copy()).to(dev)
+        sets.append((wav, torch.tensor(ns, dtype=torch.int32, device=dev), ns))
+    with torch.no_grad():
+        for wav, ln, _ in sets[:2]:
+            separate_dc(model, wav, lengths=ln)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for wav, ln, _ in sets:
+            separate_dc(model, wav, lengths=ln)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        one = sets[0]
+        t1 = time.perf_counter()
+        for b in range(K):
+            separate_dc(model, one[0][b:b + 1, :one[2][b]].contiguous())
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+    _XcdStatus.poll(wait=True)
+    audio = sum(sum(ns) for _, _, ns in sets) / 8000.0
+    return {"workload": f"separate_dc on {batches} ragged batches of {K} whole utterances (3-8 s each, padded to the batch's longest), "
+                        "dc_l2, device 2-means, eager launches",
+            "utterances": K * batches, "audio_s": audio, "ms_per_utterance": dt / (K * batches) * 1e3, "x_real_time": audio / dt,
+            "one_by_one_ms_per_utterance": dt1 / K * 1e3, "one_by_one_x_real_time": sum(one[2]) / 8000.0 / dt1,
+            "padding_overhead": sum(K * max(ns) for _, _, ns in sets) / sum(sum(ns) for _, _, ns in sets)}
 
 
 def training_leg(dev, layers=3, B=16, steps=6, warmup=3):
@@ -339,23 +397,16 @@ def main():
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
 
-        # ---- the same step with the REAL deep-clustering back end (threshold + 2-means on the device)
-        #      instead of resident masks: reported next to the headline, outside the timed region, rank 0 only;
-        #      captured and replayed like the headline
+        # ---- the step of rounds 1-3 (binary masks resident in HBM instead of the clustering): a named secondary, outside
+        #      the timed region, rank 0 only; captured and replayed like the headline
         dc_e2e = None
         if kind == "deep_clustering" and rank == 0:
-            from onssen_amd.separation import dc_masks
-
-            def step_km():
-                logmag, ri = stft_logmag(wav, NFFT, HOP)
-                emb, = model([logmag])
-                return mask_istft(ri, dc_masks(emb, logmag), HOP, N_SAMPLES)
-            run_km, g_km = capture(step_km, not args.no_graph)
-            ms_km = time_replays(run_km, 10)
-            dc_e2e = {"ms_per_step": ms_km, "x_real_time": B * (T_FRAMES * HOP / SR) / ms_km * 1e3,
-                      "launch": "hipGraph replay" if g_km is not None else "eager",
-                      "what": "waveform -> STFT -> BLSTM -> embedding -> threshold + 2-means (<= 20 Lloyd iterations on the active "
-                              "bins, on the device) -> binary masks -> mask-apply + iSTFT"}
+            run_rm, g_rm = capture(wl["step_resident_masks"], not args.no_graph)
+            ms_rm = time_replays(run_rm, 10)
+            dc_e2e = {"ms_per_step": ms_rm, "x_real_time": B * (T_FRAMES * HOP / SR) / ms_rm * 1e3,
+                      "launch": "hipGraph replay" if g_rm is not None else "eager",
+                      "what": "waveform -> STFT -> BLSTM -> embedding; mask-apply + iSTFT with RESIDENT random binary masks "
+                              "(no clustering: the headline step of rounds 1-3)"}
 
         # ---- per-kernel timing leg (HIP events on the launch stream), outside the timed region
         roof = (kernel_roofline(model.chimera if kind == "phase_net" else model, wav, dev,
@@ -378,7 +429,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"wsj0-2mix-style {kind} ({args.config}): {L}xBLSTM-{H}, F={F}, D={D}, {SR // 1000} kHz STFT "
                                f"{NFFT}/{HOP}, {B} x {T_FRAMES}-frame chunks per GPU; step = STFT+log-mag -> BLSTM "
-                               + {"deep_clustering": "-> fc_dc + L2-normalise -> mask-apply + iSTFT (2 speakers)",
+                               + {"deep_clustering": "-> fc_dc + L2-normalise -> threshold (max - 40 dB) + 2-means on the active bins' "
+                                                     "embeddings (device, <= 20 Lloyd iterations) -> binary masks -> mask-apply + iSTFT "
+                                                     "(2 speakers)",
                                   "chimera": "-> fc_dc + L2-normalise, fc_mi + sigmoid -> mask-apply + iSTFT (2 speakers)",
                                   "phase_net": "-> embedding + mask heads -> phase BLSTM over (masked magnitude, phase) "
                                                "-> unit-norm phase head -> mask-apply + iSTFT (2 speakers)"}[kind],
@@ -404,10 +457,10 @@ def main():
     if rank == 0:
         result["roofline"] = roof
         if dc_e2e is not None:
-            result["separate_dc_with_device_kmeans"] = dc_e2e
+            result["resident_mask_step"] = dc_e2e
         if world == 1 and not args.no_extra and args.config == "dc_l2" and args.precision == "bf16x3":
             result["extra_configs"] = extra_configs(dev)
-        if world == 1 and not args.no_cpu_baseline and kind != "phase_net":
+        if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, kind, wav_np, bin_masks.cpu().numpy())
         print(json.dumps(result))
     if world > 1:
@@ -572,16 +625,27 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     mk = torch.rand(B, T, F, 2, device=dev)
     t_stft = timed(lambda: stft_logmag(wav, NFFT, HOP))
     t_istft = timed(lambda: mask_istft(lm_ri[1], mk, HOP, N_SAMPLES))
+    t_cluster = None
+    if kind == "deep_clustering":          # threshold + 2-means on the step's own embeddings (its time depends on the data)
+        from onssen_amd.separation import dc_masks
+        emb_k, = model([lm_ri[0]])
+        t_cluster = timed(lambda: dc_masks(emb_k, lm_ri[0]))
     stft_bytes = B * (N_SAMPLES * 4 + T * F * 4 * 3)           # waveform in; log-magnitude + (Re, Im) out
     istft_bytes = B * (T * F * 4 * 2 + T * F * 4 * 2 + 2 * N_SAMPLES * 4)   # (Re, Im) + two masks in; two waveforms out
     flop_rec = 2.0 * 2 * B * 4 * H * H * T                     # h W_hh^T, both directions, 2 FLOP/MAC
     flop_gin = 2.0 * B * T * 8 * H * (2 * H if lyr else F)
     flop_head = 2.0 * B * T * hp.N * 2 * H
     xcd = bool(flags & _abi.BLSTM_XCD)
-    traffic = None
+    traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf)).get("xcd_recurrence_hbm_bytes_per_launch" if xcd else "recurrence_hbm_bytes_per_launch")
+        tj = json.load(open(tf))
+        key = "xcd_recurrence_hbm_bytes_per_launch" if xcd else "recurrence_hbm_bytes_per_launch"
+        latest = tj.get("latest", {})          # written by tools/profile_round.sh (tools/traffic_from_pmc.py): names its round
+        if xcd and key in latest:
+            traffic, traffic_src = latest[key], f"PMC passes of round {latest.get('round')} (profiles/traffic.json: latest; {latest.get('kernel', '')})"
+        else:
+            traffic, traffic_src = tj.get(key), "PMC passes of round 1 (profiles/traffic.json)"
     # persistent form: one launch per layer and 64 batch rows; launch-per-step form: T launches per layer
     launches = -(-B // 64) if xcd else T
     # ceiling for ALGORITHMIC (fp32-equivalent) FLOPs: the exact-fp32 MFMA rate, or a third of the dense bf16
@@ -589,7 +653,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     peak = BF16_MFMA_PEAK_TFLOPS if bf16_only else BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
     rec = {"kernel": "lstm_xcd_kernel" if xcd else "lstm_step_kernel", "bound": "mfma",
            "achieved": flop_rec / t_rec / 1e12, "peak": peak, "unit": "TFLOP/s",
-           "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic,
+           "frac": flop_rec / t_rec / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
            "peak_note": "dense bf16 MFMA 2500 TF" if bf16_only else "dense bf16 MFMA 2500 TF / 3 (split-bf16)" if x3 else "exact-fp32 MFMA",
            "bound_note": "a serial chain of T dependent time steps: each is cell update -> tagged h stores -> L2 -> polled "
                          "fragment loads -> MFMAs -> LDS reduction; the exchange (every member reads all of h: 576 KB per step "
@@ -618,7 +682,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "layer0_split_plus_fused_recurrence": t_l0f * 1e3,
                           "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0,
                           "recurrence_deeper_layers": (L - 1) * t_rec * 1e3 if lyr else 0.0,
-                          "fc_dc_l2norm": t_head * 1e3, "mask_istft": t_istft * 1e3}
+                          "fc_dc_l2norm": t_head * 1e3, "threshold_2means_masks": t_cluster * 1e3, "mask_istft": t_istft * 1e3}
         rec["first_layer"] = {"fused_input_projection": True, "ms": t_l0f * 1e3, "us_per_time_step": t_l0f / T * 1e6,
                               "note": "x W_ih^T inside the recurrence launch (no G, no layer-0 GEMM); includes the 7 us feature split; "
                                       "the unfused alternative would be input_proj_l0 + one plain recurrence launch = "
@@ -626,7 +690,7 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     elif kind == "deep_clustering":
         rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "input_proj_l0_with_split": t_g0 * 1e3,
                           "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0, "recurrence_all_layers": L * t_rec * 1e3,
-                          "fc_dc_l2norm": t_head * 1e3, "mask_istft": t_istft * 1e3}
+                          "fc_dc_l2norm": t_head * 1e3, "threshold_2means_masks": t_cluster * 1e3, "mask_istft": t_istft * 1e3}
     return rec
 
 
@@ -641,6 +705,14 @@ def cpu_baseline(sd, kind, wav_np, masks_np):
     n_thr = torch.get_num_threads()
     Bs = min(len(wav_np), 8)                     # bounded sample: 8 chunks of the batch
     wav_s, masks_s = wav_np[:Bs], masks_np[:Bs]
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
 
     def once():
         X = [O.stft(w, NFFT, HOP) for w in wav_s]
@@ -648,9 +720,18 @@ def cpu_baseline(sd, kind, wav_np, masks_np):
         if kind == "chimera":
             _, a, b = TC.chimera_forward(sd, lm)
             mk = np.stack([a.numpy(), b.numpy()], 1)
-        else:
-            TC.deep_clustering_forward(sd, lm)
-            mk = masks_s.transpose(0, 3, 1, 2)
+        elif kind == "phase_net":
+            ph = np.stack([np.stack([x.real, x.imag], -1) for x in X]).astype(np.float32)
+            _, a, b, _, _ = TC.phase_net_forward(sd, lm, ph)
+            mk = np.stack([a.numpy(), b.numpy()], 1)
+        else:                                    # the reference's own back end: sklearn KMeans on the active bins (evaluate.py:36-41)
+            from sklearn.cluster import KMeans
+            emb = TC.deep_clustering_forward(sd, lm).numpy()
+            mk = np.zeros((Bs, 2) + lm.shape[1:], np.float64)
+            for i in range(Bs):
+                act = O.dc_active_bins(lm[i])
+                lab = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(emb[i][act])
+                mk[i] = O.dc_binary_masks(lm[i], lab)
         for i in range(Bs):
             O.mask_istft(X[i], mk[i], HOP, N_SAMPLES)
 
@@ -669,6 +750,12 @@ def cpu_baseline(sd, kind, wav_np, masks_np):
     torch.set_num_threads(n_thr)
     med, best_thr, n_pass = best
 
+    if kind == "phase_net":          # (no network-only leg: SURVEY 8(d) quotes it for the mask-estimation networks)
+        torch.set_num_threads(n_thr)
+        return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
+                "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "cpu_model": cpu_model, "host_threads": n_thr, "kind": "port",
+                "sample": f"{Bs} of the batch's {T_FRAMES}-frame chunks per pass, median of {n_pass} passes "
+                          f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads)"}
     fwd = TC.chimera_forward if kind == "chimera" else TC.deep_clustering_forward
     lm_all = np.stack([O.log_magnitude(O.stft(w, NFFT, HOP)) for w in wav_np[:min(len(wav_np), 32)]])
     if len(lm_all) < 32:
@@ -697,9 +784,10 @@ def cpu_baseline(sd, kind, wav_np, masks_np):
                          "threads_tried": sorted(thr_set)}
     torch.set_num_threads(n_thr)
     return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
-            "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "kind": "port",
+            "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "cpu_model": cpu_model, "host_threads": n_thr, "kind": "port",
             "sample": f"{Bs} of the batch's 400-frame chunks per pass, median of {n_pass} passes "
-                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads)",
+                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads"
+                      + ("; sklearn KMeans(2) on the active bins' embeddings like egs/wsj0-2mix/deep_clustering/evaluate.py:36-41)" if kind == "deep_clustering" else ")"),
             "network_only": net}
 
 

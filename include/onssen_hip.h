@@ -80,6 +80,10 @@ extern "C" {
 #define ONSSEN_BLSTM_G_READY 128     /* measurement aid (bench.py times the recurrence kernel by itself): skip the input
                                        projection of every layer -- G is what an earlier call with the same arguments left
                                        in the workspace (L = 1 calls only make sense) */
+#define ONSSEN_BLSTM_WS_DIRTY 65536  /* (with XCD | BF16X3) the workspace behind its header was NOT zeroed for this shape (a grow-only
+                                       scratch buffer reused across ragged batches of changing length): the call clears the k
+                                       padding of the recurrence output images itself (two tiny launches) before it runs.  The
+                                       header must still have been zeroed once by the owner. */
 /* Debug flags (0 in production).  Launch-per-step form only: bits 8..11 switch off parts of the kernel for profiling
  * ablations (results are then meaningless): 0x100 h loads, 0x200 W_hh loads, 0x400 MFMA, 0x800 G/c loads; 0x1000 selects
  * libm-grade gate non-linearities.  ONSSEN_BLSTM_XCD form: 0x800 = TEST bit, rotates the exchange groups across the XCDs

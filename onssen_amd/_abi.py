@@ -17,6 +17,7 @@ BLSTM_FUSE_IN0 = 16
 BLSTM_FUSE_TAIL = 32
 BLSTM_BF16 = 64
 BLSTM_G_READY = 128
+BLSTM_WS_DIRTY = 65536
 LSTM_BWD_STEPS, LSTM_BWD_XCD = 0, 1
 DC_CLUSTER_LAUNCH_PER_ITERATION = 1
 BLSTM_WS_HEADER = 32768   # ONSSEN_BLSTM_WS_HEADER_BYTES: zeroed once by the workspace owner

@@ -732,6 +732,21 @@ int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t*
   return ONSSEN_OK;
 }
 
+// ONSSEN_BLSTM_WS_DIRTY: the k padding of a recurrence output image (columns 2*Hp .. 32*KB - 1 of every row) is never written by
+// the recurrence; a workspace that was not zeroed for this shape gets it cleared here (stale bits there could be bf16 NaNs,
+// and NaN x 0-weight = NaN in the next GEMM)
+__global__ void x3_pad_zero_kernel(unsigned short* __restrict__ img, long rows, int KB, int K) {
+  const int k0 = K & 31;                         // first padding column inside the last k block (0: no padding)
+  if (k0 == 0) return;
+  const int per = 32 - k0;
+  const long total = rows * 2 * per;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long row = e / (2 * per);
+    const int r = (int)(e - row * 2 * per), hl = r / per, kk = k0 + r % per;
+    img[(row * KB + (KB - 1)) * 64 + hl * 32 + kk] = 0;
+  }
+}
+
 static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                               int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                               const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
@@ -784,6 +799,13 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
   const bool bf16_only = images && (flags & ONSSEN_BLSTM_BF16);   // plain bf16 products instead of the three-term split
   uint16_t* img_x = (uint16_t*)((char*)ws + wl.off_imgx);
   uint16_t* img_ab[2] = {(uint16_t*)((char*)ws + wl.off_imga), (uint16_t*)((char*)ws + wl.off_imgb)};
+  if (images && (flags & ONSSEN_BLSTM_WS_DIRTY) && ((2 * Hp) & 31)) {
+    const long rows = (long)T * B;
+    const long n = rows * 2 * (32 - ((2 * Hp) & 31));
+    const unsigned nb = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    for (int i = 0; i < (L > 1 ? 2 : 1); ++i)
+      hipLaunchKernelGGL(x3_pad_zero_kernel, dim3(nb), dim3(256), 0, st, img_ab[i], rows, ceil_div(2 * Hp, 32), 2 * Hp);
+  }
   for (int l = 0; l < L; ++l) {
     // the last layer writes `y`; the layers before it alternate so that each reads what the previous wrote
     float* yout = ((L - 1 - l) % 2 == 0) ? y : ybuf;

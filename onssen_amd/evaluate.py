@@ -7,9 +7,11 @@ from .hip import get_lib
 _WS = {}
 
 
-def batch_SDR_torch(estimation, origin, mask=None, return_perm=False):
+def batch_SDR_torch(estimation, origin, mask=None, return_perm=False, lengths=None):
     """estimation, origin (batch, nsource, nsample); mask optional (batch, nsample).  Returns (batch,) mean SDR of the
-    best permutation (and, with return_perm, the permutation's index in lexicographic order, like upstream)."""
+    best permutation (and, with return_perm, the permutation's index in lexicographic order, like upstream).
+    ``lengths`` (batch,) (extension): a ragged batch -- row b holds lengths[b] <= nsample samples, the rest is padding that
+    takes no part (same value, bit for bit, as the batch-1 call on the row's own samples)."""
     assert estimation.size() == origin.size(), "Estimation and original sources should have same shape."
     B, C, n = estimation.size()
     assert C < n, "Axis 1 should be the number of sources, and axis 2 should be the signal."
@@ -25,8 +27,12 @@ def batch_SDR_torch(estimation, origin, mask=None, return_perm=False):
         ws = _WS[(dev, B)] = torch.empty(lib.batch_sdr_workspace_bytes(B), dtype=torch.uint8, device=dev)
     sdr = torch.empty(B, device=dev, dtype=torch.float32)
     perm = torch.empty(B, device=dev, dtype=torch.int32)
+    if lengths is not None:
+        from .features import _lengths_i32
+        lengths = _lengths_i32(lengths, B, n, dev, "lengths")
     lib.batch_sdr(est.data_ptr(), org.data_ptr(), mk.data_ptr() if mk is not None else None, B, C, n, sdr.data_ptr(),
-                  perm.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                  perm.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream,
+                  lengths=lengths.data_ptr() if lengths is not None else None)
     return (sdr, perm.long()) if return_perm else sdr
 
 
@@ -52,49 +58,94 @@ class tester:
     def get_est_sig(self, input, label, output):
         raise NotImplementedError
 
-    def eval(self, window=16):
-        """Mean SI-SDR over the loader.  Upstream synchronises on every utterance (``.item()``); here ``window`` utterances
-        are queued back to back -- the host launches utterance i+1 while the device works on utterance i -- and the status
-        words of their persistent recurrences are examined once per window.  An aborted launch in a window re-runs that
-        window on the launch-per-step recurrence (inference is functional: same inputs, same outputs)."""
+    @staticmethod
+    def collate(items):
+        """K evaluation items (``[feature (1,T_k,F), ...], [stft_r (1,T_k,F), stft_i (1,T_k,F), sig_ref (1,C,n_k)]``, the
+        loader contract above) -> ONE ragged batch: every tensor zero-padded to the longest utterance, plus ``frames`` (K,)
+        and ``lengths`` (K,) int32 device tensors.  Inputs and all labels but the last are padded along the frame axis, the
+        last label (``sig_ref``) along the sample axis."""
+        from torch.nn.utils.rnn import pad_sequence
+        rows = [([t[r] for t in inp], [t[r] for t in lab]) for inp, lab in items for r in range(inp[0].shape[0])]
+        dev = rows[0][0][0].device
+        frames = [r[0][0].shape[0] for r in rows]
+        lengths = [r[1][-1].shape[-1] for r in rows]
+        inp = [pad_sequence([r[0][k] for r in rows], batch_first=True) for k in range(len(rows[0][0]))]
+        lab = [pad_sequence([r[1][k] for r in rows], batch_first=True) for k in range(len(rows[0][1]) - 1)]
+        lab.append(pad_sequence([r[1][-1].transpose(0, -1) for r in rows], batch_first=True).transpose(1, -1).contiguous())
+        return inp, lab, (torch.tensor(frames, dtype=torch.int32).to(dev, non_blocking=True),
+                          torch.tensor(lengths, dtype=torch.int32).to(dev, non_blocking=True))
+
+    def eval(self, window=8, batch=1):
+        """Mean SI-SDR over the loader.
+
+        ``batch`` = 1 is the reference's loop (onssen/utils/test.py:29-41: one utterance per forward).  That shape keeps 2
+        of the chip's 8 XCDs busy, so ``batch`` = K > 1 (16 fills the chip) evaluates K utterances of DIFFERENT lengths
+        per forward: they are zero-padded to the longest (``collate``) and every stage -- network, clustering / masks,
+        iSTFT, SI-SDR -- is told each row's own extent, so that every utterance's SDR is bit for bit the one the batch-1
+        loop computes.  ``get_est_sig`` must then accept ``frames=`` and ``lengths=`` (tester_dc / tester_chimera do).
+
+        Upstream synchronises on every utterance (``.item()``); here ``window`` forwards are queued back to back -- the host
+        launches forward i+1 while the device works on forward i -- and the status words of their persistent launches are
+        examined once per window.  An aborted launch re-runs that window on the launch-per-step recurrence (inference
+        is functional: same inputs, same outputs)."""
         import warnings
         from .nn._core import XcdAborted, XcdNonFinite, _XcdPolicy, _XcdStatus
         total, count = 0.0, 0
         self.model = self.model.eval()
 
-        def one(input, label):
-            output = self.model(input)
-            sig_est, sig_ref = self.get_est_sig(input, label, output)
-            return batch_SDR_torch(sig_est, sig_ref)
+        def one(input, label, ragged):
+            if ragged is None:
+                output = self.model(input)
+                sig_est, sig_ref = self.get_est_sig(input, label, output)
+                return batch_SDR_torch(sig_est, sig_ref)
+            frames, lengths = ragged
+            output = self.model(input, frames=frames)
+            sig_est, sig_ref = self.get_est_sig(input, label, output, frames=frames, lengths=lengths)
+            return batch_SDR_torch(sig_est, sig_ref, lengths=lengths)
 
         def rerun(pend, e):
             _XcdPolicy.recovered += 1
             if not isinstance(e, XcdNonFinite):
-                warnings.warn(f"onssen_amd: {e}  Re-running {len(pend)} utterance(s) on the launch-per-step recurrence.", RuntimeWarning)
+                warnings.warn(f"onssen_amd: {e}  Re-running {len(pend)} forward(s) on the launch-per-step recurrence.", RuntimeWarning)
             try:
-                _XcdStatus.flush()               # the window's other launches ran into the same abort word: drain their reports
+                _XcdStatus.flush(policy=False)   # the window's other launches ran into the same abort word: drain their reports
             except XcdAborted:
                 pass
             with _XcdPolicy.forced_steps():
-                sdrs = [one(input, label) for input, label, _ in pend]
+                sdrs = [one(input, label, ragged) for input, label, ragged, _ in pend]
                 _XcdStatus.flush()
             return sdrs
 
         def close(pend):
-            sdrs = [sdr for _, _, sdr in pend]
+            sdrs = [sdr for _, _, _, sdr in pend]
             try:
                 _XcdStatus.flush()
             except XcdAborted as e:
                 sdrs = rerun(pend, e)
             return float(torch.cat([x.reshape(-1) for x in sdrs]).double().sum()), sum(x.numel() for x in sdrs)
 
+        def forwards():
+            """(input, label, ragged) per forward: the loader's items as they come, or K of them collated."""
+            if int(batch) <= 1:
+                for input, label in self.test_loader:
+                    yield input, label, None
+                return
+            items = []
+            for item in self.test_loader:
+                items.append(item)
+                if sum(i[0][0].shape[0] for i in items) >= int(batch):
+                    yield self.collate(items)
+                    items = []
+            if items:
+                yield self.collate(items)
+
         with torch.no_grad():
             pend = []
-            for input, label in self.test_loader:
+            for input, label, ragged in forwards():
                 try:
-                    pend.append((input, label, one(input, label)))
+                    pend.append((input, label, ragged, one(input, label, ragged)))
                 except XcdAborted as e:          # reported by this forward's look at the statuses of the launches before it
-                    pend.append((input, label, None))
+                    pend.append((input, label, ragged, None))
                     sdrs = rerun(pend, e)
                     total += float(torch.cat([x.reshape(-1) for x in sdrs]).double().sum())
                     count += sum(x.numel() for x in sdrs)
@@ -122,12 +173,14 @@ class tester_dc(tester):
         super().__init__(args)
         self.hop_size, self.host_kmeans = hop_size, host_kmeans
 
-    def get_est_sig(self, input, label, output):
+    def get_est_sig(self, input, label, output, frames=None, lengths=None):
         from .features import mask_istft
         from .separation import dc_masks
         feature_mix, = input
         embedding, = output
         ri, sig_ref = _mix_ri(label)
+        if self.host_kmeans and frames is not None:
+            raise ValueError("tester_dc(host_kmeans=True) evaluates one utterance per forward (eval(batch=1))")
         if self.host_kmeans:
             import numpy as np
             from sklearn.cluster import KMeans
@@ -138,8 +191,8 @@ class tester_dc(tester):
                 lab = torch.from_numpy(lab.astype(np.int64)).to(feature_mix.device).float()
                 masks[b][act] = torch.stack([lab, 1.0 - lab], -1)
         else:
-            masks = dc_masks(embedding, feature_mix.float(), 40.0)
-        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1]), sig_ref.float()
+            masks = dc_masks(embedding, feature_mix.float(), 40.0, frames=frames)
+        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1], frames=frames, lengths=lengths), sig_ref.float()
 
 
 class tester_chimera(tester):
@@ -149,9 +202,9 @@ class tester_chimera(tester):
         super().__init__(args)
         self.hop_size = hop_size
 
-    def get_est_sig(self, input, label, output):
+    def get_est_sig(self, input, label, output, frames=None, lengths=None):
         from .features import mask_istft
         _, mask_A, mask_B = output
         ri, sig_ref = _mix_ri(label)
         masks = torch.stack([mask_A, mask_B], -1)
-        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1]), sig_ref.float()
+        return mask_istft(ri, masks, self.hop_size, sig_ref.shape[-1], frames=frames, lengths=lengths), sig_ref.float()

@@ -12,13 +12,31 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def stft_logmag(wav, window_size=256, hop_size=64, epsilon=1e-7, return_stft=True):
+def _lengths_i32(lengths, B, hi, device, what):
+    """Per-row extents of a ragged batch as an int32 device tensor (validated on the host when they come from it)."""
+    if torch.is_tensor(lengths) and lengths.is_cuda:
+        out = lengths.to(device=device, dtype=torch.int32).contiguous()
+    else:
+        host = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1)
+        if host.numel() != B or int(host.min()) < 1 or int(host.max()) > hi:
+            raise ValueError(f"{what}: expected {B} values in [1, {hi}], got {host.tolist()}")
+        out = host.to(device=device, dtype=torch.int32)
+    if out.numel() != B:
+        raise ValueError(f"{what}: expected {B} values, got {out.numel()}")
+    return out
+
+
+def stft_logmag(wav, window_size=256, hop_size=64, epsilon=1e-7, return_stft=True, lengths=None):
     """wav (B, n) or (n,) float32 cuda tensor ->
     (log_magnitude (B,T,F) float32, stft_ri (B,T,F,2) float32 | None).
 
     stft_ri[..., 0] + 1j*stft_ri[..., 1] is what feature_utils.get_stft
     returns per utterance (frame x frequency complex64; librosa<0.10 defaults:
-    periodic Hann, centred, reflect padding); stft_ri itself is get_phase."""
+    periodic Hann, centred, reflect padding); stft_ri itself is get_phase.
+
+    ``lengths`` (B,): a RAGGED batch -- row b holds lengths[b] <= n valid samples (the rest is padding and is never
+    read); its 1 + lengths[b] // hop frames are bit for bit those of a batch-1 call on wav[b, :lengths[b]], the frames
+    after them are silence."""
     if wav.dim() == 1:
         wav = wav[None]
     if not wav.is_cuda:
@@ -30,15 +48,23 @@ def stft_logmag(wav, window_size=256, hop_size=64, epsilon=1e-7, return_stft=Tru
     T, F = 1 + n // hop_size, window_size // 2 + 1
     logmag = torch.empty(B, T, F, device=wav.device, dtype=torch.float32)
     ri = torch.empty(B, T, F, 2, device=wav.device, dtype=torch.float32) if return_stft else None
+    if lengths is not None:
+        lengths = _lengths_i32(lengths, B, n, wav.device, "lengths")
+        if not torch.cuda.is_current_stream_capturing() and int(lengths.min()) <= window_size // 2:
+            raise ValueError("stft_logmag: every utterance must be longer than window_size / 2 samples (reflect padding)")
     get_lib().stft_logmag(wav.data_ptr(), B, n, wav.stride(0), window_size, hop_size, float(epsilon),
-                          logmag.data_ptr(), ri.data_ptr() if ri is not None else None, _stream())
+                          logmag.data_ptr(), ri.data_ptr() if ri is not None else None, _stream(),
+                          n_per_utt=lengths.data_ptr() if lengths is not None else None)
     return logmag, ri
 
 
-def mask_istft(stft_ri, masks, hop_size=64, length=None):
+def mask_istft(stft_ri, masks, hop_size=64, length=None, frames=None, lengths=None):
     """stft_ri (B,T,F,2); masks (B,T,F,C) (any strides) or None ->
     (B, C, length) float32: istft(stft * mask_c) per speaker, librosa
-    semantics (hop, length=nsample)."""
+    semantics (hop, length=nsample).
+
+    ``frames`` / ``lengths`` (B,): a RAGGED batch -- row b has frames[b] <= T frames and lengths[b] <= length output
+    samples (zeros after them); inside them the result is bit for bit that of a batch-1 call on that utterance."""
     if not stft_ri.is_cuda:
         raise RuntimeError("mask_istft: needs tensors on a ROCm device; onssen_amd has no CPU fallback")
     stft_ri = stft_ri.float().contiguous()
@@ -47,16 +73,23 @@ def mask_istft(stft_ri, masks, hop_size=64, length=None):
     if length is None:
         length = hop_size * (T - 1)
     lib = get_lib()
+    rag = {}
+    if (frames is None) != (lengths is None):
+        raise ValueError("mask_istft: a ragged batch needs both frames= and lengths=")
+    if frames is not None:
+        frames = _lengths_i32(frames, B, T, stft_ri.device, "frames")
+        lengths = _lengths_i32(lengths, B, length, stft_ri.device, "lengths")
+        rag = dict(frames=frames.data_ptr(), lengths=lengths.data_ptr())
     if masks is None:
         out = torch.empty(B, 1, length, device=stft_ri.device, dtype=torch.float32)
         lib.mask_istft(stft_ri.data_ptr(), None, 0, 0, 0, 0, B, 1, T, n_fft, hop_size, length, out.data_ptr(),
-                       _stream())
+                       _stream(), **rag)
         return out
     masks = masks.float()
     C = masks.shape[3]
     out = torch.empty(B, C, length, device=stft_ri.device, dtype=torch.float32)
     lib.mask_istft(stft_ri.data_ptr(), masks.data_ptr(), masks.stride(0), masks.stride(3), masks.stride(1),
-                   masks.stride(2), B, C, T, n_fft, hop_size, length, out.data_ptr(), _stream())
+                   masks.stride(2), B, C, T, n_fft, hop_size, length, out.data_ptr(), _stream(), **rag)
     return out
 
 

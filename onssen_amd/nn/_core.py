@@ -188,8 +188,13 @@ class _XcdStatus:
         cls.pending.append((ev, host, (ws, offset)))
 
     @classmethod
-    def poll(cls, wait=False):
+    def poll(cls, wait=False, policy=True):
+        """Examine the recorded status words whose copies have landed.  The back-off policy is updated ONCE per call -- an
+        abort if any examined launch aborted, otherwise "ok" if a persistent recurrence completed (a completed launch of
+        another workspace in the same poll must not reset the streak an abort has just extended) -- and not at all with
+        ``policy=False`` (draining the reports of launches that ran into an abort word that was already counted)."""
         keep, err = [], None
+        saw_abort, saw_ok = False, False
         for ev, host, wsb in cls.pending:
             if wait:
                 ev.synchronize()
@@ -200,8 +205,7 @@ class _XcdStatus:
                 if int(host[0]) != 0:
                     ws, off = wsb
                     ws[off:off + 4].zero_()
-                    if not isinstance(err, XcdAborted):
-                        _XcdPolicy.on_abort()
+                    saw_abort = True
                     err = err if isinstance(err, XcdAborted) else XcdAborted(
                         "persistent 2-means launch gave up a bounded wait (its workgroups were not co-resident): the masks of "
                         "that call are not the converged ones.")
@@ -209,7 +213,7 @@ class _XcdStatus:
             if int(host[1]) == 1:
                 cls.safe_protocol_seen = True
             if int(host[0]) == 0:
-                _XcdPolicy.on_ok()
+                saw_ok = True
             if int(host[0]) != 0 or int(host[2]) != 0:
                 wsb[1120:1132].zero_()                  # abort / non-finite words: the next launch starts clean
                 if int(host[0]) != 0:
@@ -217,8 +221,7 @@ class _XcdStatus:
                     # advanced): the next persistent launch on this workspace would walk through its start-up barrier.
                     # Nothing is in flight here (the event has fired): the owner zeroes the whole exchange header again.
                     wsb[:_abi.BLSTM_WS_HEADER].zero_()
-                    if not isinstance(err, XcdAborted):
-                        _XcdPolicy.on_abort()           # once per reported call (its launches abort together)
+                    saw_abort = True
                     err = err if isinstance(err, XcdAborted) else XcdAborted(
                         f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
                         "(and, in training, the gradients) of that call are invalid.")
@@ -233,14 +236,19 @@ class _XcdStatus:
                         "reference's NaNs.  ONSSEN_XCD=0 (launch per step) propagates them like nn.LSTM; ONSSEN_NONFINITE=propagate "
                         "makes separate_* / tester.eval / train_step re-run such a call that way by themselves.")
         cls.pending = keep
+        if policy:
+            if saw_abort:
+                _XcdPolicy.on_abort()                   # once per poll: the launches of a call (and of its window) abort together
+            elif saw_ok:
+                _XcdPolicy.on_ok()
         if err is not None:
             raise err
 
     @classmethod
-    def flush(cls):
+    def flush(cls, policy=True):
         """Wait for every recorded status and raise if a launch aborted (see the class docstring)."""
         if cls.pending and not torch.cuda.is_current_stream_capturing():
-            cls.poll(wait=True)
+            cls.poll(wait=True, policy=policy)
 
 
 def _flush_at_exit():
@@ -491,6 +499,20 @@ class _Workspaces:
             self.cache[key] = buf
         return buf
 
+    def scratch(self, tag, nbytes, header, device):
+        """Grow-only buffer for call shapes that keep changing (ragged batches of whole utterances: a new longest
+        utterance per batch): allocated uninitialised, only the first ``header`` bytes zeroed, reused as it is by every later
+        call that fits -- a shape-keyed cache would allocate and memset a 100-300 MB workspace per batch.  The callee
+        is told that the rest is dirty (ONSSEN_BLSTM_WS_DIRTY).  Not for hipGraph capture (a regrowth would free memory a
+        captured graph still points into): captures take the shape-keyed cache."""
+        key = ("scratch", tag)
+        buf = self.cache.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(max(nbytes, int(nbytes * 1.25)), dtype=torch.uint8, device=device)
+            buf[:header].zero_()
+            self.cache[key] = buf
+        return buf
+
 
 def require_device(x, who):
     if not x.is_cuda:
@@ -506,22 +528,52 @@ def heads_take_image(B, H, groups=()):
             and all(g % 4 == 0 and 80 % g == 0 and 80 // g <= 4 for g in groups))
 
 
-def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
+def as_frames(frames, B, T, device):
+    """Per-row frame counts of a ragged batch as an int32 device tensor (validated on the host when they come from it)."""
+    if torch.is_tensor(frames) and frames.is_cuda:
+        fr = frames.to(device=device, dtype=torch.int32).contiguous()
+    else:
+        host = torch.as_tensor(frames, dtype=torch.int64).reshape(-1)
+        if host.numel() != B or int(host.min()) < 1 or int(host.max()) > T:
+            raise ValueError(f"frames: expected {B} values in [1, {T}], got {host.tolist()}")
+        fr = host.to(device=device, dtype=torch.int32)
+    if fr.numel() != B:
+        raise ValueError(f"frames: expected {B} values, got {fr.numel()}")
+    return fr
+
+
+def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, frames=None):
     """x (B,T,In) float32 cuda -> y (T,B,2,Hp) time-major (padded units are 0).  With ``need_y=False`` (see
-    heads_take_image) only the x3 image attached to the result is valid."""
+    heads_take_image) only the x3 image attached to the result is valid.
+
+    ``frames`` (int32 device tensor, see as_frames): a RAGGED batch of whole utterances padded to T -- row b is live at
+    t < frames[b] and holds h = c = 0 (output rows 0) elsewhere, so that its outputs are bit for bit those of a batch-1
+    call on that utterance alone (the reference evaluates one utterance at a time, onssen/utils/test.py:29-41).  Runs the
+    ragged instantiation of the persistent recurrence (split-bf16, first layer unfused); exact fp32 takes the
+    launch-per-step recurrence; the opt-in bf16 mode has no ragged form."""
     lib = get_lib()
     p = packed.p
     B, T, In = x.shape
     if not torch.cuda.is_current_stream_capturing():
         _XcdStatus.poll()
-    ug, flags = recurrence_plan(B, p.hidden_size)
+    if frames is not None and precision() == "bf16":
+        raise RuntimeError("ragged batches (frames=...) are not available with ONSSEN_PRECISION=bf16")
+    if frames is not None and precision() == "f32":
+        with _XcdPolicy.forced_steps():                 # the exact-fp32 persistent kernel has no ragged instantiation
+            ug, flags = recurrence_plan(B, p.hidden_size)
+    else:
+        ug, flags = recurrence_plan(B, p.hidden_size)
     pk = packed.get(ug)
     if In != p.input_size:
         raise RuntimeError(f"input feature size {In} != {p.input_size}")
     if x.stride(2) != 1:
         x = x.contiguous()
     nbytes = lib.blstm_workspace_bytes(B, T, In, p.hidden_size, p.num_layers, pk.ug)
-    wsb = ws.get((tag, B, T), nbytes, x.device)
+    if frames is not None and not torch.cuda.is_current_stream_capturing():
+        wsb = ws.scratch(tag, nbytes, _abi.BLSTM_WS_HEADER, x.device)      # a new longest utterance per batch: no per-shape buffers
+        flags |= _abi.BLSTM_WS_DIRTY
+    else:
+        wsb = ws.get((tag, B, T), nbytes, x.device)
     y = torch.empty(T, B, 2, pk.Hp, device=x.device, dtype=torch.float32)
     images = bool(flags & _abi.BLSTM_XCD) and bool(flags & _abi.BLSTM_BF16X3)     # activations travel as x3 images
     wih = pk.wih_img if images else pk.wih_x3 if flags & _abi.BLSTM_BF16X3 else pk.wih
@@ -530,7 +582,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
     # faster at B=64, 1.0 % at B=32 (it lost 2.4 % there before), 1.6 % SLOWER at B=16 -- the fused MFMAs cost every
     # time step the same, the GEMM (and the 246 MB of G) they replace shrink with the batch
     fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
-    if images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)):
+    if frames is None and images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)):
         flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
         wih = [pk.wih_frag0] + list(wih[1:])
         if pk.bias0_tail is not None:
@@ -540,7 +592,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True):
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in bias], y.data_ptr() if need_y or not images else None,
-                      wsb.data_ptr(), wsb.numel(), flags, _stream())
+                      wsb.data_ptr(), wsb.numel(), flags, _stream(), frames=frames.data_ptr() if frames is not None else None)
     if p.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
         _XcdPolicy.note_launch(bool(flags & _abi.BLSTM_XCD))
     y.x3_image = None

@@ -4,7 +4,7 @@ import torch.nn.functional as F
 
 from ._train import head_linear, l2_normalize
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
-                    heads_take_image, require_device, run_blstm, run_head, run_head_pair, use_hip_path)
+                    as_frames, heads_take_image, require_device, run_blstm, run_head, run_head_pair, use_hip_path)
 
 
 class chimera(PackedWeightsMixin, nn.Module):
@@ -27,22 +27,28 @@ class chimera(PackedWeightsMixin, nn.Module):
         self._ws = _Workspaces()
         self._init_packed_hooks()
 
-    def forward(self, input):
+    def forward(self, input, frames=None):
+        """``frames`` (extension; inference only): per-row frame counts of a ragged batch of whole utterances, as in
+        ``deep_clustering.forward``."""
         assert len(input) == 1, "There must be one tensor in the input for the chimera network"
         x = input[0].float()
         batch_size, frame, frequency = x.size()
         if not use_hip_path(self) or needs_graph(*input):
+            if frames is not None:
+                raise RuntimeError("chimera: frames=... (ragged batch) is an inference-path extension")
             return self._autograd_forward(x)
-        emb, masks = self.embedding_and_masks(x)
+        emb, masks = self.embedding_and_masks(x, frames)
         return [emb, masks[:, :, :, 0], masks[:, :, :, 1]]
 
-    def embedding_and_masks(self, x):
+    def embedding_and_masks(self, x, frames=None):
         """HIP inference path: x (B,T,F) -> (embedding (B,T,F,D), masks (B,T,F,C)); ``forward``
         returns the per-speaker slices of ``masks`` like upstream (chimera.py:43-45)."""
         x = x.float()
         batch_size, frame, frequency = x.size()
         require_device(x, "chimera")
-        y = run_blstm(self._packed, self._ws, x,
+        if frames is not None:
+            frames = as_frames(frames, batch_size, frame, x.device)
+        y = run_blstm(self._packed, self._ws, x, frames=frames,
                       need_y=not heads_take_image(batch_size, self.hidden_dim, (self.embedding_dim,)))
         # both heads in one launch where the recurrence left its x3 image: fc_mi's columns ride in fc_dc's last, mostly empty tile
         pair = run_head_pair(self._head_dc, self._head_mi, y, batch_size, frame, self.embedding_dim)

@@ -4,7 +4,7 @@ import torch.nn.functional as F
 
 from ._train import batch_norm_rows, head_linear, l2_normalize
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
-                    heads_take_image, require_device, run_blstm, run_head, use_hip_path)
+                    as_frames, heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
 
 class deep_clustering(PackedWeightsMixin, nn.Module):
@@ -29,14 +29,21 @@ class deep_clustering(PackedWeightsMixin, nn.Module):
         self._ws = _Workspaces()
         self._init_packed_hooks()
 
-    def forward(self, input):
+    def forward(self, input, frames=None):
+        """``frames`` (extension; inference only): per-row frame counts of a RAGGED batch of whole utterances padded to
+        the longest -- every row's embedding at its own frames is bit for bit what a batch-1 forward of that utterance
+        returns (the reference's evaluation runs them one at a time, onssen/utils/test.py:29-41)."""
         assert len(input) == 1, "There must be one tensor in the input for the deep clustering model"
         x = input[0].float()
         batch_size, frame, frequency = x.size()
         if not use_hip_path(self) or needs_graph(*input):
+            if frames is not None:
+                raise RuntimeError("deep_clustering: frames=... (ragged batch) is an inference-path extension")
             return [self._autograd_forward(x)]
         require_device(x, "deep_clustering")
-        y = run_blstm(self._packed, self._ws, x,
+        if frames is not None:
+            frames = as_frames(frames, batch_size, frame, x.device)
+        y = run_blstm(self._packed, self._ws, x, frames=frames,
                       need_y=not heads_take_image(batch_size, self.hidden_dim, (self.embedding_dim,)))
         emb = run_head(self._head, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
         return [emb.view(batch_size, frame, frequency, -1)]

@@ -10,28 +10,44 @@ from .features import mask_istft, stft_logmag
 from .nn._core import _XcdStatus, recovering
 
 
+def _ragged(wav, lengths, hop_size):
+    """(lengths, frames) as int32 device tensors for a ragged batch of waveforms, or (None, None)."""
+    if lengths is None:
+        return None, None
+    from .features import _lengths_i32
+    lengths = _lengths_i32(lengths, wav.shape[0], wav.shape[-1], wav.device, "lengths")
+    return lengths, (1 + lengths // hop_size).to(torch.int32)
+
+
 @recovering
 @torch.no_grad()
-def separate_chimera(model, wav, window_size=256, hop_size=64):
-    """wav (B, n) cuda float32 -> (B, 2, n): masks straight from the network."""
-    logmag, ri = stft_logmag(wav, window_size, hop_size)
-    _, masks = model.embedding_and_masks(logmag)
-    out = mask_istft(ri, masks, hop_size, wav.shape[-1])
+def separate_chimera(model, wav, window_size=256, hop_size=64, lengths=None):
+    """wav (B, n) cuda float32 -> (B, 2, n): masks straight from the network.  ``lengths`` (B,): a ragged batch of whole
+    utterances padded to n samples (see separate_dc)."""
+    lengths, frames = _ragged(wav, lengths, hop_size)
+    logmag, ri = stft_logmag(wav, window_size, hop_size, lengths=lengths)
+    _, masks = model.embedding_and_masks(logmag, frames)
+    out = mask_istft(ri, masks, hop_size, wav.shape[-1], frames=frames, lengths=lengths)
     _XcdStatus.flush()            # an aborted recurrence is caught HERE (and the call re-run, see `recovering`), not by the next call
     return out
 
 
 _CLUSTER_WS = {}
+_CLUSTER_SCRATCH = {}      # device -> grow-only buffer of the ragged / shape-changing calls (see dc_masks)
 
 
-def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
+def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None):
     """Binary deep-clustering masks (B,T,F,2) on the device: threshold at max - db/20, 2-means on the active
     bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host).
 
     Default: the active bins are compacted once and all Lloyd iterations run in ONE persistent launch (8 workgroups per
     utterance meeting at a counter); its waits are bounded, and a wait that gave up is reported like an aborted recurrence
     (``_XcdStatus``: the owning call is re-run with the launch-per-iteration form, which is also what runs inside
-    ``_XcdPolicy.forced_steps()`` and with ONSSEN_DC_PERSISTENT=0)."""
+    ``_XcdPolicy.forced_steps()`` and with ONSSEN_DC_PERSISTENT=0).
+
+    ``frames`` (B,): a ragged batch -- utterance b owns its first frames[b] frames; its padding is never active, takes no
+    part in the threshold or the sums, and gets zero masks.  Such calls (a new longest utterance per batch) share ONE
+    grow-only workspace per device, allocated uninitialised with only its header zeroed."""
     import os
     from . import _abi
     from .hip import get_lib
@@ -41,18 +57,36 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
     emb, logmag = emb.contiguous(), logmag.contiguous()
     nb = int(lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D))
     key = (emb.device, B, T, F, D)
-    ws = _CLUSTER_WS.get(key)
-    if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
-        if len(_CLUSTER_WS) >= 4:
-            _CLUSTER_WS.clear()
-        ws = _CLUSTER_WS[key] = torch.zeros(nb, dtype=torch.uint8, device=emb.device)     # status word starts out zero
+    capturing = torch.cuda.is_current_stream_capturing()
+    head = nb - B * T * F * D * 4          # everything in front of the compaction area: centroids, counters, the status word
+    if frames is not None:
+        # ragged batches bring a new longest utterance every time: ONE grow-only buffer per device, allocated uninitialised;
+        # only the (small) header is zeroed -- the compaction area, as large as the embedding, is written before it is read
+        if capturing:
+            raise RuntimeError("dc_masks: ragged batches (frames=...) cannot be captured in a hipGraph (shared grow-only workspace)")
+        ws = _CLUSTER_SCRATCH.get(emb.device)
+        if ws is None or ws.numel() < nb:
+            ws = _CLUSTER_SCRATCH[emb.device] = torch.empty(max(nb, int(nb * 1.25)), dtype=torch.uint8, device=emb.device)
+        ws[:head].zero_()                  # (the status word of an earlier call was examined by _XcdStatus before this one is issued)
+    else:
+        ws = _CLUSTER_WS.pop(key, None)    # per-shape buffers (hipGraph-capturable), most recently used last, at most 8
+        if ws is None:
+            if capturing:
+                raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
+            while len(_CLUSTER_WS) >= 8:
+                _CLUSTER_WS.pop(next(iter(_CLUSTER_WS)))
+            ws = torch.empty(nb, dtype=torch.uint8, device=emb.device)
+            ws[:head].zero_()              # status word starts out zero
+        _CLUSTER_WS[key] = ws
     persistent = os.environ.get("ONSSEN_DC_PERSISTENT", "1") == "1" and _XcdPolicy.force_steps == 0
     masks = torch.empty(B, T, F, 2, device=emb.device, dtype=torch.float32)
+    if frames is not None:
+        from .features import _lengths_i32
+        frames = _lengths_i32(frames, B, T, emb.device, "frames")
     lib.dc_cluster(emb.data_ptr(), logmag.data_ptr(), B, T, F, D, float(db_threshold), iters, masks.data_ptr(),
                    ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream,
-                   flags=0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
+                   flags=0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION,
+                   frames=frames.data_ptr() if frames is not None else None)
     if persistent:
         _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
@@ -60,18 +94,26 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20):
 
 @recovering
 @torch.no_grad()
-def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, host_kmeans=False):
+def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, host_kmeans=False, lengths=None):
     """Deep-clustering separation, waveform in -> (B, 2, n) waveforms out, entirely on the GPU
     (STFT -> network -> threshold + 2-means -> binary masks -> mask-apply + iSTFT).  ``host_kmeans=True``
     clusters with sklearn KMeans(n_clusters=2, random_state=0) on the host exactly as upstream does
     (egs/wsj0-2mix/deep_clustering/evaluate.py:36-38); the two differ only in the arbitrary cluster
-    numbering and in bins that sit between the clusters."""
-    logmag, ri = stft_logmag(wav, window_size, hop_size)
-    emb, = model([logmag])
+    numbering and in bins that sit between the clusters.
+
+    ``lengths`` (B,): a RAGGED batch of whole utterances -- row b holds lengths[b] valid samples of the n it is padded to
+    (the reference separates them one at a time, onssen/utils/test.py:29-41; together they fill the chip).  Every row's
+    result inside its own length is bit for bit what the batch-1 call on wav[b:b+1, :lengths[b]] returns; zeros after it."""
+    lengths, frames = _ragged(wav, lengths, hop_size)
+    logmag, ri = stft_logmag(wav, window_size, hop_size, lengths=lengths)
+    emb, = model([logmag]) if frames is None else model([logmag], frames=frames)
     if not host_kmeans:
-        out = mask_istft(ri, dc_masks(emb, logmag, db_threshold), hop_size, wav.shape[-1])
+        out = mask_istft(ri, dc_masks(emb, logmag, db_threshold, frames=frames), hop_size, wav.shape[-1], frames=frames,
+                         lengths=lengths)
         _XcdStatus.flush()        # an aborted recurrence is reported by THIS call, not by the next one
         return out
+    if frames is not None:
+        raise ValueError("separate_dc: host_kmeans=True takes uniform batches only")
     _XcdStatus.flush()
     from sklearn.cluster import KMeans
     B, T, F, D = emb.shape

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """GPU box: the evaluation loop the reference actually runs (onssen/utils/test.py:29-41 -- whole utterances, batch 1):
-tester_dc.eval() / tester_chimera.eval() over the synthetic evaluation loader.  Reports wall time per utterance, audio
-seconds per wall second, and how much of the wall time the GPU was busy (events around every utterance's work)."""
+tester_dc.eval() / tester_chimera.eval() over the synthetic evaluation loader, one utterance per forward like upstream
+(batch=1) and K utterances of different lengths per forward (batch=K, round 4: same SDRs bit for bit).  Reports wall time
+per utterance and audio seconds per wall second."""
 import json, os, sys, time
 import torch
 os.environ.setdefault("ONSSEN_SYNTHETIC_DATA", "1")
@@ -24,13 +25,14 @@ for cfg, cls, tcls in (("config_dc.json", "deep_clustering", tester_dc), ("confi
     args.checkpoint_path = None
     args.test_loader = list(wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", dev)) * 4    # resident: the loop itself is what is timed
     t = tcls(args)
-    t.eval()                                   # warm-up: weight packing, workspaces
-    torch.cuda.synchronize()
     secs = sum(float(lab[2].shape[-1]) / 8000.0 * lab[2].shape[0] for _, lab in args.test_loader)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sdr = t.eval()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     n = sum(1 for _ in args.test_loader)
-    print(f"{cls:16s} {n} utterances, {secs:.1f} s of audio: eval() {dt * 1e3:.1f} ms = {dt / n * 1e3:.2f} ms per utterance = {secs / dt:.0f} x real time (SI-SDR {sdr:.2f})", flush=True)
+    for batch in (1, 8, 16, 32):
+        t.eval(batch=batch)                        # warm-up: weight packing, workspaces
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sdr = t.eval(batch=batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"{cls:16s} batch {batch:2d}: {n} utterances, {secs:.1f} s of audio: eval() {dt * 1e3:.1f} ms = {dt / n * 1e3:.3f} ms per utterance = "
+              f"{secs / dt:.0f} x real time (SI-SDR {sdr:.4f})", flush=True)
