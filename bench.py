@@ -87,7 +87,7 @@ def build_workload(config, B, dev, rank=0, T=None):
     m0 = (torch.rand(B, Tn, F, generator=gen) > 0.5).float()
     bin_masks = torch.stack([m0, 1 - m0], -1).to(dev)   # stand-in for the K-means assignment
 
-    from onssen_amd.separation import dc_masks
+    from onssen_amd.separation import dc_masks, dc_masks_from_features
 
     def step_resident_masks():       # rounds 1-3's headline: the network's embedding is computed, the masks are a resident stand-in
         logmag, ri = stft_logmag(wav, nfft, hop)
@@ -102,9 +102,12 @@ def build_workload(config, B, dev, rank=0, T=None):
         elif kind == "chimera":
             emb, masks = model.embedding_and_masks(logmag)
             sig = mask_istft(ri, masks, hop, n)
-        else:                          # deep clustering: the real separation (threshold + 2-means -> binary masks)
-            emb, = model([logmag])
-            sig = mask_istft(ri, dc_masks(emb, logmag), hop, n)
+        else:                          # deep clustering: the real separation (threshold + 2-means -> binary masks), as
+            emb = dc_masks_from_features(model, logmag)      # separation.separate_dc runs it: the fc_dc GEMM stores only the
+            if emb is None:                                  # active bins' embeddings, straight into the clustering's array
+                e, = model([logmag])
+                emb = dc_masks(e, logmag)
+            sig = mask_istft(ri, emb, hop, n)
         return emb, sig
     return dict(kind=kind, H=H, L=L, B=B, F=F, D=D, SR=sr, NFFT=nfft, HOP=hop, T=Tn, N=n, model=model, wav=wav, wav_np=wav_np,
                 bin_masks=bin_masks, sd=sd, step=step, step_resident_masks=step_resident_masks)
@@ -625,11 +628,40 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
     mk = torch.rand(B, T, F, 2, device=dev)
     t_stft = timed(lambda: stft_logmag(wav, NFFT, HOP))
     t_istft = timed(lambda: mask_istft(lm_ri[1], mk, HOP, N_SAMPLES))
-    t_cluster = None
-    if kind == "deep_clustering":          # threshold + 2-means on the step's own embeddings (its time depends on the data)
+    t_cluster, dc_legs = None, None
+    if kind == "deep_clustering":          # the clustering back end on the step's own embeddings (its time depends on the data)
+        from onssen_amd.nn._core import heads_take_image, run_blstm
         from onssen_amd.separation import dc_masks
-        emb_k, = model([lm_ri[0]])
-        t_cluster = timed(lambda: dc_masks(emb_k, lm_ri[0]))
+        if images and heads_take_image(B, H, (D,)) and os.environ.get("ONSSEN_DC_COMPACT", "1") == "1":
+            # the compacted form (what the step runs): threshold -> target map | fc_dc GEMM scattering the active rows | cluster
+            nbk, comp_off, dest_off = lib.dc_compact_layout(B, T, F, D)
+            wsk = torch.zeros(nbk, dtype=torch.uint8, device=dev)
+            yk = run_blstm(model._packed, model._ws, lm_ri[0], need_y=False)
+            wsy, offy = yk.x3_image
+            mk2 = torch.empty(B, T, F, 2, device=dev)
+            lmk = lm_ri[0].contiguous()
+
+            def k_index():
+                lib.dc_index(lmk.data_ptr(), B, T, F, D, 40.0, wsk.data_ptr(), nbk, st())
+
+            def k_head():
+                lib.linear_x3p_compact(wsy.data_ptr() + offy, T * B, K1, hp.img.data_ptr(), hp.b.data_ptr(), hp.N, D, 1e-12,
+                                       wsk.data_ptr() + dest_off, T * F, F, wsk.data_ptr() + comp_off, B, T * F * D, bf16_only, st())
+
+            def k_index_cluster():
+                k_index()
+                lib.dc_cluster_compact(B, T, F, D, 20, mk2.data_ptr(), wsk.data_ptr(), nbk, st())
+            k_index(); k_head()
+            t_idx, t_headc = timed(k_index), timed(k_head)
+            t_cl = timed(k_index_cluster) - t_idx
+            n_act = int(wsk[int(lib.dll.onssen_dc_cluster_status_offset(B, D)) - B * 72 * 4:int(lib.dll.onssen_dc_cluster_status_offset(B, D))]
+                        .view(torch.int32).view(B, 72)[:, 64].sum())
+            dc_legs = {"threshold_target_map": t_idx * 1e3, "fc_dc_l2norm_active_rows_only": t_headc * 1e3,
+                       "init_lloyd_masks": t_cl * 1e3, "active_bin_fraction": n_act / float(B * T * F)}
+            t_cluster = t_idx + t_cl + (t_headc - t_head)      # what the back end adds to the step that had resident masks
+        else:
+            emb_k, = model([lm_ri[0]])
+            t_cluster = timed(lambda: dc_masks(emb_k, lm_ri[0]))
     stft_bytes = B * (N_SAMPLES * 4 + T * F * 4 * 3)           # waveform in; log-magnitude + (Re, Im) out
     istft_bytes = B * (T * F * 4 * 2 + T * F * 4 * 2 + 2 * N_SAMPLES * 4)   # (Re, Im) + two masks in; two waveforms out
     flop_rec = 2.0 * 2 * B * 4 * H * H * T                     # h W_hh^T, both directions, 2 FLOP/MAC
@@ -683,6 +715,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
                           "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0,
                           "recurrence_deeper_layers": (L - 1) * t_rec * 1e3 if lyr else 0.0,
                           "fc_dc_l2norm": t_head * 1e3, "threshold_2means_masks": t_cluster * 1e3, "mask_istft": t_istft * 1e3}
+        if dc_legs:
+            rec["dc_back_end_legs_ms"] = dc_legs
         rec["first_layer"] = {"fused_input_projection": True, "ms": t_l0f * 1e3, "us_per_time_step": t_l0f / T * 1e6,
                               "note": "x W_ih^T inside the recurrence launch (no G, no layer-0 GEMM); includes the 7 us feature split; "
                                       "the unfused alternative would be input_proj_l0 + one plain recurrence launch = "
@@ -691,6 +725,8 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "input_proj_l0_with_split": t_g0 * 1e3,
                           "input_proj_deeper_layers": (L - 1) * t_gin * 1e3 if lyr else 0.0, "recurrence_all_layers": L * t_rec * 1e3,
                           "fc_dc_l2norm": t_head * 1e3, "threshold_2means_masks": t_cluster * 1e3, "mask_istft": t_istft * 1e3}
+        if dc_legs:
+            rec["dc_back_end_legs_ms"] = dc_legs
     return rec
 
 

@@ -458,6 +458,34 @@ int onssen_batch_sdr_ragged_f32(const float* est, const float* org, const float*
                                 const int32_t* lengths, float* sdr_out, int* perm_out, void* ws, size_t ws_bytes,
                                 void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Deep-clustering separation without the embedding round trip (round 4).  Which bins are clustered is decided by the
+ * mixture's log-magnitude alone (`m = np.max(feature_mix) - 40/20; emb = embedding[feature_mix >= m, :]`,
+ * egs/wsj0-2mix/deep_clustering/evaluate.py:36-37) and is known before the network has run; the silent bins' embeddings
+ * are never read (their masks are 0).  So:
+ *   1. onssen_dc_index_f32 (after the STFT): per utterance the threshold, the number of active bins and a target map
+ *      dest[b][t*F + f] = row of bin (t, f) in the utterance's compacted array, -1 for a silent bin (int32, inside ws);
+ *   2. onssen_linear_x3p_compact: the fc_dc GEMM of onssen_linear_x3p with ONSSEN_EPI_L2NORM whose epilogue stores only the
+ *      normalised rows of the active bins, each straight into its row of the compacted array (comp, inside ws);
+ *   3. onssen_dc_cluster_compact_f32: farthest-point initialisation, all Lloyd iterations in one persistent launch and the
+ *      mask pass on the compacted array -- the same arithmetic as onssen_dc_cluster_f32 in its default form, bit-identical
+ *      masks, without the 10 320 B/frame embedding write, its re-read and the compaction pass.
+ * ws: onssen_dc_compact_workspace_bytes() bytes, 256-byte aligned, the part in front of the compacted array zeroed by its
+ * owner like onssen_dc_cluster_f32's (same status word: onssen_dc_cluster_status_offset); onssen_dc_compact_layout gives the
+ * byte offsets of `comp` ([B][T*F][D] floats, rows past an utterance's active count unused) and `dest` ([B][T*F] int32).
+ * frames: NULL, or per-utterance frame counts of a ragged batch (see the ragged entry points).
+ * onssen_linear_x3p_compact: a_img / w_img / bias / N / group / eps as onssen_linear_x3p (N = F * group); row m of the GEMM is
+ * (utterance m % R, frame m / R); dest_bs = ints per utterance in dest, comp_bs = floats per utterance in comp. */
+size_t onssen_dc_compact_workspace_bytes(int B, int T, int F, int D);
+int onssen_dc_compact_layout(int B, int T, int F, int D, size_t* comp_offset, size_t* dest_offset);
+int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frames, int F, int D, float db_threshold, void* ws,
+                        size_t ws_bytes, void* stream);
+int onssen_linear_x3p_compact(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
+                              float eps, const int32_t* dest, int64_t dest_bs, int F, float* comp, int R, int64_t comp_bs,
+                              int bf16_only, void* stream);
+int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                  void* stream);
+
 /* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
  * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */
 int onssen_debug_launch_chain(float* scratch, int n, int workgroups, void* stream);

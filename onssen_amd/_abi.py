@@ -81,6 +81,12 @@ SIGNATURES = {
     "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    # deep-clustering separation without the embedding round trip (round 4)
+    "onssen_dc_compact_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "onssen_dc_compact_layout": (_i, [_i, _i, _i, _i, _vp, _vp]),
+    "onssen_dc_index_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _vp, _sz, _vp]),
+    "onssen_linear_x3p_compact": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _f, _vp, _i64, _i, _vp, _i, _i64, _i, _vp]),
+    "onssen_dc_cluster_compact_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
     # ragged batches of whole utterances (round 4)
     "onssen_stft_logmag_ragged_f32": (_i, [_vp, _i, _i, _i64, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "onssen_blstm_forward_ragged_f32": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
@@ -303,6 +309,23 @@ class Lib:
     def labels(self, mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, stream):
         self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
                                               cos_s1, cos_s2, stream), "onssen_labels_f32")
+
+    def dc_compact_layout(self, B, T, F, D):
+        """(workspace bytes, byte offset of the compacted array, byte offset of the target map)."""
+        co, do = _sz(), _sz()
+        self.check(self.dll.onssen_dc_compact_layout(B, T, F, D, C.byref(co), C.byref(do)), "onssen_dc_compact_layout")
+        return int(self.dll.onssen_dc_compact_workspace_bytes(B, T, F, D)), co.value, do.value
+
+    def dc_index(self, feat, B, T, F, D, db, ws, ws_bytes, stream, frames=None):
+        self.check(self.dll.onssen_dc_index_f32(feat, B, T, frames, F, D, db, ws, ws_bytes, stream), "onssen_dc_index_f32")
+
+    def linear_x3p_compact(self, a_img, M, K, w_img, bias, N, group, eps, dest, dest_bs, F, comp, R, comp_bs, bf16_only, stream):
+        self.check(self.dll.onssen_linear_x3p_compact(a_img, M, K, w_img, bias, N, group, eps, dest, dest_bs, F, comp, R, comp_bs,
+                                                      int(bool(bf16_only)), stream), "onssen_linear_x3p_compact")
+
+    def dc_cluster_compact(self, B, T, F, D, iters, masks, ws, ws_bytes, stream, flags=0):
+        self.check(self.dll.onssen_dc_cluster_compact_f32(B, T, F, D, iters, masks, ws, ws_bytes, flags, stream),
+                   "onssen_dc_cluster_compact_f32")
 
     def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0, frames=None):
         if frames is not None:       # ragged batch: utterance b owns frames[b] * F bins

@@ -431,7 +431,7 @@ static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, i
   p.c_vec = !C2 && aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0 && (c_bs % 4) == 0;
   p.a_bs = (long)a_bs; p.w_bs = (long)w_bs; p.c_bs = (long)c_bs;
   p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = (long)c2_bs; p.n_split = n_split;
-  p.resid = nullptr; p.r_mod = 1;
+  p.resid = nullptr; p.r_mod = 1; p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM), (unsigned)batch);
   hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS, 4, 3, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   ONSSEN_LAUNCH_CHECK();
@@ -474,6 +474,7 @@ static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* 
   LinearXpArgs p;
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = group; p.eps = eps; p.resid = resid; p.r_mod = resid ? resid_mod : 1;
+  p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   p.a_bs = p.w_bs = p.c_bs = 0;
   p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
   static const int x3_gn = ONSSEN_KNOB_INT("ONSSEN_X3_GN", 4);
@@ -565,6 +566,7 @@ int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* 
   LinearXpArgs p;
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = group; p.eps = eps; p.resid = nullptr; p.r_mod = 1;
+  p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   p.a_bs = p.w_bs = p.c_bs = 0;
   p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = 0; p.n_split = n_split;
   p.tile_group = 4;
@@ -578,6 +580,36 @@ int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* 
                    else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 3, false, 320, 256>), gridq, dim3(512), 0, st, p); }
   else { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 1, false, 320, 128>), gridq, dim3(512), 0, st, p);
          else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_SIGMOID, 3, false, 320, 128>), gridq, dim3(512), 0, st, p); }
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_linear_x3p_compact(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
+                              float eps, const int32_t* dest, int64_t dest_bs, int F, float* comp, int R, int64_t comp_bs,
+                              int bf16_only, void* stream) {
+  if (!a_img || !w_img || !bias || !dest || !comp || R <= 0 || M <= 0 || K <= 0 || N <= 0 || F <= 0) return ONSSEN_E_ARG;
+  if (group <= 0 || (group % 4) != 0 || (80 % group) != 0 || 80 / group > 4 || N != F * group) return ONSSEN_E_ARG;
+  if (!aligned16(a_img) || !aligned16(w_img) || !aligned16(comp) || (comp_bs % 4) != 0) return ONSSEN_E_ALIGN;
+  const int KB = ceil_div(K, 32);
+  if ((long)lxq::BM_MAX * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  LinearXpArgs p;
+  p.A = a_img; p.W = w_img; p.bias = bias; p.C = comp; p.c_s0 = 0; p.c_s1 = (long)comp_bs; p.R = R; p.M = M; p.N = N;
+  p.KB = KB; p.group = group; p.eps = eps; p.resid = nullptr; p.r_mod = 1;
+  p.a_bs = p.w_bs = p.c_bs = 0;
+  p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
+  p.dest = dest; p.dest_bs = (long)dest_bs; p.F = F;
+  p.tile_group = 4;
+  p.c_vec = 1;
+  // half-height tiles where 256-row tiles would leave CUs idle (the cost model of onssen_linear_x3p)
+  const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 320), t128 = (long)ceil_div(M, 128) * ceil_div(N, 320);
+  const int bm = (double)ceil_div(t128, 256L) * 128 * 1.15 < (double)ceil_div(t256, 256L) * 256 ? 128 : 256;
+  const dim3 gridq((unsigned)ceil_div(N, 320), (unsigned)ceil_div(M, bm));
+  hipStream_t st = (hipStream_t)stream;
+  if (bm == 256) { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_COMPACT, 1, false, 320, 256>), gridq, dim3(512), 0, st, p);
+                   else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_COMPACT, 3, false, 320, 256>), gridq, dim3(512), 0, st, p); }
+  else { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_COMPACT, 1, false, 320, 128>), gridq, dim3(512), 0, st, p);
+         else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM_COMPACT, 3, false, 320, 128>), gridq, dim3(512), 0, st, p); }
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -1230,6 +1262,80 @@ static int dc_cluster_impl(const float* emb, const float* feature, int B, int T,
   }
   ONSSEN_KM_ASSIGN(1, masks);
 #undef ONSSEN_KM_ASSIGN
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+// ---- compacted form (round 4): index -> (the fc_dc GEMM scatters the active rows) -> cluster ---------------------------------
+size_t onssen_dc_compact_workspace_bytes(int B, int T, int F, int D) {
+  const size_t base = onssen_dc_cluster_workspace_bytes(B, T, F, D);
+  return base ? align256(base) + align256((size_t)B * T * F * sizeof(int32_t)) : 0;
+}
+
+int onssen_dc_compact_layout(int B, int T, int F, int D, size_t* comp_offset, size_t* dest_offset) {
+  if (onssen_dc_cluster_workspace_bytes(B, T, F, D) == 0) return ONSSEN_E_ARG;
+  if (comp_offset) *comp_offset = align256(onssen_dc_cluster_status_offset(B, D) + 256);
+  if (dest_offset) *dest_offset = align256(onssen_dc_cluster_workspace_bytes(B, T, F, D));
+  return ONSSEN_OK;
+}
+
+int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frames, int F, int D, float db_threshold, void* ws,
+                        size_t ws_bytes, void* stream) {
+  if (!feature || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX) return ONSSEN_E_ARG;
+  if (ws_bytes < onssen_dc_compact_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(ws) & 255u) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1) + 1;
+  float* w = (float*)ws;
+  int* iw = (int*)((char*)ws + align256(dc_cluster_header_floats(B, D) * sizeof(float)));
+  size_t dest_off = 0;
+  onssen_dc_compact_layout(B, T, F, D, nullptr, &dest_off);
+  int* dest = (int*)((char*)ws + dest_off);
+  const dim3 sgrid(km::NBLK, (unsigned)B);
+  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, (const float*)nullptr, feature, per_utt, D, db_threshold, w, stride, frames, F, (const int*)nullptr);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, (const float*)nullptr, per_utt, D, w, stride, iw);
+  hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, frames, F);
+  hipLaunchKernelGGL(kmeans2_index_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, dest, frames, F);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                  void* stream) {
+  if (!masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0) return ONSSEN_E_ARG;
+  if (flags & ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION) return ONSSEN_E_ARG;      // the compacted form IS the persistent form
+  if (ws_bytes < onssen_dc_compact_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(ws) & 255u) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const long per_utt = (long)T * F, stride = 1 + 2 * D + km::NBLK * 2 * (D + 1) + 1;
+  float* w = (float*)ws;
+  int* iw = (int*)((char*)ws + align256(dc_cluster_header_floats(B, D) * sizeof(float)));
+  unsigned* status = (unsigned*)((char*)ws + onssen_dc_cluster_status_offset(B, D));
+  size_t comp_off = 0, dest_off = 0;
+  onssen_dc_compact_layout(B, T, F, D, &comp_off, &dest_off);
+  const float* comp = (const float*)((char*)ws + comp_off);
+  const int* dest = (const int*)((char*)ws + dest_off);
+  const dim3 sgrid(km::NBLK, (unsigned)B);
+  hipLaunchKernelGGL(kmeans2_c0_kernel, dim3((unsigned)B), dim3(64), 0, st, comp, dest, per_utt, D, w, stride);
+  hipLaunchKernelGGL((kmeans2_search_kernel<2>), sgrid, dim3(256), 0, st, comp, (const float*)nullptr, per_utt, D, 0.0f, w, stride, (const int*)nullptr, F, (const int*)iw);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, comp, per_utt, D, w, stride, (int*)nullptr);
+  const unsigned spin = xcd_spin_limit();
+  static const int lloyd_utts = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int n = cus / km::NBP;
+    return n < 1 ? 1 : n > 32 ? 32 : n;
+  }();
+  for (int u0 = 0; u0 < B && iters > 0; u0 += lloyd_utts) {
+    const int nutt = B - u0 < lloyd_utts ? B - u0 : lloyd_utts;
+    const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
+    if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+    else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+  }
+  if (D == 20) hipLaunchKernelGGL((kmeans2_mask_compact_kernel<20>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);
+  else hipLaunchKernelGGL((kmeans2_mask_compact_kernel<0>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

@@ -36,6 +36,78 @@ _CLUSTER_WS = {}
 _CLUSTER_SCRATCH = {}      # device -> grow-only buffer of the ragged / shape-changing calls (see dc_masks)
 
 
+def _cluster_ws(device, key, nb, head, ragged):
+    """Workspace of the clustering back end.  Uniform shapes: one buffer per shape (hipGraph-capturable), most recently used
+    last, at most 8.  Ragged batches bring a new longest utterance every time: ONE grow-only buffer per device.  Either way
+    it is allocated uninitialised and only its first ``head`` bytes (centroids, counters, the status word -- everything in front
+    of the compacted array, which is as large as the embedding and is written before it is read) are zeroed."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ragged:
+        if capturing:
+            raise RuntimeError("dc_masks: ragged batches (frames=...) cannot be captured in a hipGraph (shared grow-only workspace)")
+        ws = _CLUSTER_SCRATCH.get(device)
+        if ws is None or ws.numel() < nb:
+            ws = _CLUSTER_SCRATCH[device] = torch.empty(max(nb, int(nb * 1.25)), dtype=torch.uint8, device=device)
+        ws[:head].zero_()                  # (the status word of an earlier call was examined by _XcdStatus before this one is issued)
+        return ws
+    ws = _CLUSTER_WS.pop(key, None)
+    if ws is None:
+        if capturing:
+            raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
+        while len(_CLUSTER_WS) >= 8:
+            _CLUSTER_WS.pop(next(iter(_CLUSTER_WS)))
+        ws = torch.empty(nb, dtype=torch.uint8, device=device)
+        ws[:head].zero_()                  # status word starts out zero
+    _CLUSTER_WS[key] = ws
+    return ws
+
+
+def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=None):
+    """Deep-clustering masks (B,T,F,2) straight from the mixture's log-magnitude WITHOUT materialising the embedding
+    (round 4): the active bins are known before the network runs (evaluate.py:36-37), so the threshold is turned into a
+    target map first (onssen_dc_index_f32), ``model``'s fc_dc GEMM stores only the active bins' normalised rows -- straight
+    into the compacted array the clustering reads (onssen_linear_x3p_compact) -- and threshold / initialisation / Lloyd /
+    masks run on that (onssen_dc_cluster_compact_f32).  Bit-identical masks to ``dc_masks(model([logmag])[0], logmag)``,
+    minus the 10 320 B/frame embedding write, its re-read and the compaction pass.
+
+    Returns None when this forward cannot take that route (not an eval-mode ``deep_clustering`` on the persistent split-bf16
+    path, an embedding width the GEMM's register epilogue does not hold, a forced launch-per-step re-run): the caller then
+    computes the embedding and calls ``dc_masks``."""
+    import os
+    from .hip import get_lib
+    from .nn._core import (_XcdPolicy, _XcdStatus, _stream, as_frames, heads_take_image, precision, run_blstm, use_hip_path)
+    from .nn.deep_clustering import deep_clustering
+    B, T, F = logmag.shape
+    D = getattr(model, "embedding_dim", 0)
+    if (not isinstance(model, deep_clustering) or not use_hip_path(model) or F != model.input_dim or precision() == "f32"
+            or (frames is not None and precision() == "bf16")
+            or os.environ.get("ONSSEN_DC_PERSISTENT", "1") != "1" or os.environ.get("ONSSEN_DC_COMPACT", "1") != "1"
+            or _XcdPolicy.force_steps != 0 or not heads_take_image(B, model.hidden_dim, (D,)) or D > 32):
+        return None
+    lib = get_lib()
+    logmag = logmag.float().contiguous()
+    if frames is not None:
+        frames = as_frames(frames, B, T, logmag.device)
+    nb, comp_off, dest_off = lib.dc_compact_layout(B, T, F, D)
+    ws = _cluster_ws(logmag.device, (logmag.device, B, T, F, D, "compact"), nb, comp_off, frames is not None)
+    st = torch.cuda.current_stream().cuda_stream
+    fr = frames.data_ptr() if frames is not None else None
+    lib.dc_index(logmag.data_ptr(), B, T, F, D, float(db_threshold), ws.data_ptr(), nb, st, frames=fr)
+    y = run_blstm(model._packed, model._ws, logmag, need_y=False, frames=frames)
+    img = getattr(y, "x3_image", None)
+    if img is None:                            # (the recurrence fell back between the check above and its own plan)
+        return None
+    wsb, off = img
+    Hp = y.shape[3]
+    hd = model._head.get(Hp)
+    lib.linear_x3p_compact(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
+                           ws.data_ptr() + dest_off, T * F, F, ws.data_ptr() + comp_off, B, T * F * D, precision() == "bf16", st)
+    masks = torch.empty(B, T, F, 2, device=logmag.device, dtype=torch.float32)
+    lib.dc_cluster_compact(B, T, F, D, iters, masks.data_ptr(), ws.data_ptr(), nb, st)
+    _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
+    return masks
+
+
 def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None):
     """Binary deep-clustering masks (B,T,F,2) on the device: threshold at max - db/20, 2-means on the active
     bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host).
@@ -56,28 +128,7 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None):
     B, T, F, D = emb.shape
     emb, logmag = emb.contiguous(), logmag.contiguous()
     nb = int(lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D))
-    key = (emb.device, B, T, F, D)
-    capturing = torch.cuda.is_current_stream_capturing()
-    head = nb - B * T * F * D * 4          # everything in front of the compaction area: centroids, counters, the status word
-    if frames is not None:
-        # ragged batches bring a new longest utterance every time: ONE grow-only buffer per device, allocated uninitialised;
-        # only the (small) header is zeroed -- the compaction area, as large as the embedding, is written before it is read
-        if capturing:
-            raise RuntimeError("dc_masks: ragged batches (frames=...) cannot be captured in a hipGraph (shared grow-only workspace)")
-        ws = _CLUSTER_SCRATCH.get(emb.device)
-        if ws is None or ws.numel() < nb:
-            ws = _CLUSTER_SCRATCH[emb.device] = torch.empty(max(nb, int(nb * 1.25)), dtype=torch.uint8, device=emb.device)
-        ws[:head].zero_()                  # (the status word of an earlier call was examined by _XcdStatus before this one is issued)
-    else:
-        ws = _CLUSTER_WS.pop(key, None)    # per-shape buffers (hipGraph-capturable), most recently used last, at most 8
-        if ws is None:
-            if capturing:
-                raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
-            while len(_CLUSTER_WS) >= 8:
-                _CLUSTER_WS.pop(next(iter(_CLUSTER_WS)))
-            ws = torch.empty(nb, dtype=torch.uint8, device=emb.device)
-            ws[:head].zero_()              # status word starts out zero
-        _CLUSTER_WS[key] = ws
+    ws = _cluster_ws(emb.device, (emb.device, B, T, F, D), nb, nb - B * T * F * D * 4, frames is not None)
     persistent = os.environ.get("ONSSEN_DC_PERSISTENT", "1") == "1" and _XcdPolicy.force_steps == 0
     masks = torch.empty(B, T, F, 2, device=emb.device, dtype=torch.float32)
     if frames is not None:
@@ -106,14 +157,17 @@ def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, hos
     result inside its own length is bit for bit what the batch-1 call on wav[b:b+1, :lengths[b]] returns; zeros after it."""
     lengths, frames = _ragged(wav, lengths, hop_size)
     logmag, ri = stft_logmag(wav, window_size, hop_size, lengths=lengths)
-    emb, = model([logmag]) if frames is None else model([logmag], frames=frames)
     if not host_kmeans:
-        out = mask_istft(ri, dc_masks(emb, logmag, db_threshold, frames=frames), hop_size, wav.shape[-1], frames=frames,
-                         lengths=lengths)
+        masks = dc_masks_from_features(model, logmag, db_threshold, frames=frames)      # the embedding never leaves the GEMM ...
+        if masks is None:                                                                 # ... unless this forward cannot do that
+            emb, = model([logmag]) if frames is None else model([logmag], frames=frames)
+            masks = dc_masks(emb, logmag, db_threshold, frames=frames)
+        out = mask_istft(ri, masks, hop_size, wav.shape[-1], frames=frames, lengths=lengths)
         _XcdStatus.flush()        # an aborted recurrence is reported by THIS call, not by the next one
         return out
     if frames is not None:
         raise ValueError("separate_dc: host_kmeans=True takes uniform batches only")
+    emb, = model([logmag])
     _XcdStatus.flush()
     from sklearn.cluster import KMeans
     B, T, F, D = emb.shape

@@ -21,9 +21,11 @@ def build_emu():
     parts = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc"))]   # one TU, several files
     newest = max(os.path.getmtime(f) for f in parts + HDRS)
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+        tmp = OUT + ".tmp%d" % os.getpid()      # build beside it, then rename: a process that has the old file mapped keeps its inode
         subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-I",
                                os.path.join(ROOT, "tests", "emu", "include"), "-pthread", "-shared", "-fPIC",
-                               SRC, "-o", OUT] + extra)
+                               SRC, "-o", tmp] + extra)
+        os.replace(tmp, OUT)
     return OUT
 
 

@@ -203,3 +203,24 @@ def test_loss_dc_gram_form_equals_the_literal_form():
     assert got.shape == (B, B)
     np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), rtol=1e-12)
     np.testing.assert_allclose(g_got.numpy(), g_ref.numpy(), rtol=1e-9, atol=1e-14)
+
+
+def test_two_process_bench_selftest_record():
+    """bench.py with WORLD_SIZE = 2 has run on hardware (two processes on ONE MI355X, ONSSEN_BENCH_ONE_DEVICE=1, gloo for the
+    harness' barrier / gathers, launch-per-step kernels so that two processes' persistent launches do not starve each other:
+    tools/gpu_r4b.sh).  The committed record must be what the driver's N > 1 contract asks for: one JSON line from rank 0, the
+    whole-job value over both ranks, every rank's own step time, the roofline block."""
+    import json
+    import os
+    fn = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_two_process_selftest.json")
+    lines = [l for l in open(fn).read().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert len(r["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in r["per_rank_ms_per_step"])
+    assert abs(r["ms_per_step"] - max(r["per_rank_ms_per_step"])) <= 1e-6 * r["ms_per_step"]      # MAX over ranks
+    audio_per_step = 2 * r["config"]["chunks_per_gpu"] * r["config"]["frames_per_chunk"] * 64 / 8000.0
+    assert abs(r["value"] - audio_per_step / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]        # whole job: both ranks' chunks
+    assert r["roofline"]["frac"] > 0 and r["roofline"]["legs_le_step"] is True
+    assert "2-means" in r["config"]["workload"] and r["config"]["parallelism"].startswith("utterance-sharded x2")
+    assert r["vs_baseline"] is None and r["data"] == "synthetic"

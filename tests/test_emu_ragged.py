@@ -265,3 +265,69 @@ def test_ragged_forms_the_persistent_kernel_does_not_have_are_refused(lib):
         with pytest.raises(_abi.OnssenError, match="code -1"):
             lib.blstm_forward(P(dummy), 18, 9, 2, 2, 9, 8, 1, 4, [P(dummy)], [P(dummy)], [P(dummy)], P(dummy), P(ws), ws.nbytes,
                               flags, None, frames=P(fr))
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_dc_compacted_pipeline_equals_the_full_embedding_pipeline(lib, monkeypatch, ragged):
+    """Round 4, the embedding never round-trips HBM: onssen_dc_index_f32 (threshold -> target map) + onssen_linear_x3p_compact
+    (the fc_dc GEMM stores only the active bins' rows, straight into the compacted array) + onssen_dc_cluster_compact_f32
+    against onssen_linear_x3p(L2NORM) + onssen_dc_cluster_f32: the same compacted rows and the same masks, bit for bit."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
+    lib.dll.onssen_xcd_spin_limit(40000000)
+    rng = np.random.default_rng(5)
+    B, T, F, D, K = 3, 11, 33, 20, 40
+    N, M = F * D, T * B
+    frames = [11, 7, 9] if ragged else None
+    # a head whose embeddings fall into two clusters: W maps two planted directions of the activations to two centroids
+    lab = rng.integers(0, 2, (B, T, F))
+    cen = rand(rng, 2, D)
+    x = _shm((B, T, K)); x[...] = 0.2 * rand(rng, B, T, K)
+    x[..., 0] = 1.0
+    W = _shm((N, K)); W[...] = 0.05 * rand(rng, N, K)
+    bias = _shm((N,)); bias[...] = 0
+    # per-bin offset along the constant input column: bins of frame-independent "speaker" pattern (varies with f only) ...
+    pat = rng.integers(0, 2, F)
+    W[:, 0] = cen[pat].reshape(-1)
+    feat = _shm((B, T, F)); feat[...] = (-3.0 + 2.9 * rng.random((B, T, F))).astype(np.float32)
+    feat[:, :, ::5] = -6.0                                         # silent bins
+    fr = None
+    if ragged:
+        fr = _shm((B,), dtype=np.int32); fr[...] = frames
+        for b in range(B):
+            feat[b, frames[b]:] = 30.0                             # louder than anything real: must not matter
+    KB = (K + 31) // 32
+    a_img, w_img = _shm((M, KB, 2, 32), dtype=np.uint16), _shm((N, KB, 2, 32), dtype=np.uint16)
+    lib.x3_image(P(x), K, T * K, B, M, K, P(a_img), None)
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    # (A) the full embedding, then the round-3 back end
+    emb = _shm((B, T, F, D), fill=np.nan)
+    lib.linear_x3p(P(a_img), M, K, P(w_img), P(bias), N, _abi.EPI_L2NORM, D, 1e-12, P(emb), B, N, T * N, None)
+    nbA = lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D)
+    wsA = _shm((nbA // 4 + 64,))
+    mA = _shm((B, T, F, 2), fill=np.nan)
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 12, P(mA), P(wsA), nbA, None, frames=P(fr) if ragged else None)
+    # (B) index -> compacting GEMM -> cluster
+    nbB, comp_off, dest_off = lib.dc_compact_layout(B, T, F, D)
+    wsB = _shm((nbB // 4 + 64,))
+    wsB.view(np.uint32)[comp_off // 4:] = 0x7fc00000            # NaNs where nothing may be read before it is written
+    mB = _shm((B, T, F, 2), fill=np.nan)
+    base = wsB.ctypes.data
+    lib.dc_index(P(feat), B, T, F, D, 40.0, base, nbB, None, frames=P(fr) if ragged else None)
+    dest = wsB.view(np.int32)[dest_off // 4:dest_off // 4 + B * T * F].reshape(B, T * F)
+    for b in range(B):
+        Tb = frames[b] if ragged else T
+        act = np.zeros((T, F), bool)
+        act[:Tb] = O.dc_active_bins(np.array(feat[b, :Tb]))
+        want = np.where(act.reshape(-1), np.cumsum(act.reshape(-1)) - 1, -1)
+        np.testing.assert_array_equal(dest[b], want)
+    lib.linear_x3p_compact(P(a_img), M, K, P(w_img), P(bias), N, D, 1e-12, base + dest_off, T * F, F, base + comp_off, B,
+                           T * F * D, False, None)
+    comp = wsB[comp_off // 4:comp_off // 4 + B * T * F * D].reshape(B, T * F, D)
+    for b in range(B):
+        n = int((dest[b] >= 0).sum())
+        np.testing.assert_array_equal(comp[b, :n], np.array(emb[b]).reshape(-1, D)[dest[b] >= 0])      # same bits, compacted
+    lib.dc_cluster_compact(B, T, F, D, 12, P(mB), base, nbB, None)
+    assert wsB.view(np.uint32)[lib.dll.onssen_dc_cluster_status_offset(B, D) // 4] == 0
+    np.testing.assert_array_equal(np.array(mB), np.array(mA))
+    assert np.array(mB)[..., 0].sum() > 0 and np.array(mB)[..., 1].sum() > 0         # both clusters used

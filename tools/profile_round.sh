@@ -17,6 +17,7 @@ done
 cd $GRAFT_REPO_ROOT
 find $root/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $root/kernel_stats.csv
 python tools/pmc_summary.py $root > $root/pmc_summary.txt 2>&1
+python tools/traffic_from_pmc.py $root $tag > $root/traffic_latest.json 2>&1      # -> $root/traffic.json (copy to profiles/traffic.json)
 # drop the bulky raw traces, keep the summaries
 find $root -name "*kernel_trace.csv" -delete; find $root -name "*counter_collection.csv" -size +8M -delete
 head -12 $root/kernel_stats.csv; head -60 $root/pmc_summary.txt
