@@ -289,6 +289,18 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
 int onssen_lstm_train_forward_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
                                   int ug, const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,
                                   float* gates, float* cs, void* ws, size_t ws_bytes, void* stream);
+/* The same training forward in a chosen FORM of onssen_blstm_forward_f32 (round 4: the training path no longer leaves the
+ * library when the persistent launch cannot be used -- the re-run of a step whose persistent launch aborted, H > 640):
+ *   flags = ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3   the persistent launch (= onssen_lstm_train_forward_f32; wih = x3 image,
+ *                                                    whh = onssen_lstm_pack_whh_bf16x3 images)
+ *   flags = ONSSEN_BLSTM_BF16X3                      one launch per time step, split-bf16 (wih = onssen_linear_pack_bf16x3
+ *                                                    planes, whh as above; H <= 640)
+ *   flags = 0                                        one launch per time step, exact fp32 (wih / whh = onssen_lstm_pack_f32
+ *                                                    arrays; any H)
+ * gates / cs as above; pair it with onssen_lstm_train_backward_f32 (either form: both read the same saved state). */
+int onssen_lstm_train_forward_form_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
+                                       int ug, const void* wih, const void* whh, const float* bias_p, float* y, float* gates,
+                                       float* cs, void* ws, size_t ws_bytes, int flags, void* stream);
 int64_t onssen_lstm_whhT_elems(int H, int ug);
 int onssen_lstm_pack_whhT_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream);
 int64_t onssen_lstm_whhR_elems(int H, int ug);
@@ -475,7 +487,8 @@ int onssen_batch_sdr_ragged_f32(const float* est, const float* org, const float*
  * byte offsets of `comp` ([B][T*F][D] floats, rows past an utterance's active count unused) and `dest` ([B][T*F] int32).
  * frames: NULL, or per-utterance frame counts of a ragged batch (see the ragged entry points).
  * onssen_linear_x3p_compact: a_img / w_img / bias / N / group / eps as onssen_linear_x3p (N = F * group); row m of the GEMM is
- * (utterance m % R, frame m / R); dest_bs = ints per utterance in dest, comp_bs = floats per utterance in comp. */
+ * (utterance m % R, frame m / R); dest_bs = ints per utterance in dest, comp_bs = floats per utterance in comp; dest must be
+ * readable for 12 bytes past its last entry (the map is fetched in 16-byte words; the workspace layout above pads it). */
 size_t onssen_dc_compact_workspace_bytes(int B, int T, int F, int D);
 int onssen_dc_compact_layout(int B, int T, int F, int D, size_t* comp_offset, size_t* dest_offset);
 int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frames, int F, int D, float db_threshold, void* ws,

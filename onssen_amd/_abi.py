@@ -52,6 +52,7 @@ SIGNATURES = {
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_x3_image_both_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_lstm_train_forward_form_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
     "onssen_lstm_pack_whhT_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_whhR_elems": (_i64, [_i, _i]),
@@ -253,6 +254,10 @@ class Lib:
     def lstm_train_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates, cs, ws, ws_bytes, stream):
         self.check(self.dll.onssen_lstm_train_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates,
                                                           cs, ws, ws_bytes, stream), "onssen_lstm_train_forward_f32")
+
+    def lstm_train_forward_form(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih, whh, bias, y, gates, cs, ws, ws_bytes, flags, stream):
+        self.check(self.dll.onssen_lstm_train_forward_form_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih, whh, bias, y, gates,
+                                                               cs, ws, ws_bytes, flags, stream), "onssen_lstm_train_forward_form_f32")
 
     def lstm_whhT_elems(self, H, ug):
         return int(self.dll.onssen_lstm_whhT_elems(H, ug))

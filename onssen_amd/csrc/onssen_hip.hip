@@ -910,6 +910,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     sp.G = G; sp.whh = x3 ? nullptr : whh_p_host[l]; sp.whh_x3 = x3 ? (const unsigned short*)whh_p_host[l] : nullptr;
     sp.hs = hsb; sp.KQ2 = KQ2; sp.Hs = Hs; sp.dbg = dbg; sp.y = yout; sp.c = cst; sp.B = B; sp.T = T; sp.Hp = Hp; sp.NP = NP;
     sp.KQ = KQ; sp.NU = Hp / ug; sp.step = 0; sp.ablate = (flags >> 8) & 63; sp.frames = frames;
+    sp.save_g = save_g; sp.save_c = save_c;
 #define ONSSEN_STEPS(MT_, NT_) rc = launch_steps<MT_, NT_>(sp, (char*)ws, T, x3, st)
     if (mt == 1) {
       switch (ug) {
@@ -968,6 +969,19 @@ static bool lstm_bwd_geometry(int H, int ug, int* Hp, int* NP, int* KQB, int* NU
   *KQB = ceil_div(*NP, 32);
   *NUB = ceil_div(*Hp, 16);
   return true;
+}
+
+int onssen_lstm_train_forward_form_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
+                                       const void* wih, const void* whh, const float* bias_p, float* y, float* gates,
+                                       float* cs, void* ws, size_t ws_bytes, int flags, void* stream) {
+  if (!y || !gates || !cs || !aligned16(gates)) return ONSSEN_E_ARG;
+  // the forms that can save state: the persistent split-bf16 launch, and the launch-per-step recurrence in either precision
+  const int form = flags & (ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3);
+  if ((flags & ~(ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3)) != 0 || form == ONSSEN_BLSTM_XCD) return ONSSEN_E_ARG;
+  const float* wih_a[1] = {(const float*)wih};
+  const float* whh_a[1] = {(const float*)whh};
+  const float* bias[1] = {bias_p};
+  return blstm_forward_impl(x, xs_b, xs_t, B, T, in_dim, H, 1, ug, wih_a, whh_a, bias, y, ws, ws_bytes, flags, stream, gates, cs);
 }
 
 int64_t onssen_lstm_whhT_elems(int H, int ug) {
@@ -1269,7 +1283,7 @@ static int dc_cluster_impl(const float* emb, const float* feature, int B, int T,
 // ---- compacted form (round 4): index -> (the fc_dc GEMM scatters the active rows) -> cluster ---------------------------------
 size_t onssen_dc_compact_workspace_bytes(int B, int T, int F, int D) {
   const size_t base = onssen_dc_cluster_workspace_bytes(B, T, F, D);
-  return base ? align256(base) + align256((size_t)B * T * F * sizeof(int32_t)) : 0;
+  return base ? align256(base) + align256((size_t)B * T * F * sizeof(int32_t) + 16) : 0;   // (+16: onssen_linear_x3p_compact reads the map in 16-byte words)
 }
 
 int onssen_dc_compact_layout(int B, int T, int F, int D, size_t* comp_offset, size_t* dest_offset) {

@@ -254,11 +254,14 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
     Returns the local mean loss (float).
 
     An aborted persistent recurrence launch (forward or backward; ``nn/_core._XcdPolicy``) never reaches the weights: the
-    status words are examined BEFORE the optimizer step; with ``world > 1`` the ranks agree on "somebody aborted" through a
-    one-element MAX all-reduce (an aborted rank's garbage is already inside everybody's averaged gradients), and then EVERY
-    rank runs forward / backward / exchange again -- the rank that aborted on the ATen LSTM -- so the collectives stay
-    matched.  BatchNorm's running statistics are put back before the re-run; the persistent form stays enabled for the
-    next step.  Non-finite activations still raise."""
+    status words are examined BEFORE the optimizer step; with ``world > 1`` the ranks agree on the outcome through a
+    one-element MAX all-reduce of a status code (0 = fine, 1 = somebody's persistent launch aborted, 2 = somebody hit a
+    fatal error: non-finite activations, a second abort) -- an aborted rank's garbage is already inside everybody's averaged
+    gradients --, and then EVERY rank either runs forward / backward / exchange again (the rank that aborted on the
+    launch-per-step HIP recurrences: the training path never leaves the library, round 4) or raises: no rank is left
+    waiting inside a collective for a peer that has raised.  BatchNorm's running statistics are put back before the
+    re-run; the persistent form stays enabled for the next step."""
+    from . import _abi
     from .nn._core import XcdAborted, _XcdPolicy, _XcdStatus
     reducer = _reducer_for(model, world, group) if world > 1 else None
     if reducer is None and getattr(model, "_onssen_reducer", None) is not None:     # left over from a world > 1 step
@@ -266,31 +269,45 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
         object.__setattr__(model, "_onssen_reducer", None)
     on_gpu = input[0].is_cuda
     bufs = [b.detach().clone() for b in model.buffers()] if on_gpu and model.training else None
-    loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
-    aborted = None
-    if on_gpu:
+
+    def agree(err, fatal_if_aborted=False):
+        """(status over all ranks, this rank's exception): 0 fine, 1 re-run, 2 fatal."""
+        code = 0 if err is None else 1 if isinstance(err, XcdAborted) and not fatal_if_aborted else 2
+        if world > 1 and on_gpu:
+            flag = torch.tensor([float(code)], device=input[0].device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            code = int(flag.item())
+        return code
+
+    def examine():
+        if not on_gpu:
+            return None
         try:
             _XcdStatus.flush()        # aborted exchange / non-finite activations: examined here, not after the update
-        except XcdAborted as e:
-            aborted = e
-    any_aborted = aborted is not None
-    if world > 1 and on_gpu:
-        flag = torch.tensor([1.0 if any_aborted else 0.0], device=input[0].device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        any_aborted = bool(flag.item() > 0)
-    if any_aborted:
+        except _abi.OnssenError as e:
+            return e
+        return None
+
+    loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+    err = examine()
+    code = agree(err)
+    if code == 2:
+        raise err if err is not None else _abi.OnssenError("onssen_amd.train_step: another rank reported a fatal error in this step")
+    if code == 1:
         import contextlib
         import warnings
         _XcdPolicy.recovered += 1
-        warnings.warn(f"onssen_amd.train_step: {aborted or 'a persistent recurrence aborted on another rank'}  "
-                      "Re-running forward / backward of this step" + (" on the ATen LSTM." if aborted else "."), RuntimeWarning)
+        warnings.warn(f"onssen_amd.train_step: {err or 'a persistent recurrence aborted on another rank'}  "
+                      "Re-running forward / backward of this step" + (" on the launch-per-step recurrences." if err else "."), RuntimeWarning)
         if bufs is not None:
             with torch.no_grad():
                 for b, old in zip(model.buffers(), bufs):
                     b.copy_(old)
-        with (_XcdPolicy.forced_steps() if aborted is not None else contextlib.nullcontext()):
+        with (_XcdPolicy.forced_steps() if err is not None else contextlib.nullcontext()):
             loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
-        _XcdStatus.flush()            # a second abort (only possible on a rank that did not abort the first time) raises
+        err = examine()               # a second abort (only possible on a rank that did not abort the first time) is fatal,
+        if agree(err, fatal_if_aborted=True) == 2:     # ... and every rank learns of it before anybody raises
+            raise err if err is not None else _abi.OnssenError("onssen_amd.train_step: another rank failed in the re-run of this step")
     torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
     return float(loss_avg.item())

@@ -295,19 +295,21 @@ class BLSTMParams(nn.Module):
         return out
 
     def autograd_forward(self, x, training):
-        """Training path (needs autograd).  On a ROCm device with H <= 640: the HIP forward with saved state and the
-        HIP backward recurrence (nn/_train.py); ONSSEN_TRAIN_HIP=0, a CPU tensor or a wider layer
-        take the stock ATen LSTM op instead."""
-        hip = x.is_cuda and self.hidden_size <= 640 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"
-        allowed = hip and _XcdPolicy.persistent_allowed()
-        if hip:
-            _XcdPolicy.note_launch(allowed)
-        if allowed:
+        """Training path (needs autograd).  On a ROCm device: ALWAYS the HIP kernels (nn/_train.py) -- the
+        persistent forward with saved state + the persistent backward recurrence where they apply (H <= 640, no abort
+        back-off in force), otherwise the launch-per-step forward with saved state (split-bf16 up to H = 640, exact fp32
+        above) + the launch-per-step backward: the re-run of a training step whose persistent launch aborted and wide layers
+        stay inside the library (round 4; rounds 1-3 fell back to the stock ATen / MIOpen LSTM there).  A CPU tensor takes
+        ATen's LSTM (gloo tests, CPU-only debugging): there is no HIP device to run on."""
+        if x.is_cuda:
             from ._train import BLSTMTrainFunction
+            persistent = (self.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed())
+            if self.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
+                _XcdPolicy.note_launch(persistent)
             if getattr(self, "_train_packed", None) is None:
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))
             p_drop = float(self.dropout) if training and self.num_layers > 1 else 0.0
-            return BLSTMTrainFunction.apply(x, self._train_packed, p_drop, *self.flat_weights())
+            return BLSTMTrainFunction.apply(x, self._train_packed, p_drop, persistent, *self.flat_weights())
         B = x.shape[0]
         z = x.new_zeros(2 * self.num_layers, B, self.hidden_size)
         out, _, _ = torch._VF.lstm(x, (z, z), self.flat_weights(), True, self.num_layers,

@@ -172,14 +172,18 @@ class BLSTMTrainFunction(torch.autograd.Function):
     them.  All tensors are fp32 (autocast / bf16 inputs are cast on entry, never reinterpreted)."""
 
     @staticmethod
-    def forward(ctx, x, packed, p_drop, *flat):
+    def forward(ctx, x, packed, p_drop, persistent, *flat):
+        """``persistent``: the XCD-local persistent kernels (H <= 640); otherwise the launch-per-step forms of the same
+        recurrences -- split-bf16 up to H = 640, exact-fp32 forward above -- with the same saved state and gradient GEMMs."""
         lib = get_lib()
         prm = packed.p
         H, L = prm.hidden_size, prm.num_layers
         B, T, In = x.shape
-        ug = 4 * -(-H // 128)
-        if H > 640:
-            raise RuntimeError("HIP training path: H <= 640 (XCD-local recurrence)")
+        if persistent and H > 640:
+            raise RuntimeError("HIP training path: the persistent recurrences hold H <= 640")
+        ug = 4 * -(-H // 128) if persistent else int(os.environ.get("ONSSEN_UG", "8"))
+        x3 = H <= 640
+        fwd_flags = (_abi.BLSTM_XCD | _abi.BLSTM_BF16X3) if persistent else _abi.BLSTM_BF16X3 if x3 else 0
         _XcdStatus.poll()
         pk = packed.get(ug)
         Hp, NP = pk.Hp, pk.NP
@@ -193,14 +197,17 @@ class BLSTMTrainFunction(torch.autograd.Function):
         xp = x.transpose(0, 1).reshape(T * B, In)                        # time-major rows for the weight gradients
         for l in range(L):
             nbytes = lib.blstm_workspace_bytes(B, T, in_l, H, 1, ug)
-            ws = _Workspace.get(("fwd", B, T, in_l, H), nbytes, dev, zero=True)
+            ws = _Workspace.get(("fwd", B, T, in_l, H, ug), nbytes, dev, zero=True)
             y = torch.empty(T, B, 2, Hp, device=dev, dtype=torch.float32)
             gates = torch.empty(T, B, 2, NP, device=dev, dtype=torch.float32)
             cs = torch.empty(T, B, 2, Hp, device=dev, dtype=torch.float32)
-            lib.lstm_train_forward(xin.data_ptr(), xs_b, xs_t, B, T, in_l, H, ug, pk.wih_img[l].data_ptr(),
-                                   pk.whh_x3[l].data_ptr(), pk.bias[l].data_ptr(), y.data_ptr(), gates.data_ptr(),
-                                   cs.data_ptr(), ws.data_ptr(), ws.numel(), st)
-            _XcdStatus.post(ws)           # an aborted exchange is reported at the next poll (never silently)
+            wih = pk.wih_img[l] if persistent else pk.wih_x3[l] if x3 else pk.wih[l]
+            whh = pk.whh_x3[l] if x3 else pk.whh[l]
+            lib.lstm_train_forward_form(xin.data_ptr(), xs_b, xs_t, B, T, in_l, H, ug, wih.data_ptr(), whh.data_ptr(),
+                                        pk.bias[l].data_ptr(), y.data_ptr(), gates.data_ptr(), cs.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), fwd_flags, st)
+            if persistent:
+                _XcdStatus.post(ws)       # an aborted exchange is reported at the next poll (never silently)
             mask = None
             if l < L - 1:
                 nxt = y.view(T, B, 2 * Hp)
@@ -216,7 +223,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
             else:
                 saved.append((xp, y, gates, cs, None))
         ctx.saved_layers = saved
-        ctx.packed, ctx.ug, ctx.dims, ctx.p_drop = packed, ug, (B, T, In, H, L, Hp, NP), p_drop
+        ctx.packed, ctx.ug, ctx.dims, ctx.p_drop, ctx.persistent = packed, ug, (B, T, In, H, L, Hp, NP), p_drop, bool(persistent)
         ctx.flat = flat
         return y[..., :H].reshape(T, B, 2 * H).transpose(0, 1).contiguous()
 
@@ -236,9 +243,9 @@ class BLSTMTrainFunction(torch.autograd.Function):
         # (B,T,2H) -> time-major (T,B,2,Hp), padded units zero
         dy = dy_bt.transpose(0, 1).reshape(T, B, 2, H)
         dy = Fn.pad(dy, (0, Hp - H)).contiguous() if Hp != H else dy.contiguous()
-        # ONSSEN_BWD_XCD=0: one launch per time step instead of the XCD-local persistent launch
-        form = _abi.LSTM_BWD_XCD if os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
-        wsb = _Workspace.get(("bwd", B, H, form), lib.lstm_train_backward_workspace_bytes(B, H, ug, form), dev, zero=True)
+        # the persistent backward launch where the forward was persistent (ONSSEN_BWD_XCD=0: one launch per time step anyway)
+        form = _abi.LSTM_BWD_XCD if ctx.persistent and os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
+        wsb = _Workspace.get(("bwd", B, H, form, ug), lib.lstm_train_backward_workspace_bytes(B, H, ug, form), dev, zero=True)
         whh_img = pk.whh_bwd(form)
         grads = [None] * (8 * L)
         dx_rows = None
@@ -279,7 +286,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
         if LAYER_GRAD_REDUCER[0] is not None:
             LAYER_GRAD_REDUCER[0].layer_collect()     # averaged in place before autograd accumulates them
         ctx.saved_layers = None
-        return (dx, None, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------- nn.Linear on the same GEMM (training)

@@ -727,13 +727,17 @@ def test_loss_mask_gradient(lib, psa):
 _TRAIN_CASES = [(H, ug, B, T, _abi.LSTM_BWD_XCD, "0") for H, ug, B, T in
                 [(8, 4, 3, 5), (24, 8, 18, 3), (40, 20, 5, 4), (16, 8, 35, 2), (30, 4, 3, 17), (8, 4, 1, 1), (8, 4, 70, 2)]] + \
                [(24, 8, 18, 3, _abi.LSTM_BWD_XCD, "1"), (8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0")]
+_TRAIN_CASES = [c + ("xcd",) for c in _TRAIN_CASES] + \
+               [(8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0", "steps_x3"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0", "steps_f32"),
+                (12, 8, 20, 4, _abi.LSTM_BWD_STEPS, "0", "steps_x3")]
 
 
-@pytest.mark.parametrize("H,ug,B,T,form,scramble", _TRAIN_CASES)
-def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T, form, scramble):
+@pytest.mark.parametrize("H,ug,B,T,form,scramble,fwd", _TRAIN_CASES)
+def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, T, form, scramble, fwd):
     """Row N1: training forward (saved gates / cell states) + backward recurrence of one bidirectional layer against
     nn.LSTM autograd on the CPU (the reference's `loss.backward()`, onssen/utils/train.py:80-84).  Split-bf16 products:
-    gradients within 2e-4 of their largest entry."""
+    gradients within 2e-4 of their largest entry.  ``fwd``: the persistent forward, or (round 4: what an aborted training step
+    is re-run on, and H > 640) the launch-per-step forward with saved state in split-bf16 / exact fp32."""
     import torch
     from onssen_amd.nn._train import layer_gradients
     monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
@@ -750,22 +754,31 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
     nT = (lib.lstm_whhR_elems if xcd else lib.lstm_whhT_elems)(H, ug)
     wT = _shm((2, nT), dtype=np.uint16)
-    scratch = _shm((we,))
+    bw = _shm((2, we))
     for d, sfx in enumerate(("", "_reverse")):
         srcs = []
         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
             v = sd[f"rnn.{n}_l0{sfx}"]
             sv = _shm(v.shape); sv[...] = v
             srcs.append(sv)
-        lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), F, 0, H, ug, P(a[d]), P(scratch), P(c[d]), None)
+        lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), F, 0, H, ug, P(a[d]), P(bw[d]), P(c[d]), None)
         lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
         (lib.lstm_pack_whhR_bf16x3 if xcd else lib.lstm_pack_whhT_bf16x3)(P(srcs[1]), H, ug, P(wT[d]), None)
     pl = _shm((2 * NP, (F + 31) // 32, 2, 32), dtype=np.uint16)
     lib.x3_image(P(a), Kp, 0, 1, 2 * NP, F, P(pl), None)
     ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, 1, ug) // 4 + 64,))
     y, gates, cs = _shm((T, B, 2, Hp), fill=np.nan), _shm((T, B, 2, NP), fill=np.nan), _shm((T, B, 2, Hp), fill=np.nan)
-    lib.lstm_train_forward(P(x), T * F, F, B, T, F, H, ug, P(pl), P(b3), P(c), P(y), P(gates), P(cs), P(ws), ws.nbytes, None)
-    assert ws.view(np.uint32)[280] == 0
+    if fwd == "xcd":
+        lib.lstm_train_forward(P(x), T * F, F, B, T, F, H, ug, P(pl), P(b3), P(c), P(y), P(gates), P(cs), P(ws), ws.nbytes, None)
+        assert ws.view(np.uint32)[280] == 0
+    elif fwd == "steps_x3":
+        ld = (F + 31) // 32 * 32
+        planes = _shm((2, 2 * NP, ld), dtype=np.uint16)
+        lib.linear_pack_bf16x3(P(a), 2 * NP, F, Kp, ld, P(planes), None)
+        lib.lstm_train_forward_form(P(x), T * F, F, B, T, F, H, ug, P(planes), P(b3), P(c), P(y), P(gates), P(cs), P(ws), ws.nbytes,
+                                    _abi.BLSTM_BF16X3, None)
+    else:
+        lib.lstm_train_forward_form(P(x), T * F, F, B, T, F, H, ug, P(a), P(bw), P(c), P(y), P(gates), P(cs), P(ws), ws.nbytes, 0, None)
 
     # the reference: nn.LSTM on the CPU, a random linear functional of its output as the loss
     lstm = torch.nn.LSTM(F, H, 1, batch_first=True, bidirectional=True)

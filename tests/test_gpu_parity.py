@@ -947,6 +947,51 @@ def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T,F,H,L,forced", [(3, 12, 40, 768, 2, False),      # H > 640: exact-fp32 launch-per-step forward + launch-per-step backward
+                                              (5, 20, 129, 600, 2, True),      # H <= 640 inside forced_steps(): what an aborted step is re-run on
+                                              (18, 9, 33, 128, 1, True)])
+def test_training_without_the_persistent_kernels_stays_on_hip(dev, monkeypatch, B, T, F, H, L, forced):
+    """Round 4: wide layers and the re-run of an aborted step train on the launch-per-step HIP recurrences
+    (forward with saved state: onssen_lstm_train_forward_form_f32; backward: ONSSEN_LSTM_BWD_STEPS) -- never on the stock ATen /
+    MIOpen LSTM, which is replaced by a function that raises here.  Gradients against nn.LSTM autograd in float64 on the CPU."""
+    import contextlib
+    from onssen_amd.nn._core import BLSTMParams, _XcdPolicy
+
+    def no_aten_lstm(*a, **k):
+        raise AssertionError("the GPU training path called torch._VF.lstm")
+    torch.manual_seed(H + L)
+    ref = torch.nn.LSTM(F, H, L, batch_first=True, bidirectional=True).double()
+    rnn = BLSTMParams(F, H, L, dropout=0.0)
+    rnn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    rnn = rnn.to(dev)
+    x = torch.randn(B, T, F, dtype=torch.float64)
+    R = torch.randn(B, T, 2 * H, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    yr, _ = ref(xr)
+    (yr * R).sum().backward()
+    monkeypatch.setattr(torch._VF, "lstm", no_aten_lstm, raising=False)
+    n_p = _XcdPolicy.persistent_launches
+    xg = x.float().to(dev).requires_grad_(True)
+    with (_XcdPolicy.forced_steps() if forced else contextlib.nullcontext()):
+        yg = rnn.autograd_forward(xg, True)
+        (yg * R.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert _XcdPolicy.persistent_launches == n_p
+    assert (yg.detach().cpu().double() - yr.detach()).abs().max() < 2e-5
+    bad = []
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        rl2 = ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+        if not rl2 <= 1e-4:
+            bad.append(f"{what}: rel-L2 {rl2:.2e}")
+    close(xg.grad, xr.grad, "dx")
+    for name, p in rnn.named_parameters():
+        close(p.grad, getattr(ref, name).grad, name)
+    assert not bad, "; ".join(bad)
+
+
+@pytest.mark.gpu
 def test_cfg4_full_shape_gradients_match_fp64_autograd(dev, monkeypatch):
     """BASELINE cfg4's training shape as shipped -- 16 chunks x 400 frames, 3 x BLSTM-600, dropout off -- through the
     default HIP training path (persistent forward with saved state, persistent backward recurrence, split-bf16 gradient
@@ -1070,14 +1115,17 @@ def test_dc_training_step_hip_vs_aten(dev, monkeypatch):
     lab = torch.nn.functional.one_hot(torch.randint(0, 2, (B, T, Fq), device=dev), 2).float()
     wt = torch.rand(B, T, Fq, device=dev)
     results = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("ONSSEN_TRAIN_HIP", mode)
-        torch.manual_seed(2)
-        m = onn.deep_clustering(Fq, 600, 2, 20, dropout=0.0).to(dev).train()
-        out = m([x])
-        loss = torch.mean(loss_dc(out, [lab, wt]))      # as trainer.train does (onssen/utils/train.py:78)
-        loss.backward()
-        results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    import contextlib
+    from tools.aten_lstm_reference import aten_lstm_reference
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
+    for mode in ("1", "0"):      # "0": the stock ATen / MIOpen LSTM + ATen heads, patched in by the test (the product has no such path)
+        with (aten_lstm_reference() if mode == "0" else contextlib.nullcontext()):
+            torch.manual_seed(2)
+            m = onn.deep_clustering(Fq, 600, 2, 20, dropout=0.0).to(dev).train()
+            out = m([x])
+            loss = torch.mean(loss_dc(out, [lab, wt]))      # as trainer.train does (onssen/utils/train.py:78)
+            loss.backward()
+            results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
     assert abs(results["1"][0] - results["0"][0]) <= 1e-4 * abs(results["0"][0])
     for k, g0 in results["0"][1].items():
         g1 = results["1"][1][k]
@@ -1109,13 +1157,16 @@ def test_chimera_training_step_hip_vs_aten(dev, monkeypatch):
     lab = [torch.nn.functional.one_hot(torch.randint(0, 2, (B, T, Fq), device=dev), 2).float(),
            torch.rand(B, T, Fq, device=dev) + 0.1, torch.rand(B, T, Fq, device=dev), torch.rand(B, T, Fq, device=dev)]
     results = {}
+    import contextlib
+    from tools.aten_lstm_reference import aten_lstm_reference
+    monkeypatch.setenv("ONSSEN_TRAIN_HIP", "1")
     for mode in ("1", "0"):
-        monkeypatch.setenv("ONSSEN_TRAIN_HIP", mode)
-        torch.manual_seed(6)
-        m = onn.chimera(Fq, 600, 4, 20, dropout=0.0).to(dev).train()
-        loss = torch.mean(loss_chimera_msa(m([x]), lab))
-        loss.backward()
-        results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+        with (aten_lstm_reference() if mode == "0" else contextlib.nullcontext()):
+            torch.manual_seed(6)
+            m = onn.chimera(Fq, 600, 4, 20, dropout=0.0).to(dev).train()
+            loss = torch.mean(loss_chimera_msa(m([x]), lab))
+            loss.backward()
+            results[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
     assert abs(results["1"][0] - results["0"][0]) <= 1e-4 * abs(results["0"][0])
     for k, g0 in results["0"][1].items():
         g1 = results["1"][1][k]

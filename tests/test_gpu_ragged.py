@@ -162,3 +162,37 @@ def test_eval_batched_equals_the_one_by_one_loop(dev, monkeypatch, kind):
     inp, lab, (frames, lengths) = t.collate(loader[:3])
     assert inp[0].shape[0] == 3 and inp[0].shape[1] == int(frames.max()) and lab[2].shape[-1] == int(lengths.max())
     assert frames.tolist() == [l[0][0].shape[1] for l in loader[:3]]
+
+
+@pytest.mark.parametrize("B,T,ragged", [(32, 400, False), (5, 77, False), (16, 140, True)])
+def test_dc_masks_without_the_embedding_round_trip(dev, monkeypatch, B, T, ragged):
+    """Round 4: ``dc_masks_from_features`` (threshold -> target map, fc_dc GEMM storing only the active bins' rows into the
+    compacted array, clustering on it) gives the masks of ``dc_masks(model([logmag])[0], logmag)`` bit for bit -- at the
+    headline shape, a small one, and a ragged batch -- and separate_dc (which takes that route) equals the explicit pipeline."""
+    from onssen_amd.features import mask_istft, stft_logmag
+    from onssen_amd.separation import dc_masks, dc_masks_from_features, separate_dc
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    m, _ = build("deep_clustering", dev)
+    n = 64 * (T - 1) + 13
+    rng = np.random.default_rng(B)
+    ns = [int(v) for v in rng.integers(64 * 60, n, B)] if ragged else None
+    if ragged:
+        ns[0] = n
+    wav = torch.from_numpy(np.stack([synth_mixture(300 + b % 8, n) for b in range(B)])).to(dev)
+    with torch.no_grad():
+        lengths = torch.tensor(ns, dtype=torch.int32, device=dev) if ragged else None
+        frames = (1 + lengths // 64).to(torch.int32) if ragged else None
+        logmag, ri = stft_logmag(wav, lengths=lengths)
+        got = dc_masks_from_features(m, logmag, frames=frames)
+        assert got is not None
+        emb, = m([logmag]) if not ragged else m([logmag], frames=frames)
+        want = dc_masks(emb, logmag, frames=frames)
+        assert torch.equal(got, want)
+        act = logmag >= (logmag.amax(dim=(1, 2), keepdim=True) - 2.0) if not ragged else None
+        if act is not None:
+            assert torch.equal(got.sum(-1) == 1, act)                    # exactly the bins within 40 dB of the loudest are labelled
+        out = separate_dc(m, wav, lengths=lengths)
+        assert torch.equal(out, mask_istft(ri, want, 64, wav.shape[-1], frames=frames, lengths=lengths))
+        monkeypatch.setenv("ONSSEN_DC_COMPACT", "0")                     # the switch: the explicit pipeline
+        assert dc_masks_from_features(m, logmag, frames=frames) is None
+        assert torch.equal(separate_dc(m, wav, lengths=lengths), out)

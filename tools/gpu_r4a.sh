@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, first GPU pass: parity suite (incl. the ragged tests), smoke, evaluation-loop probe, bench
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; tail -5 gpurun_out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; tail -5 gpurun_out/pytest_gpu.log
 grep -E "^\[(bf16|cfg4)" -A12 gpurun_out/pytest_gpu.log | head -60
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
 timeout 300 python tools/eval_probe.py 2>&1 | grep -v Warning | tail -10 | tee gpurun_out/eval_probe.txt

@@ -47,6 +47,13 @@ def main():
     def step(i):
         inp, lab = batches[i % len(batches)]
         return train_step(model, opt, loss_dc, inp, lab, world=world)
+    import contextlib
+    aten = contextlib.nullcontext()
+    if os.environ.get("ONSSEN_TRAIN_HIP", "1") != "1":      # the comparison rows: stock ATen / MIOpen LSTM patched in by this tool
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from aten_lstm_reference import aten_lstm_reference
+        aten = aten_lstm_reference()
+    aten.__enter__()
     for i in range(args.warmup):
         step(i)
     if world > 1:
