@@ -1246,7 +1246,7 @@ static int dc_cluster_impl(const float* emb, const float* feature, int B, int T,
   if (persistent) {
     // active bins compacted once (the same pass finds the second centroid), then ALL Lloyd iterations in one launch per <= 32
     // utterances (km::NBP workgroups of km::LT threads each, one per CU: 256 workgroups fill the chip exactly)
-    hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, frames, F);
+    hipLaunchKernelGGL((kmeans2_count_kernel<false>), sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, w, stride, iw, frames, F, D);
     if (D == 20) hipLaunchKernelGGL((kmeans2_compact_kernel<20>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp, frames, F);
     else hipLaunchKernelGGL((kmeans2_compact_kernel<0>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, iw, comp, frames, F);
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
@@ -1307,9 +1307,8 @@ int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frame
   onssen_dc_compact_layout(B, T, F, D, nullptr, &dest_off);
   int* dest = (int*)((char*)ws + dest_off);
   const dim3 sgrid(km::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, (const float*)nullptr, feature, per_utt, D, db_threshold, w, stride, frames, F, (const int*)nullptr);
-  hipLaunchKernelGGL((kmeans2_pick_kernel<0>), dim3((unsigned)B), dim3(64), 0, st, (const float*)nullptr, per_utt, D, w, stride, iw);
-  hipLaunchKernelGGL(kmeans2_count_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, frames, F);
+  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, (const float*)nullptr, feature, per_utt, D, db_threshold, w, stride, frames, F, (const int*)nullptr, (const int*)nullptr);
+  hipLaunchKernelGGL((kmeans2_count_kernel<true>), sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, w, stride, iw, frames, F, D);
   hipLaunchKernelGGL(kmeans2_index_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, dest, frames, F);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
@@ -1332,9 +1331,8 @@ int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* 
   const float* comp = (const float*)((char*)ws + comp_off);
   const int* dest = (const int*)((char*)ws + dest_off);
   const dim3 sgrid(km::NBLK, (unsigned)B);
-  hipLaunchKernelGGL(kmeans2_c0_kernel, dim3((unsigned)B), dim3(64), 0, st, comp, dest, per_utt, D, w, stride);
-  hipLaunchKernelGGL((kmeans2_search_kernel<2>), sgrid, dim3(256), 0, st, comp, (const float*)nullptr, per_utt, D, 0.0f, w, stride, (const int*)nullptr, F, (const int*)iw);
-  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, comp, per_utt, D, w, stride, (int*)nullptr);
+  hipLaunchKernelGGL((kmeans2_search_kernel<2>), sgrid, dim3(256), 0, st, comp, (const float*)nullptr, per_utt, D, 0.0f, w, stride, (const int*)nullptr, F, (const int*)iw, dest);
+  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, comp, per_utt, D, w, stride, (int*)nullptr, dest);
   const unsigned spin = xcd_spin_limit();
   static const int lloyd_utts = [] {
     int dev = 0, cus = 0;

@@ -207,8 +207,8 @@ class _XcdStatus:
                     ws[off:off + 4].zero_()
                     saw_abort = True
                     err = err if isinstance(err, XcdAborted) else XcdAborted(
-                        "persistent 2-means launch gave up a bounded wait (its workgroups were not co-resident): the masks of "
-                        "that call are not the converged ones.")
+                        f"persistent 2-means launch gave up a bounded wait (code {int(host[0]) & 0xffffffff:#x}: its workgroups were not "
+                        "co-resident): the masks of that call are not the converged ones.")
                 continue
             if int(host[1]) == 1:
                 cls.safe_protocol_seen = True
