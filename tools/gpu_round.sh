@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end validation on the GPU box: parity suite, smoke, every bench configuration, rocprofv3 passes.
 # Usage: bash tools/gpu_round.sh <tag>   (tag names the profile directory gpurun_out/prof_<tag>, e.g. r02a)
-tag=${1:-r02}
+tag=${1:-r04}
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -2 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -1
@@ -32,6 +32,7 @@ timeout 200 python tools/xcd_soak.py 2>&1 < /dev/null | tail -2 | cut -c1-400 | 
 cd /tmp; timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_train -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --layers 3 --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_train.log 2>&1 < /dev/null; cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f gpurun_out/train_kernel_stats.csv; fi
 find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
+timeout 300 python tools/eval_probe.py 2>&1 | grep -v Warning | grep "batch" | tee gpurun_out/eval_probe.txt
 HEAVY=1 timeout 200 python tools/cotenant_probe.py > gpurun_out/cotenant_probe.txt 2>/dev/null; tail -12 gpurun_out/cotenant_probe.txt
 timeout 100 python tools/cluster_probe.py 2>/dev/null | head -3 | cut -c1-200 | tee gpurun_out/cluster_probe.txt
 bash tools/profile_round.sh $tag > gpurun_out/profile_round.log 2>&1

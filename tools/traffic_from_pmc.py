@@ -29,7 +29,9 @@ if f is not None and w is not None:
     out.update({"kernel": kname + ", ...> (layer >= 1 of the headline step)", "xcd_FETCH_SIZE_KB_per_launch_raw": f,
                 "xcd_WRITE_SIZE_KB_per_launch_raw": w, "dispatches": [nf, nw],
                 "xcd_recurrence_hbm_bytes_per_launch": int((2 * f + w) * 1024)})
-for label, part in (("linear_x3q_l1", "linear_x3q_kernel<0, 3, false, 3"), ("linear_x3q_head", "linear_x3q_kernel<1, 3"),
+for label, part in (("linear_x3q_l1", "linear_x3q_kernel<0, 3, false, 3"), ("linear_x3q_head_full_embedding", "linear_x3q_kernel<1, 3"),
+                    ("linear_x3q_head_active_rows_only", "linear_x3q_kernel<4, 3"), ("kmeans2_search_farthest", "kmeans2_search_kernel<2"),
+                    ("kmeans2_lloyd", "kmeans2_lloyd_kernel"),
                     ("kmeans2_compact", "kmeans2_compact_kernel"), ("kmeans2_assign_masks", "kmeans2_assign_kernel<1"),
                     ("kmeans2_mask_compact", "kmeans2_mask_compact_kernel"), ("kmeans2_index", "kmeans2_index_kernel")):
     f, _ = mean(part, "FETCH_SIZE")
