@@ -1307,9 +1307,9 @@ int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frame
   onssen_dc_compact_layout(B, T, F, D, nullptr, &dest_off);
   int* dest = (int*)((char*)ws + dest_off);
   const dim3 sgrid(km::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, (const float*)nullptr, feature, per_utt, D, db_threshold, w, stride, frames, F, (const int*)nullptr, (const int*)nullptr);
+  hipLaunchKernelGGL((kmeans2_search_kernel<0>), sgrid, dim3(256), 0, st, (const float*)nullptr, feature, per_utt, D, db_threshold, w, stride, frames, F);
   hipLaunchKernelGGL((kmeans2_count_kernel<true>), sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, w, stride, iw, frames, F, D);
-  hipLaunchKernelGGL(kmeans2_index_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, dest, frames, F);
+  hipLaunchKernelGGL(kmeans2_index_kernel, sgrid, dim3(256), 0, st, feature, per_utt, db_threshold, (const float*)w, stride, iw, dest, frames, F, D);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -1331,8 +1331,7 @@ int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* 
   const float* comp = (const float*)((char*)ws + comp_off);
   const int* dest = (const int*)((char*)ws + dest_off);
   const dim3 sgrid(km::NBLK, (unsigned)B);
-  hipLaunchKernelGGL((kmeans2_search_kernel<2>), sgrid, dim3(256), 0, st, comp, (const float*)nullptr, per_utt, D, 0.0f, w, stride, (const int*)nullptr, F, (const int*)iw, dest);
-  hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, comp, per_utt, D, w, stride, (int*)nullptr, dest);
+  // (the farthest-point initialisation rides in the Lloyd launch's first pass: INIT)
   const unsigned spin = xcd_spin_limit();
   static const int lloyd_utts = [] {
     int dev = 0, cus = 0;
@@ -1340,11 +1339,11 @@ int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* 
     const int n = cus / km::NBP;
     return n < 1 ? 1 : n > 32 ? 32 : n;
   }();
-  for (int u0 = 0; u0 < B && iters > 0; u0 += lloyd_utts) {
+  for (int u0 = 0; u0 < B; u0 += lloyd_utts) {     // (also with iters = 0: pass 0 initialises the centroids)
     const int nutt = B - u0 < lloyd_utts ? B - u0 : lloyd_utts;
     const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
-    if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
-    else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+    if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, dest);
+    else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, dest);
   }
   if (D == 20) hipLaunchKernelGGL((kmeans2_mask_compact_kernel<20>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);
   else hipLaunchKernelGGL((kmeans2_mask_compact_kernel<0>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);

@@ -16,11 +16,17 @@ args.model = onn.deep_clustering(**args["model_options"]).to(dev)
 args.checkpoint_path = None
 args.test_loader = list(wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", dev)) * 4
 t = tester_dc(args)
-t.eval(); t.eval()
+K = int(os.environ.get("K", "16"))
+t.eval(batch=K); t.eval(batch=K)
 torch.cuda.synchronize()
+# device time of the same loop: events around it (the host queues ahead)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+import time
+t0 = time.perf_counter(); e0.record(); t.eval(batch=K); e1.record(); torch.cuda.synchronize()
+print(f"eval(batch={K}): wall {1e3 * (time.perf_counter() - t0):.2f} ms, events {e0.elapsed_time(e1):.2f} ms for {len(args.test_loader)} utterances")
 pr = cProfile.Profile()
 pr.enable()
-t.eval()
+t.eval(batch=K)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO()

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in 1; do
 for c in 1 0; do
   ONSSEN_DC_COMPACT=$c timeout 300 python bench.py --no-extra --no-cpu-baseline --steps 60 --warmup 5 > gpurun_out/ab_$c.json 2>/dev/null
   python - <<PY
