@@ -428,7 +428,8 @@ def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
     nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D)
     ws = _shm((nb // 4 + 64,))
     masks = _shm((B, T, F, 2), fill=np.nan)
-    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 12, P(masks), P(ws), nb, None)
+    iters = 12 if B <= 8 else 3        # (the 9-utterance case forks 128 workgroups of 512 threads: a few passes are enough to cross the second block of utterances)
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, iters, P(masks), P(ws), nb, None)
     so = lib.dll.onssen_dc_cluster_status_offset(B, D)
     assert ws.view(np.uint32)[so // 4] == 0
     # the compacted copy: active rows of every utterance in bin order
@@ -443,7 +444,7 @@ def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
     monkeypatch.setenv("ONSSEN_EMU_FORK", "0")
     ws2 = aligned_f32(nb // 4 + 4)
     ref = np.full((B, T, F, 2), np.nan, np.float32)
-    lib.dc_cluster(P(emb0), P(feat0), B, T, F, D, 40.0, 12, P(ref), P(ws2), nb, None, flags=_abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
+    lib.dc_cluster(P(emb0), P(feat0), B, T, F, D, 40.0, iters, P(ref), P(ws2), nb, None, flags=_abi.DC_CLUSTER_LAUNCH_PER_ITERATION)
     for b in range(B):
         act = O.dc_active_bins(feat0[b])
         assert np.all(masks[b][~act] == 0) and np.all(masks[b][act].sum(-1) == 1)

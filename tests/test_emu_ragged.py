@@ -85,8 +85,8 @@ def test_dc_cluster_ragged(lib, monkeypatch, persistent):
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
     lib.dll.onssen_xcd_spin_limit(40000000)
     rng = np.random.default_rng(21)
-    B, T, F, D = 3, 14, 33, 20
-    frames = [14, 9, 11]
+    B, T, F, D = 2, 14, 33, 20
+    frames = [14, 9]
     emb0, feat0, _ = _two_cluster_embeddings(rng, B, T, F, D)
     emb, feat = _shm(emb0.shape), _shm(feat0.shape)
     emb[...] = emb0; feat[...] = feat0
@@ -98,7 +98,7 @@ def test_dc_cluster_ragged(lib, monkeypatch, persistent):
     ws = _shm((nb // 4 + 64,))
     masks = _shm((B, T, F, 2), fill=np.nan)
     flags = 0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION
-    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 12, P(masks), P(ws), nb, None, flags=flags, frames=P(fr))
+    lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, 6, P(masks), P(ws), nb, None, flags=flags, frames=P(fr))
     assert ws.view(np.uint32)[lib.dll.onssen_dc_cluster_status_offset(B, D) // 4] == 0
     for b in range(B):
         Tb = frames[b]
@@ -107,7 +107,7 @@ def test_dc_cluster_ragged(lib, monkeypatch, persistent):
         nb1 = lib.dll.onssen_dc_cluster_workspace_bytes(1, Tb, F, D)
         ws1 = _shm((nb1 // 4 + 64,))
         m1 = _shm((1, Tb, F, 2), fill=np.nan)
-        lib.dc_cluster(P(e1), P(f1), 1, Tb, F, D, 40.0, 12, P(m1), P(ws1), nb1, None, flags=flags)
+        lib.dc_cluster(P(e1), P(f1), 1, Tb, F, D, 40.0, 6, P(m1), P(ws1), nb1, None, flags=flags)
         np.testing.assert_array_equal(np.array(masks[b, :Tb]), np.array(m1[0]))
         assert np.all(np.array(masks[b, Tb:]) == 0)
         act = O.dc_active_bins(feat0[b, :Tb])
