@@ -12,14 +12,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _lengths_i32(lengths, B, hi, device, what):
-    """Per-row extents of a ragged batch as an int32 device tensor (validated on the host when they come from it)."""
+def _lengths_i32(lengths, B, hi, device, what, lo=1):
+    """Per-row extents of a ragged batch as an int32 device tensor.  Values that come from the host are validated there; a
+    device tensor is taken as it is (checking it would cost a synchronisation per call): its values must lie in [lo, hi]."""
     if torch.is_tensor(lengths) and lengths.is_cuda:
         out = lengths.to(device=device, dtype=torch.int32).contiguous()
     else:
         host = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1)
-        if host.numel() != B or int(host.min()) < 1 or int(host.max()) > hi:
-            raise ValueError(f"{what}: expected {B} values in [1, {hi}], got {host.tolist()}")
+        if host.numel() != B or int(host.min()) < lo or int(host.max()) > hi:
+            raise ValueError(f"{what}: expected {B} values in [{lo}, {hi}], got {host.tolist()}")
         out = host.to(device=device, dtype=torch.int32)
     if out.numel() != B:
         raise ValueError(f"{what}: expected {B} values, got {out.numel()}")
@@ -48,10 +49,8 @@ def stft_logmag(wav, window_size=256, hop_size=64, epsilon=1e-7, return_stft=Tru
     T, F = 1 + n // hop_size, window_size // 2 + 1
     logmag = torch.empty(B, T, F, device=wav.device, dtype=torch.float32)
     ri = torch.empty(B, T, F, 2, device=wav.device, dtype=torch.float32) if return_stft else None
-    if lengths is not None:
-        lengths = _lengths_i32(lengths, B, n, wav.device, "lengths")
-        if not torch.cuda.is_current_stream_capturing() and int(lengths.min()) <= window_size // 2:
-            raise ValueError("stft_logmag: every utterance must be longer than window_size / 2 samples (reflect padding)")
+    if lengths is not None:      # (every utterance must be longer than window_size / 2 samples: reflect padding)
+        lengths = _lengths_i32(lengths, B, n, wav.device, "lengths", lo=window_size // 2 + 1)
     get_lib().stft_logmag(wav.data_ptr(), B, n, wav.stride(0), window_size, hop_size, float(epsilon),
                           logmag.data_ptr(), ri.data_ptr() if ri is not None else None, _stream(),
                           n_per_utt=lengths.data_ptr() if lengths is not None else None)

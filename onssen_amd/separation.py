@@ -15,7 +15,7 @@ def _ragged(wav, lengths, hop_size):
     if lengths is None:
         return None, None
     from .features import _lengths_i32
-    lengths = _lengths_i32(lengths, wav.shape[0], wav.shape[-1], wav.device, "lengths")
+    lengths = _lengths_i32(lengths, wav.shape[0], wav.shape[-1], wav.device, "lengths", lo=hop_size)
     return lengths, (1 + lengths // hop_size).to(torch.int32)
 
 

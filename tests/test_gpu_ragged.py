@@ -196,3 +196,21 @@ def test_dc_masks_without_the_embedding_round_trip(dev, monkeypatch, B, T, ragge
         monkeypatch.setenv("ONSSEN_DC_COMPACT", "0")                     # the switch: the explicit pipeline
         assert dc_masks_from_features(m, logmag, frames=frames) is None
         assert torch.equal(separate_dc(m, wav, lengths=lengths), out)
+
+
+def test_separate_chimera_ragged(dev, monkeypatch):
+    """chimera++: masks straight from the network, K utterances of different lengths per call -- every row equals its own
+    batch-1 call bit for bit, zeros after its own length."""
+    from onssen_amd.separation import separate_chimera
+    monkeypatch.setenv("ONSSEN_CHECK", "1")
+    m, _ = build("chimera", dev, H=300, L=2)
+    ns = [64 * 100 + 9, 64 * 37, 64 * 99 + 63, 64 * 100 + 9, 64 * 64]
+    wav = torch.full((len(ns), max(ns)), float("nan"))
+    for b, nb in enumerate(ns):
+        wav[b, :nb] = torch.from_numpy(synth_mixture(170 + b, nb))
+    wav = wav.to(dev)
+    out = separate_chimera(m, wav, lengths=ns)
+    assert torch.isfinite(out).all()
+    for b in (0, 1, 4):
+        one = separate_chimera(m, wav[b:b + 1, :ns[b]].contiguous())
+        assert torch.equal(out[b, :, :ns[b]], one[0]) and (out[b, :, ns[b]:] == 0).all()

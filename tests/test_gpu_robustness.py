@@ -349,6 +349,21 @@ def test_windowed_evaluation_loop_matches_per_utterance_and_survives_an_abort(de
         lib.dll.onssen_xcd_spin_limit(old)
     assert P.recovered >= r0 + 1 and any("launch-per-step" in str(x.message) for x in w)
     assert abs(got - one_by_one) <= 2e-3 * max(1.0, abs(one_by_one))        # step path vs persistent path: masks may flip a bin
+    # the same with K utterances per forward (round 4): a ragged batch whose persistent launches abort is re-run on the
+    # launch-per-step recurrence and the launch-per-iteration clustering, both of which take per-row extents
+    while P.skip:
+        t.eval(window=16)
+    assert abs(t.eval(batch=4) - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
+    r1 = P.recovered
+    old = lib.dll.onssen_xcd_spin_limit(0)
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = t.eval(window=2, batch=3)
+    finally:
+        lib.dll.onssen_xcd_spin_limit(old)
+    assert P.recovered >= r1 + 1 and any("launch-per-step" in str(x.message) for x in w)
+    assert abs(got - one_by_one) <= 2e-3 * max(1.0, abs(one_by_one))
     while P.skip:                                 # consume the back-off
         t.eval(window=16)
     n_p = P.persistent_launches
