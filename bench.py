@@ -209,12 +209,18 @@ def ragged_leg(dev, K=16, batches=6):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model = model.to(dev).eval()
     rng = np.random.default_rng(7)
-    sets = []
-    for i in range(batches):
-        ns = [int(v) for v in rng.integers(3 * 8000, 8 * 8000, K)]
-        base = synth_batch(50 + i, 8, max(ns), 8000)
-        wav = torch.from_numpy(np.concatenate([base, base[::-1]])[:K].copy()).to(dev)
-        sets.append((wav, torch.tensor(ns, dtype=torch.int32, device=dev), ns))
+    all_ns = [int(v) for v in rng.integers(3 * 8000, 8 * 8000, K * batches)]
+
+    def make_sets(lengths):
+        out_sets = []
+        for i in range(batches):
+            ns = lengths[i * K:(i + 1) * K]
+            base = synth_batch(50 + i, 8, max(ns), 8000)
+            wav = torch.from_numpy(np.concatenate([base, base[::-1]])[:K].copy()).to(dev)
+            out_sets.append((wav, torch.tensor(ns, dtype=torch.int32, device=dev), ns))
+        return out_sets
+    sets = make_sets(all_ns)                                  # batches in the order the utterances come
+    sets_sorted = make_sets(sorted(all_ns, reverse=True))     # the same utterances bucketed by length (tester.eval(bucket=...))
     with torch.no_grad():
         for wav, ln, _ in sets[:2]:
             separate_dc(model, wav, lengths=ln)
@@ -224,6 +230,14 @@ def ragged_leg(dev, K=16, batches=6):
             separate_dc(model, wav, lengths=ln)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        for wav, ln, _ in sets_sorted[:2]:
+            separate_dc(model, wav, lengths=ln)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for wav, ln, _ in sets_sorted:
+            separate_dc(model, wav, lengths=ln)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
         one = sets[0]
         t1 = time.perf_counter()
         for b in range(K):
@@ -236,7 +250,9 @@ def ragged_leg(dev, K=16, batches=6):
                         "dc_l2, device 2-means, eager launches",
             "utterances": K * batches, "audio_s": audio, "ms_per_utterance": dt / (K * batches) * 1e3, "x_real_time": audio / dt,
             "one_by_one_ms_per_utterance": dt1 / K * 1e3, "one_by_one_x_real_time": sum(one[2]) / 8000.0 / dt1,
-            "padding_overhead": sum(K * max(ns) for _, _, ns in sets) / sum(sum(ns) for _, _, ns in sets)}
+            "padding_overhead": sum(K * max(ns) for _, _, ns in sets) / sum(sum(ns) for _, _, ns in sets),
+            "bucketed_by_length": {"ms_per_utterance": dts / (K * batches) * 1e3, "x_real_time": audio / dts,
+                                   "padding_overhead": sum(K * max(ns) for _, _, ns in sets_sorted) / sum(sum(ns) for _, _, ns in sets_sorted)}}
 
 
 def training_leg(dev, layers=3, B=16, steps=6, warmup=3):

@@ -75,7 +75,7 @@ class tester:
         return inp, lab, (torch.tensor(frames, dtype=torch.int32).to(dev, non_blocking=True),
                           torch.tensor(lengths, dtype=torch.int32).to(dev, non_blocking=True))
 
-    def eval(self, window=8, batch=1):
+    def eval(self, window=8, batch=1, bucket=1):
         """Mean SI-SDR over the loader.
 
         ``batch`` = 1 is the reference's loop (onssen/utils/test.py:29-41: one utterance per forward).  That shape keeps 2
@@ -83,6 +83,9 @@ class tester:
         per forward: they are zero-padded to the longest (``collate``) and every stage -- network, clustering / masks,
         iSTFT, SI-SDR -- is told each row's own extent, so that every utterance's SDR is bit for bit the one the batch-1
         loop computes.  ``get_est_sig`` must then accept ``frames=`` and ``lengths=`` (tester_dc / tester_chimera do).
+        ``bucket`` = G > 1: G * K utterances are read ahead, sorted by length and cut into G batches of similar lengths -- a
+        batch costs what its longest utterance costs, and real corpora spread over a factor of 5 in length; the mean does not
+        depend on the order.
 
         Upstream synchronises on every utterance (``.item()``); here ``window`` forwards are queued back to back -- the host
         launches forward i+1 while the device works on forward i -- and the status words of their persistent launches are
@@ -130,14 +133,26 @@ class tester:
                 for input, label in self.test_loader:
                     yield input, label, None
                 return
+            K, G = int(batch), max(1, int(bucket))
+
+            def batches(items):      # similar lengths together: longest first
+                items = sorted(items, key=lambda it: -it[0][0].shape[1]) if G > 1 else items
+                chunk = []
+                for it in items:
+                    chunk.append(it)
+                    if sum(i[0][0].shape[0] for i in chunk) >= K:
+                        yield self.collate(chunk)
+                        chunk = []
+                if chunk:
+                    yield self.collate(chunk)
             items = []
             for item in self.test_loader:
                 items.append(item)
-                if sum(i[0][0].shape[0] for i in items) >= int(batch):
-                    yield self.collate(items)
+                if sum(i[0][0].shape[0] for i in items) >= K * G:
+                    yield from batches(items)
                     items = []
             if items:
-                yield self.collate(items)
+                yield from batches(items)
 
         with torch.no_grad():
             pend = []

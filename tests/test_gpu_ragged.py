@@ -149,6 +149,8 @@ def test_eval_batched_equals_the_one_by_one_loop(dev, monkeypatch, kind):
     for K in (3, 8, 16):
         got = t.eval(batch=K)
         assert abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one)), (K, got, one_by_one)     # (fp64 sums grouped differently)
+    got = t.eval(batch=3, bucket=2)                                # 6 utterances read ahead, sorted by length, two batches of 3
+    assert abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
     # every utterance's own SDR, bit for bit
     from onssen_amd.evaluate import batch_SDR_torch
     with torch.no_grad():

@@ -3,6 +3,7 @@
 # Usage: bash tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/
 tag=${1:-r01}
 root=$PWD/gpurun_out/prof_$tag
+rm -rf $root      # (gpurun merges into gpurun_out/: a stale pass of an earlier call would be averaged in)
 mkdir -p $root
 export TMPDIR=/tmp
 cd /tmp
