@@ -163,8 +163,7 @@ def _pack_x3(lib, sd, F, H, L, ug):
     return Hp, NP, wih3, whh3, bias
 
 
-@pytest.mark.parametrize("H,ug,frames", [(8, 4, [6, 3, 5]),                       # one 4-row group per direction
-                                         (24, 8, [4, 2, 4, 1, 3, 4, 2, 3, 4]),   # 9 rows: three 4-row groups
+@pytest.mark.parametrize("H,ug,frames", [(24, 8, [4, 2, 4, 1, 3, 4, 2, 3, 4]),   # 9 rows: three 4-row groups
                                          (12, 4, [3] * 9 + [2] * 9)])            # 18 rows: 8-row groups (stacked)
 def test_blstm_ragged_persistent_is_the_batch_of_one_bit_for_bit(lib, monkeypatch, H, ug, frames):
     """onssen_blstm_forward_ragged_f32 in the XCD-local persistent form (forked workgroups): inside its own frames every row
