@@ -470,6 +470,14 @@ def main():
             if int(st[0]) != 0 or int(st[2]) != 0:
                 raise SystemExit(f"persistent recurrence aborted / saw non-finite activations during the timed region (words {st.tolist()})")
             _XcdStatus.safe_protocol_seen |= int(st[1]) == 1
+    if kind == "deep_clustering":     # ... and the persistent Lloyd launch's: a bounded wait that gave up inside a graph replay would
+        from onssen_amd import separation      # otherwise pass unnoticed (the replays do not post their status words)
+        from onssen_amd.hip import get_lib as _gl
+        for key, buf in separation._CLUSTER_WS.items():
+            off = int(_gl().dll.onssen_dc_cluster_status_offset(key[1], key[4]))
+            word = int(buf[off:off + 4].cpu().view(torch.int32)[0])
+            if word != 0:
+                raise SystemExit(f"persistent 2-means launch gave up a bounded wait during the timed region (status {word & 0xffffffff:#x})")
     result["config"]["recurrence"] = ("XCD-local persistent kernel (one launch per layer)" if recurrence_plan(B, H)[1] & 4
                                       else "one launch per time step")
     result["config"]["xcd_placement_independent_protocol_used"] = _XcdStatus.safe_protocol_seen
