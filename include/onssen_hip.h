@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 9   /* 9: ragged batches of whole utterances (onssen_*_ragged_f32).  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 9   /* 9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -359,8 +359,11 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
  * 1 - label on active bins, 0 in both on silent bins.
  * Replaces `KMeans(n_clusters=2, random_state=0).fit_predict(emb)` + the mask fill at
  * egs/wsj0-2mix/deep_clustering/evaluate.py:36-41 (sklearn on the host upstream).  Deterministic farthest-point
- * initialisation and at most `iters` Lloyd iterations (an utterance whose assignment reaches its exact fixed point stops
- * earlier); cluster numbering is arbitrary, as it is upstream.  D <= 32.
+ * initialisation and at most `iters` Lloyd iterations; an utterance stops earlier when its assignment reaches its exact
+ * fixed point or -- sklearn's own rule, KMeans(tol=1e-4) being the reference's default -- when the summed squared shift of
+ * the two centroids is <= tol x the mean per-feature variance of the clustered rows (tol = 0: the fixed point only).  The
+ * rows are unit vectors (F.normalize, onssen/nn/deep_clustering.py:41): that variance is taken as (1 - |mean|^2) / D.
+ * Cluster numbering is arbitrary, as it is upstream.  D <= 32.
  * Default form: the active bins are compacted once into the workspace and ALL iterations run in one persistent launch
  * (8 workgroups per utterance that meet at a counter; every wait is bounded by onssen_xcd_spin_limit: a wait that gives up
  * sets the u32 at ws + onssen_dc_cluster_status_offset(B, D) -- the masks of that call are then not the converged ones and
@@ -372,7 +375,7 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
 size_t onssen_dc_cluster_workspace_bytes(int B, int T, int F, int D);
 size_t onssen_dc_cluster_status_offset(int B, int D);
 int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream);
+                          int iters, float tol, float* masks, void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N1  deep-clustering loss: VALUE (onssen_loss_dc_f32) and its GRADIENT w.r.t. the embedding (onssen_loss_dc_grad_f32):
@@ -461,7 +464,7 @@ int onssen_blstm_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, 
                                     const float* const* whh_p_host, const float* const* bias_p_host, float* y, void* ws,
                                     size_t ws_bytes, int flags, void* stream);
 int onssen_dc_cluster_ragged_f32(const float* emb, const float* feature, int B, int T, const int32_t* frames, int F, int D,
-                                 float db_threshold, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                 float db_threshold, int iters, float tol, float* masks, void* ws, size_t ws_bytes, int flags,
                                  void* stream);
 int onssen_mask_istft_ragged_f32(const float* stft_ri, const float* mask, int64_t m_sb, int64_t m_sc, int64_t m_st,
                                  int64_t m_sf, int B, int C, int T, const int32_t* frames, int n_fft, int hop, int length,
@@ -496,8 +499,8 @@ int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frame
 int onssen_linear_x3p_compact(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
                               float eps, const int32_t* dest, int64_t dest_bs, int F, float* comp, int R, int64_t comp_bs,
                               int bf16_only, void* stream);
-int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
-                                  void* stream);
+int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float tol, float* masks, void* ws, size_t ws_bytes,
+                                  int flags, void* stream);
 
 /* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
  * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */

@@ -80,18 +80,18 @@ SIGNATURES = {
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
+    "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     # deep-clustering separation without the embedding round trip (round 4)
     "onssen_dc_compact_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_dc_compact_layout": (_i, [_i, _i, _i, _i, _vp, _vp]),
     "onssen_dc_index_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _vp, _sz, _vp]),
     "onssen_linear_x3p_compact": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _f, _vp, _i64, _i, _vp, _i, _i64, _i, _vp]),
-    "onssen_dc_cluster_compact_f32": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _sz, _i, _vp]),
+    "onssen_dc_cluster_compact_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _i, _vp]),
     # ragged batches of whole utterances (round 4)
     "onssen_stft_logmag_ragged_f32": (_i, [_vp, _i, _i, _i64, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "onssen_blstm_forward_ragged_f32": (_i, [_vp, _i64, _i64, _i, _i, _vp, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
-    "onssen_dc_cluster_ragged_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _vp, _vp, _sz, _i, _vp]),
+    "onssen_dc_cluster_ragged_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _f, _i, _f, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_ragged_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "onssen_batch_sdr_ragged_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
@@ -328,14 +328,14 @@ class Lib:
         self.check(self.dll.onssen_linear_x3p_compact(a_img, M, K, w_img, bias, N, group, eps, dest, dest_bs, F, comp, R, comp_bs,
                                                       int(bool(bf16_only)), stream), "onssen_linear_x3p_compact")
 
-    def dc_cluster_compact(self, B, T, F, D, iters, masks, ws, ws_bytes, stream, flags=0):
-        self.check(self.dll.onssen_dc_cluster_compact_f32(B, T, F, D, iters, masks, ws, ws_bytes, flags, stream),
+    def dc_cluster_compact(self, B, T, F, D, iters, masks, ws, ws_bytes, stream, flags=0, tol=1e-4):
+        self.check(self.dll.onssen_dc_cluster_compact_f32(B, T, F, D, iters, tol, masks, ws, ws_bytes, flags, stream),
                    "onssen_dc_cluster_compact_f32")
 
-    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0, frames=None):
+    def dc_cluster(self, emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, stream, flags=0, frames=None, tol=1e-4):
         if frames is not None:       # ragged batch: utterance b owns frames[b] * F bins
-            self.check(self.dll.onssen_dc_cluster_ragged_f32(emb, feat, B, T, frames, F, D, db, iters, masks, ws, ws_bytes, flags,
+            self.check(self.dll.onssen_dc_cluster_ragged_f32(emb, feat, B, T, frames, F, D, db, iters, tol, masks, ws, ws_bytes, flags,
                                                              stream), "onssen_dc_cluster_ragged_f32")
             return
-        self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, masks, ws, ws_bytes, flags, stream),
+        self.check(self.dll.onssen_dc_cluster_f32(emb, feat, B, T, F, D, db, iters, tol, masks, ws, ws_bytes, flags, stream),
                    "onssen_dc_cluster_f32")

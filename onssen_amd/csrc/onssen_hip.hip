@@ -1220,8 +1220,8 @@ size_t onssen_dc_cluster_workspace_bytes(int B, int T, int F, int D) {
 }
 
 static int dc_cluster_impl(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                           int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream, const int32_t* frames) {
-  if (!emb || !feature || !masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0)
+                           int iters, float tol, float* masks, void* ws, size_t ws_bytes, int flags, void* stream, const int32_t* frames) {
+  if (!emb || !feature || !masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0 || !(tol >= 0.f))
     return ONSSEN_E_ARG;
   if (ws_bytes < onssen_dc_cluster_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
   if (!aligned16(emb) || (reinterpret_cast<uintptr_t>(ws) & 255u)) return ONSSEN_E_ALIGN;
@@ -1263,15 +1263,15 @@ static int dc_cluster_impl(const float* emb, const float* feature, int B, int T,
     for (int u0 = 0; u0 < B && iters > 0; u0 += lloyd_utts) {
       const int nutt = B - u0 < lloyd_utts ? B - u0 : lloyd_utts;
       const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
-      if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
-      else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status);
+      if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, tol);
+      else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0>), lgrid, dim3(km::LT), 0, st, (const float*)comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, tol);
     }
   } else {
     hipLaunchKernelGGL((kmeans2_search_kernel<1>), sgrid, dim3(256), 0, st, emb, feature, per_utt, D, db_threshold, w, stride, frames, F);
     hipLaunchKernelGGL((kmeans2_pick_kernel<1>), dim3((unsigned)B), dim3(64), 0, st, emb, per_utt, D, w, stride, (int*)nullptr);
     for (int it = 0; it < iters; ++it) {
       ONSSEN_KM_ASSIGN(0, (float*)nullptr);
-      hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(256), 0, st, D, km::NBLK, w, stride);
+      hipLaunchKernelGGL(kmeans2_update_kernel, dim3((unsigned)B), dim3(256), 0, st, D, km::NBLK, w, stride, tol);
     }
   }
   ONSSEN_KM_ASSIGN(1, masks);
@@ -1314,9 +1314,9 @@ int onssen_dc_index_f32(const float* feature, int B, int T, const int32_t* frame
   return ONSSEN_OK;
 }
 
-int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
-                                  void* stream) {
-  if (!masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0) return ONSSEN_E_ARG;
+int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float tol, float* masks, void* ws, size_t ws_bytes,
+                                  int flags, void* stream) {
+  if (!masks || !ws || B <= 0 || T <= 0 || F <= 0 || D <= 0 || D > km::DMAX || iters < 0 || !(tol >= 0.f)) return ONSSEN_E_ARG;
   if (flags & ONSSEN_DC_CLUSTER_LAUNCH_PER_ITERATION) return ONSSEN_E_ARG;      // the compacted form IS the persistent form
   if (ws_bytes < onssen_dc_compact_workspace_bytes(B, T, F, D)) return ONSSEN_E_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(ws) & 255u) return ONSSEN_E_ALIGN;
@@ -1342,8 +1342,8 @@ int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* 
   for (int u0 = 0; u0 < B; u0 += lloyd_utts) {     // (also with iters = 0: pass 0 initialises the centroids)
     const int nutt = B - u0 < lloyd_utts ? B - u0 : lloyd_utts;
     const dim3 lgrid((unsigned)(ceil_div(nutt, 8) * 8 * km::NBP));
-    if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, dest);
-    else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, dest);
+    if (D == 20) hipLaunchKernelGGL((kmeans2_lloyd_kernel<20, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, tol, dest);
+    else hipLaunchKernelGGL((kmeans2_lloyd_kernel<0, true>), lgrid, dim3(km::LT), 0, st, comp, per_utt, D, iters, w, stride, iw, u0, nutt, spin, status, tol, dest);
   }
   if (D == 20) hipLaunchKernelGGL((kmeans2_mask_compact_kernel<20>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);
   else hipLaunchKernelGGL((kmeans2_mask_compact_kernel<0>), dim3(km::NBLK * 4, (unsigned)B), dim3(256), 0, st, comp, dest, per_utt, D, (const float*)w, stride, masks);
@@ -1352,15 +1352,15 @@ int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float* 
 }
 
 int onssen_dc_cluster_f32(const float* emb, const float* feature, int B, int T, int F, int D, float db_threshold,
-                          int iters, float* masks, void* ws, size_t ws_bytes, int flags, void* stream) {
-  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, masks, ws, ws_bytes, flags, stream, nullptr);
+                          int iters, float tol, float* masks, void* ws, size_t ws_bytes, int flags, void* stream) {
+  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, tol, masks, ws, ws_bytes, flags, stream, nullptr);
 }
 
 int onssen_dc_cluster_ragged_f32(const float* emb, const float* feature, int B, int T, const int32_t* frames, int F, int D,
-                                 float db_threshold, int iters, float* masks, void* ws, size_t ws_bytes, int flags,
+                                 float db_threshold, int iters, float tol, float* masks, void* ws, size_t ws_bytes, int flags,
                                  void* stream) {
   if (!frames) return ONSSEN_E_ARG;
-  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, masks, ws, ws_bytes, flags, stream, frames);
+  return dc_cluster_impl(emb, feature, B, T, F, D, db_threshold, iters, tol, masks, ws, ws_bytes, flags, stream, frames);
 }
 
 #ifdef ONSSEN_FFT_PROFILE

@@ -62,7 +62,7 @@ def _cluster_ws(device, key, nb, head, ragged):
     return ws
 
 
-def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=None):
+def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=None, tol=1e-4):
     """Deep-clustering masks (B,T,F,2) straight from the mixture's log-magnitude WITHOUT materialising the embedding
     (round 4): the active bins are known before the network runs (evaluate.py:36-37), so the threshold is turned into a
     target map first (onssen_dc_index_f32), ``model``'s fc_dc GEMM stores only the active bins' normalised rows -- straight
@@ -103,19 +103,21 @@ def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=No
     lib.linear_x3p_compact(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
                            ws.data_ptr() + dest_off, T * F, F, ws.data_ptr() + comp_off, B, T * F * D, precision() == "bf16", st)
     masks = torch.empty(B, T, F, 2, device=logmag.device, dtype=torch.float32)
-    lib.dc_cluster_compact(B, T, F, D, iters, masks.data_ptr(), ws.data_ptr(), nb, st)
+    lib.dc_cluster_compact(B, T, F, D, iters, masks.data_ptr(), ws.data_ptr(), nb, st, tol=float(tol))
     _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
 
 
-def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None):
+def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None, tol=1e-4):
     """Binary deep-clustering masks (B,T,F,2) on the device: threshold at max - db/20, 2-means on the active
     bins' embeddings (counterpart of evaluate.py:36-41, where it is sklearn on the host).
 
     Default: the active bins are compacted once and all Lloyd iterations run in ONE persistent launch (8 workgroups per
     utterance meeting at a counter); its waits are bounded, and a wait that gave up is reported like an aborted recurrence
     (``_XcdStatus``: the owning call is re-run with the launch-per-iteration form, which is also what runs inside
-    ``_XcdPolicy.forced_steps()`` and with ONSSEN_DC_PERSISTENT=0).
+    ``_XcdPolicy.forced_steps()`` and with ONSSEN_DC_PERSISTENT=0).  ``iters`` / ``tol``: at most that many Lloyd iterations,
+    stopped earlier at the exact fixed point or by sklearn's rule (``KMeans(tol=1e-4)``, upstream's default: summed squared
+    centroid shift <= tol x mean per-feature variance); ``tol=0`` iterates to the fixed point.
 
     ``frames`` (B,): a ragged batch -- utterance b owns its first frames[b] frames; its padding is never active, takes no
     part in the threshold or the sums, and gets zero masks.  Such calls (a new longest utterance per batch) share ONE
@@ -137,7 +139,7 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None):
     lib.dc_cluster(emb.data_ptr(), logmag.data_ptr(), B, T, F, D, float(db_threshold), iters, masks.data_ptr(),
                    ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream,
                    flags=0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION,
-                   frames=frames.data_ptr() if frames is not None else None)
+                   frames=frames.data_ptr() if frames is not None else None, tol=float(tol))
     if persistent:
         _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
