@@ -50,7 +50,8 @@ extern "C" {
 #define ONSSEN_BLSTM_XCD 4        /* (with BF16X3) one persistent launch per layer: every (direction, 4 / 8 / 16-row group)
                                      recurrence runs inside one XCD, W_hh register-resident, h_t exchanged through
                                      that XCD's L2 as data-tagged bf16 words (no flags).  Needs ceil(H/ug) <= 32,
-                                     H <= 640, ug <= 20.  The kernel verifies the placement itself and otherwise
+                                     H <= 640, ug <= 20 -- or (round 4, split-bf16 only, without FUSE_IN0 / BF16 and
+                                     not in the training forward) ug = 24: 640 < H <= 768.  The kernel verifies the placement itself and otherwise
                                      uses placement-independent (write-through / system-scope) accesses; bounded
                                      waits: ws word [281] = 1 reports that, word [280] != 0 an aborted launch
                                      (outputs invalid), word [282] = 1 a non-finite activation (a NaN cannot carry

@@ -214,7 +214,7 @@ int onssen_stft_logmag_ragged_f32(const float* wav, int B, int n_max, int64_t wa
 }
 
 int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_elems) {
-  if (H <= 0 || ug < 4 || ug > 20 || (ug % 4) != 0) return ONSSEN_E_ARG;
+  if (H <= 0 || ug < 4 || ug > 24 || (ug % 4) != 0) return ONSSEN_E_ARG;
   const int hp = ceil_div(H, ug) * ug, kq = ceil_div(hp, 16);
   if (Hp) *Hp = hp;
   if (NP) *NP = 4 * hp;
@@ -815,7 +815,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
   const bool x3 = (flags & ONSSEN_BLSTM_BF16X3) != 0;
   int KQ2 = 0, Hs = 0;
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
-  if (x3 && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the split-bf16 form
+  if (x3 && !(flags & ONSSEN_BLSTM_XCD) && KQ2 > 4 * rec::QB3) return ONSSEN_E_ARG;   // H <= 640 in the launch-per-step split-bf16 form
   uint16_t* hsb = (uint16_t*)wsp;
   const size_t hs_bytes = (size_t)2 * 2 * ceil_div(B, 4) * KQ2 * 2048;   // split-bf16 images of all groups; >= the fp32 image (2*KQ2 >= KQ)
   wsp += align256(hs_bytes);
@@ -875,7 +875,10 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
     if (flags & ONSSEN_BLSTM_XCD) {
       // without ONSSEN_BLSTM_BF16X3: the exact-fp32 instantiation (whh_p_host[l] = the fp32 fragment image of
       // onssen_lstm_pack_f32, G from the exact-fp32 GEMM above, fp32 rows between the layers)
-      if (ug > 20 || Hp / ug > 32 || KQ2 > 20 || (!x3 && (save_g || save_c))) return ONSSEN_E_ARG;
+      // split-bf16: H <= 768 (ug = 24: 32 members of 24 units = every CU of an XCD; round 4), exact fp32 and the forms that fuse
+      // the first layer / save state: H <= 640 (ug <= 20)
+      if (ug > 24 || Hp / ug > 32 || KQ2 > 24 || (!x3 && (save_g || save_c))) return ONSSEN_E_ARG;
+      if (ug > 20 && (!x3 || fuse0 || save_g || save_c || (flags & ONSSEN_BLSTM_BF16))) return ONSSEN_E_ARG;
       // bounded waits: ~0.2 s of polling on the GPU; ONSSEN_XCD_SPIN_LIMIT overrides (the host-side emulation, where a
       // 'workgroup' is a process at the mercy of the OS scheduler, raises it)
       const unsigned xcd_spin = xcd_spin_limit();
@@ -901,7 +904,8 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
         case 8: rc = launch_xcd<2>(xa, xcd_nw, st); break;
         case 12: rc = launch_xcd<3>(xa, xcd_nw, st); break;
         case 16: rc = launch_xcd<4>(xa, xcd_nw, st); break;
-        default: rc = launch_xcd<5>(xa, xcd_nw, st); break;
+        case 20: rc = launch_xcd<5>(xa, xcd_nw, st); break;
+        default: rc = launch_xcd_wide(xa, st); break;      // ug = 24: 640 < H <= 768
       }
       if (rc != ONSSEN_OK) return rc;
       continue;

@@ -124,20 +124,27 @@ def recovering(fn):
     return wrapper
 
 
+def persistent_capable(H):
+    """Does the XCD-local persistent INFERENCE recurrence hold a layer of H units?  Up to 640 in every precision mode; up to 768
+    in the default split-bf16 mode (round 4: 32 members of 24 units -- every CU of an XCD --, W_hh in 144 of the 256 registers)."""
+    return H <= 640 or (H <= 768 and precision() == "bf16x3")
+
+
 def recurrence_plan(B, H):
     """(ug, flags) for onssen_blstm_forward_f32.
 
-    H <= 640: the XCD-local persistent recurrence (one launch per layer, every (direction, 4 / 8 / 16-row group)
+    H <= 640 (768 in split-bf16): the XCD-local persistent recurrence (one launch per layer, every (direction, 4 / 8 / 16-row group)
     inside one XCD, at most 32 unit groups -> ug = 4*ceil(H/128)) -- split-bf16 / bf16 products on x3 images, or
     (precision f32, round 3) exact-fp32 MFMAs on fp32 images.  Otherwise one
-    launch per time step with 8 hidden units per workgroup.  ONSSEN_XCD=0 forces the per-step form (so does a
+    launch per time step with 8 hidden units per workgroup (split-bf16 up to H = 640, exact fp32 above).  ONSSEN_XCD=0 forces the per-step form (so does a
     ``_XcdPolicy.forced_steps()`` scope or a back-off after consecutive aborts), ONSSEN_UG overrides its unit-group
     size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
     flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
-    x3 = _split_bf16() and H <= 640
+    xcd = persistent_capable(H) and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed()
+    x3 = _split_bf16() and (H <= 640 or xcd)
     if x3:
         flags |= _abi.BLSTM_BF16X3
-    if H <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed():
+    if xcd:
         # (precision f32: the same persistent launch in exact fp32 -- flags carry BLSTM_XCD without BLSTM_BF16X3)
         if precision() == "bf16":
             flags |= _abi.BLSTM_BF16
@@ -418,7 +425,7 @@ class _PackedImages:
             lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
             self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
             self.wih_img.append(ai)
-            if l == 0 and in_l <= 129:   # fragment image for the fused first-layer input projection (FUSE_IN0: <= 4 MFMA k-chunks)
+            if l == 0 and in_l <= 129 and self.ug <= 20:   # fragment image for the fused first-layer input projection (FUSE_IN0: <= 4 MFMA k-chunks)
                 kc = (in_l + 31) // 32
                 f0 = torch.empty(2, (self.Hp // self.ug) * kc * (self.ug // 4) * 1024, device=dev, dtype=torch.int16)
                 for d in range(2):
@@ -595,7 +602,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in bias], y.data_ptr() if need_y or not images else None,
                       wsb.data_ptr(), wsb.numel(), flags, _stream(), frames=frames.data_ptr() if frames is not None else None)
-    if p.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
+    if persistent_capable(p.hidden_size) and os.environ.get("ONSSEN_XCD", "1") == "1":
         _XcdPolicy.note_launch(bool(flags & _abi.BLSTM_XCD))
     y.x3_image = None
     y.fp32_valid = bool(need_y or not images)

@@ -533,6 +533,67 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
+@pytest.mark.parametrize("H,B,T,ragged", [(48, 3, 4, False), (40, 17, 3, False), (48, 5, 4, True)])
+def test_blstm_xcd_24_unit_groups(lib, monkeypatch, H, B, T, ragged):
+    """Round 4: 24 hidden units per member (640 < H <= 768 on the device: 32 members = every CU of an XCD) -- split-bf16 only,
+    neither the fused first projection nor the training state; the other precision modes and those flags are refused."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", "0")
+    lib.dll.onssen_xcd_spin_limit(40000000)
+    F, L, ug = 9, 2, 24
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(5)
+    x = _shm((B, T, F)); x[...] = rand(rng, B, T, F)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    wih3, whh3, bias = [], [], []
+    for l in range(L):
+        K = F if l == 0 else 2 * Hp
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
+        scratch = _shm((we,))
+        for d, sfx in enumerate(("", "_reverse")):
+            srcs = []
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                v = sd[f"rnn.{n}_l{l}{sfx}"]
+                sv = _shm(v.shape); sv[...] = v
+                srcs.append(sv)
+            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
+                          P(a[d]), P(scratch), P(c[d]), None)
+            lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
+        pl = _shm((2 * NP, (K + 31) // 32, 2, 32), dtype=np.uint16)
+        lib.x3_image(P(a), Kp, 0, 1, 2 * NP, K, P(pl), None)
+        wih3.append(pl), whh3.append(b3), bias.append(c)
+    ws = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
+    _poison_handoff(ws, B, T, Hp, NP, L)
+    y = _shm((T, B, 2, Hp), fill=np.nan)
+    args = (P(x), T * F, F, B, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3], [P(a) for a in bias], P(y), P(ws),
+            ws.nbytes)
+    for bad in (_abi.BLSTM_XCD, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD | _abi.BLSTM_FUSE_IN0,
+                _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD | _abi.BLSTM_BF16):
+        with pytest.raises(_abi.OnssenError):
+            lib.blstm_forward(*args, bad, None)
+    frames = None
+    if ragged:
+        frames = _shm((B,), dtype=np.int32); frames[...] = [4, 1, 3, 2, 4]
+        lib.blstm_forward(*args, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD, None, frames=P(frames))
+    else:
+        lib.blstm_forward(*args, _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD, None)
+    status = ws.view(np.uint32)
+    assert status[280] == 0, f"launch aborted (code {status[280]})"
+    got = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+    if ragged:
+        for b in range(B):
+            n = int(frames[b])
+            ref = O.blstm_stack(np.array(x[b:b + 1, :n]), sd, "rnn.", L)
+            assert np.abs(got[b, :n] - ref[0]).max() < 2e-5
+            assert np.all(got[b, n:] == 0)
+        return
+    ref = O.blstm_stack(np.array(x), sd, "rnn.", L)
+    assert np.abs(got - ref).max() < 2e-5
+    assert np.all(np.array(y)[:, :, :, H:] == 0)
+
+
 @pytest.mark.parametrize("H,ug,B,T,scramble", [(8, 4, 3, 4, "0"), (24, 8, 17, 3, "0"), (40, 20, 5, 5, "0"), (24, 8, 6, 3, "1")])
 def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
     """ONSSEN_BLSTM_XCD WITHOUT ONSSEN_BLSTM_BF16X3 (round 3): the persistent recurrence in exact fp32 -- fp32 fragment
