@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 9   /* 9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -186,6 +186,14 @@ int onssen_linear_x3p_batched(const uint16_t* a_img, int64_t a_bs, int M, int K,
 int onssen_linear_x3p_batched_split(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
                                     const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1,
                                     int n_split, float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream);
+/* ... with the roles of the two outputs alternating: even problems as above, ODD problems write their columns n < n_split_odd
+ * to C2 (+ z*c2_bs, column n) and the rest to C (+ z*c_bs, column n - n_split_odd).  With w_bs smaller than a problem's N rows the
+ * problems' W windows overlap: the training path lays out [h_prev forward | x | h_prev reverse] (Hp | Kx | Hp image rows),
+ * w_bs = Hp rows -- problem 0 reads [h_f | x], problem 1 [x | h_r], and the layer input's transposed image exists once. */
+int onssen_linear_x3p_batched_split_alt(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                                        const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1,
+                                        int n_split, float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int n_split_odd,
+                                        int batch, void* stream);
 
 /* x3 image of the TRANSPOSE of a row-major fp32 matrix src [K][ld >= M], optionally shifted along k: image row m
  * (0 <= m < M), element k (0 <= k < K) = src[(k + k_shift) * ld + m], 0 where k + k_shift is outside [0, K).  Operands of
@@ -217,6 +225,13 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
 int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int n_split,
                            int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, float* C2, int64_t c2_s0,
                            int64_t c2_s1, int bf16_only, void* stream);
+/* The embedding head of a TRAINING forward (onssen/nn/deep_clustering.py:39-41: fc_dc, then F.normalize over each bin's D
+ * features): C [M][N] = the normalised rows as with ONSSEN_EPI_L2NORM, and inv_norm [M][N / group] = 1 / max(||x||, eps) of
+ * every group (group a multiple of 4 dividing 80).  With the two, the backward of the normalisation needs no raw product
+ * (onssen_l2norm_rows_grad_y_f32): the 4 M N bytes of x are neither written nor read back, and the separate normalisation
+ * pass of the forward disappears. */
+int onssen_linear_x3p_norms(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
+                            float eps, float* C, float* inv_norm, void* stream);
 
 /* The same GEMM with phase_net's head epilogue (onssen/nn/phase_network.py:58-66: fc_phase(bn(rnn)) + mix phase, then
  * F.normalize over (re, im)): C = normalise_group(a_img . w_img^T + bias + resid), group = 2 (pairs of consecutive
@@ -323,7 +338,7 @@ int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float
  * B*T frames of the batch): y = (x - mean) * invstd * gamma + beta with the batch's biased variance, mean / invstd returned
  * for the backward pass (the caller updates running_mean / running_var from mean and 1 / invstd^2 - eps, unbiased by
  * M / (M - 1), as nn.BatchNorm1d does); and its backward: dbeta = sum dy, dgamma = sum dy * xhat,
- * dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).  Column sums are partial sums of 128-row strips added in a
+ * dx = gamma * invstd * (dy - dbeta / M - xhat * dgamma / M).  Column sums are partial sums of 32-row strips added in a
  * fixed order (deterministic).  ws: onssen_bn_rows_workspace_bytes(M, C). */
 size_t onssen_bn_rows_workspace_bytes(int64_t M, int C);
 int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps, float* y,
@@ -331,6 +346,10 @@ int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamm
 int onssen_bn_rows_grad_f32(const float* x, const float* dy, int64_t M, int C, const float* gamma, const float* mean,
                             const float* invstd, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, int D, float eps, float* dx, void* stream);
+/* ... from the normalisation's output y and inv_norm = 1 / max(||x||, eps) per row (what onssen_linear_x3p_norms leaves):
+ * dx = (g - y (y . g)) * inv_norm where the norm was not clamped, g * inv_norm otherwise. */
+int onssen_l2norm_rows_grad_y_f32(const float* y, const float* inv_norm, const float* g, int64_t rows, int D, float eps, float* dx,
+                                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K11 glue  recurrent input of the phase network for all C speakers at once:

@@ -9,7 +9,7 @@ import ctypes as C
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 9
+ABI_VERSION = 10
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
 BLSTM_XCD = 4
@@ -49,6 +49,8 @@ SIGNATURES = {
     "onssen_linear_x3p_batched": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
                                              _i, _vp]),
+    "onssen_linear_x3p_batched_split_alt": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64,
+                                                 _i64, _i, _i, _vp]),
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_x3_image_both_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -65,6 +67,8 @@ SIGNATURES = {
     "onssen_bn_rows_train_f32": (_i, [_vp, _i64, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_bn_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_l2norm_rows_grad_f32": (_i, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
+    "onssen_l2norm_rows_grad_y_f32": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp]),
+    "onssen_linear_x3p_norms": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "onssen_phase_input_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_debug_cotenant_spin": (_i, [_i, _i, C.c_longlong, _i, _vp]),
@@ -245,6 +249,12 @@ class Lib:
         self.check(self.dll.onssen_linear_x3p_batched_split(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1, n_split,
                                                             out2, c2_bs, c2_s0, c2_s1, batch, stream), "onssen_linear_x3p_batched_split")
 
+    def linear_x3p_batched_split_alt(self, a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1, n_split, out2, c2_bs,
+                                     c2_s0, c2_s1, n_split_odd, batch, stream):
+        self.check(self.dll.onssen_linear_x3p_batched_split_alt(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1,
+                                                                n_split, out2, c2_bs, c2_s0, c2_s1, n_split_odd, batch, stream),
+                   "onssen_linear_x3p_batched_split_alt")
+
     def x3_image_t(self, src, ld, M, K, k_shift, img, stream):
         self.check(self.dll.onssen_x3_image_t_f32(src, ld, M, K, k_shift, img, stream), "onssen_x3_image_t_f32")
 
@@ -294,6 +304,13 @@ class Lib:
 
     def l2norm_rows_grad(self, x, g, rows, D, eps, dx, stream):
         self.check(self.dll.onssen_l2norm_rows_grad_f32(x, g, rows, D, eps, dx, stream), "onssen_l2norm_rows_grad_f32")
+
+    def l2norm_rows_grad_y(self, y, inv_norm, g, rows, D, eps, dx, stream):
+        self.check(self.dll.onssen_l2norm_rows_grad_y_f32(y, inv_norm, g, rows, D, eps, dx, stream), "onssen_l2norm_rows_grad_y_f32")
+
+    def linear_x3p_norms(self, a_img, M, K, w_img, bias, N, group, eps, Cp, inv_norm, stream):
+        self.check(self.dll.onssen_linear_x3p_norms(a_img, M, K, w_img, bias, N, group, eps, Cp, inv_norm, stream),
+                   "onssen_linear_x3p_norms")
 
     def dropout(self, x, n, p, seed, out, stream):
         self.check(self.dll.onssen_dropout_f32(x, n, p, seed, out, stream), "onssen_dropout_f32")

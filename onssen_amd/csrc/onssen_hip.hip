@@ -418,9 +418,11 @@ int onssen_x3_image_both_f32(const float* src, int64_t ld, int M, int K, uint16_
 
 static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
                                    const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1, int n_split,
-                                   float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream) {
+                                   float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int batch, void* stream,
+                                   int n_split_odd = 0) {
   if (!a_img || !w_img || !bias || !C || M <= 0 || K <= 0 || N <= 0 || R <= 0 || batch <= 0 || batch > 65535) return ONSSEN_E_ARG;
   if (C2 && (n_split <= 0 || n_split >= N)) return ONSSEN_E_ARG;
+  if (n_split_odd && (!C2 || n_split_odd < 0 || n_split_odd >= N)) return ONSSEN_E_ARG;
   if (!aligned16(a_img) || !aligned16(w_img) || (a_bs % 8) != 0 || (w_bs % 8) != 0) return ONSSEN_E_ALIGN;
   const int KB = ceil_div(K, 32);
   if ((long)lxp::BM * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
@@ -430,7 +432,7 @@ static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, i
   p.KB = KB; p.group = 0; p.eps = 0.f; p.tile_group = 4;
   p.c_vec = !C2 && aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0 && (c_bs % 4) == 0;
   p.a_bs = (long)a_bs; p.w_bs = (long)w_bs; p.c_bs = (long)c_bs;
-  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = (long)c2_bs; p.n_split = n_split;
+  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = (long)c2_bs; p.n_split = n_split; p.n_split_odd = n_split_odd;
   p.resid = nullptr; p.r_mod = 1; p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   const dim3 grid((unsigned)ceil_div(N, lxp::BN), (unsigned)ceil_div(M, lxp::BM), (unsigned)batch);
   hipLaunchKernelGGL((linear_x3p_kernel<ONSSEN_EPI_BIAS, 4, 3, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
@@ -452,9 +454,18 @@ int onssen_linear_x3p_batched_split(const uint16_t* a_img, int64_t a_bs, int M, 
                                  batch, stream);
 }
 
+int onssen_linear_x3p_batched_split_alt(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,
+                                        const float* bias, int N, int R, float* C, int64_t c_bs, int64_t c_s0, int64_t c_s1,
+                                        int n_split, float* C2, int64_t c2_bs, int64_t c2_s0, int64_t c2_s1, int n_split_odd,
+                                        int batch, void* stream) {
+  if (!C2 || n_split_odd <= 0) return ONSSEN_E_ARG;
+  return linear_x3p_batched_impl(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, C, c_bs, c_s0, c_s1, n_split, C2, c2_bs, c2_s0, c2_s1,
+                                 batch, stream, n_split_odd);
+}
+
 static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
                            int group, float eps, const float* resid, int resid_mod, float* C, int R, int64_t c_s0,
-                           int64_t c_s1, void* stream) {
+                           int64_t c_s1, void* stream, float* inv_norm = nullptr) {
   if (!a_img || !w_img || !bias || !C || R <= 0 || M <= 0 || K <= 0 || N <= 0) return ONSSEN_E_ARG;
   if (!aligned16(a_img) || !aligned16(w_img)) return ONSSEN_E_ALIGN;
   const int KB = ceil_div(K, 32);
@@ -470,13 +481,14 @@ static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* 
     return ONSSEN_E_ARG;
   }
   if (resid && (mode != ONSSEN_EPI_L2NORM || resid_mod <= 0)) return ONSSEN_E_ARG;
+  if (inv_norm && (mode != ONSSEN_EPI_L2NORM || pairs)) return ONSSEN_E_ARG;
   ONSSEN_CLEAR_ERROR();
   LinearXpArgs p;
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = C; p.c_s0 = (long)c_s0; p.c_s1 = (long)c_s1; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = group; p.eps = eps; p.resid = resid; p.r_mod = resid ? resid_mod : 1;
   p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   p.a_bs = p.w_bs = p.c_bs = 0;
-  p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
+  p.C2 = inv_norm; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0; p.n_split_odd = 0;
   static const int x3_gn = ONSSEN_KNOB_INT("ONSSEN_X3_GN", 4);
   p.tile_group = x3_gn < 1 ? 1 : x3_gn;
   p.c_vec = aligned16(C) && (N % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
@@ -487,8 +499,8 @@ static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* 
   // groups per wave (80 columns) and stays at 320 columns.  ONSSEN_X3Q=320 / 256 forces the width, ONSSEN_X3Q_BM=256 / 128 the height.
   const char* env_q = getenv("ONSSEN_X3Q");   // read per call: the tests switch it
   const char* env_bm = getenv("ONSSEN_X3Q_BM");
-  const int use_q = (pairs || resid) ? 1 : env_q ? atoi(env_q) : 1, force_bm = env_bm ? atoi(env_bm) : 0;
-  if ((pairs || resid) && (long)lxq::BM_MAX * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
+  const int use_q = (pairs || resid || inv_norm) ? 1 : env_q ? atoi(env_q) : 1, force_bm = env_bm ? atoi(env_bm) : 0;
+  if ((pairs || resid || inv_norm) && (long)lxq::BM_MAX * KB * 128 > 0x7fffffffL) return ONSSEN_E_ARG;
   if (use_q && (long)lxq::BM_MAX * KB * 128 <= 0x7fffffffL) {
     int bm = 256, bn = 320;
     double best = 1e30;
@@ -553,6 +565,12 @@ int onssen_linear_x3p(const uint16_t* a_img, int M, int K, const uint16_t* w_img
   return linear_x3p_impl(a_img, M, K, w_img, bias, N, mode, group, eps, nullptr, 0, C, R, c_s0, c_s1, stream);
 }
 
+int onssen_linear_x3p_norms(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int group,
+                            float eps, float* C, float* inv_norm, void* stream) {
+  if (!inv_norm || group <= 2) return ONSSEN_E_ARG;
+  return linear_x3p_impl(a_img, M, K, w_img, bias, N, ONSSEN_EPI_L2NORM, group, eps, nullptr, 0, C, 1, N, 0, stream, inv_norm);
+}
+
 int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int n_split,
                            int group, float eps, float* C, int R, int64_t c_s0, int64_t c_s1, float* C2, int64_t c2_s0,
                            int64_t c2_s1, int bf16_only, void* stream) {
@@ -568,7 +586,7 @@ int onssen_linear_x3p_pair(const uint16_t* a_img, int M, int K, const uint16_t* 
   p.KB = KB; p.group = group; p.eps = eps; p.resid = nullptr; p.r_mod = 1;
   p.dest = nullptr; p.dest_bs = 0; p.F = 0;
   p.a_bs = p.w_bs = p.c_bs = 0;
-  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = 0; p.n_split = n_split;
+  p.C2 = C2; p.c2_s0 = (long)c2_s0; p.c2_s1 = (long)c2_s1; p.c2_bs = 0; p.n_split = n_split; p.n_split_odd = 0;
   p.tile_group = 4;
   p.c_vec = aligned16(C) && (n_split % 4) == 0 && (c_s0 % 4) == 0 && (c_s1 % 4) == 0;
   // half-height tiles where 256-row tiles would leave CUs idle (the cost model of onssen_linear_x3p)
@@ -597,7 +615,7 @@ int onssen_linear_x3p_compact(const uint16_t* a_img, int M, int K, const uint16_
   p.A = a_img; p.W = w_img; p.bias = bias; p.C = comp; p.c_s0 = 0; p.c_s1 = (long)comp_bs; p.R = R; p.M = M; p.N = N;
   p.KB = KB; p.group = group; p.eps = eps; p.resid = nullptr; p.r_mod = 1;
   p.a_bs = p.w_bs = p.c_bs = 0;
-  p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0;
+  p.C2 = nullptr; p.c2_s0 = p.c2_s1 = p.c2_bs = 0; p.n_split = 0; p.n_split_odd = 0;
   p.dest = dest; p.dest_bs = (long)dest_bs; p.F = F;
   p.tile_group = 4;
   p.c_vec = 1;
@@ -630,8 +648,12 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
   if (ws_bytes < onssen_loss_dc_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_dc_partial_kernel, dim3(lossdc::NBLK, (unsigned)B), dim3(256), 0, st, emb, one_hot, mag, TF, D, C,
-                     (float*)ws);
+  if (D + C <= 32)
+    hipLaunchKernelGGL(loss_dc_partial_mfma_kernel, dim3(lossdc::NBLK, (unsigned)B), dim3(256), 0, st, emb, one_hot, mag, TF, D, C,
+                       (float*)ws);
+  else
+    hipLaunchKernelGGL(loss_dc_partial_kernel, dim3(lossdc::NBLK, (unsigned)B), dim3(256), 0, st, emb, one_hot, mag, TF, D, C,
+                       (float*)ws);
   hipLaunchKernelGGL(loss_dc_final_kernel, dim3((unsigned)B), dim3(256), 0, st, (const float*)ws, D, C, per_utt, total_mag);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
@@ -1119,7 +1141,7 @@ int onssen_bn_rows_train_f32(const float* x, int64_t M, int C, const float* gamm
   const dim3 gp((unsigned)nblk, (unsigned)ceil_div(C, 256));
   hipLaunchKernelGGL((bn_rows_partial_kernel<0>), gp, dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (long)M, C, (float*)ws);
-  hipLaunchKernelGGL((bn_rows_final_kernel<0>), dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, (const float*)ws, nblk, (long)M, C,
+  hipLaunchKernelGGL((bn_rows_final_kernel<0>), dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)ws, nblk, (long)M, C,
                      eps, mean, invstd);
   const long nb = ((long)M * C + 255) / 256;
   hipLaunchKernelGGL((bn_rows_apply_kernel<0>), dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, x, (const float*)nullptr,
@@ -1137,7 +1159,7 @@ int onssen_bn_rows_grad_f32(const float* x, const float* dy, int64_t M, int C, c
   const int nblk = (int)((M + bnr::STRIP - 1) / bnr::STRIP);
   const dim3 gp((unsigned)nblk, (unsigned)ceil_div(C, 256));
   hipLaunchKernelGGL((bn_rows_partial_kernel<1>), gp, dim3(256), 0, st, x, dy, mean, invstd, (long)M, C, (float*)ws);
-  hipLaunchKernelGGL((bn_rows_final_kernel<1>), dim3((unsigned)ceil_div(C, 128)), dim3(128), 0, st, (const float*)ws, nblk, (long)M, C,
+  hipLaunchKernelGGL((bn_rows_final_kernel<1>), dim3((unsigned)ceil_div(C, 16)), dim3(256), 0, st, (const float*)ws, nblk, (long)M, C,
                      0.0f, dbeta, dgamma);
   const long nb = ((long)M * C + 255) / 256;
   hipLaunchKernelGGL((bn_rows_apply_kernel<1>), dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, st, x, dy, mean, invstd, gamma,
@@ -1164,6 +1186,18 @@ int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, in
   const long nb = (rows + 255) / 256;
   hipLaunchKernelGGL((l2norm_rows_kernel<true>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x, g,
                      (long)rows, D, eps, dx);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_l2norm_rows_grad_y_f32(const float* y, const float* inv_norm, const float* g, int64_t rows, int D, float eps, float* dx,
+                                  void* stream) {
+  if (!y || !inv_norm || !g || !dx || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
+  if (!aligned16(y) || !aligned16(g) || !aligned16(dx)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  const long nb = (rows + 255) / 256;
+  hipLaunchKernelGGL(l2norm_rows_grad_y_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, y,
+                     inv_norm, g, (long)rows, D, eps, dx);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

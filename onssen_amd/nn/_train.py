@@ -102,22 +102,29 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
         lib.x3_image_both(dp2.data_ptr(), 2 * NP, 2 * NP, TB, a_rows.data_ptr(), a_t.data_ptr(), st)
     else:
         lib.x3_image_t(dp2.data_ptr(), 2 * NP, 2 * NP, TB, 0, a_t.data_ptr(), st)
-    w1 = torch.empty(2, N1, KB, 2, 32, device=dev, dtype=torch.int16)           # per direction: [x | h of the step before]
     y2 = y.view(TB, 2 * Hp)
-    for d in range(2):
-        lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1[d].data_ptr(), st)
-        # the forward direction looks B rows back, the reverse direction B rows ahead
-        lib.x3_image_t(y2[:, d * Hp:].data_ptr(), 2 * Hp, Hp, TB, -B if d == 0 else B, w1[d, Kx:].data_ptr(), st)
     zero_bias = _zeros(max(N1, wih_p.shape[2]), dev)                      # (read-only operand of the GEMMs)
     # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
     direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
     if direct:
+        # ONE image of the layer input for both directions: rows [h_prev forward | x | h_prev reverse], direction 0 contracts
+        # with rows [0, Hp + Kx), direction 1 with rows [Hp, Hp + Kx + Hp) -- overlapping windows, the outputs alternate
+        # (the forward direction looks B rows back, the reverse direction B rows ahead)
+        w1 = torch.empty(Hp + Kx + Hp, KB, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_t(y2.data_ptr(), 2 * Hp, Hp, TB, -B, w1.data_ptr(), st)
+        lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1[Hp:].data_ptr(), st)
+        lib.x3_image_t(y2[:, Hp:].data_ptr(), 2 * Hp, Hp, TB, B, w1[Hp + Kx:].data_ptr(), st)
         dW_ih2 = torch.empty(2, 4 * H, Kx, device=dev, dtype=torch.float32)
         dW_hh2 = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
         # packed row m = 4u + gate -> row gate*H + u: R = 4, unit stride ld, gate stride H*ld
-        lib.linear_x3p_batched_split(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1, 4,
-                                     dW_ih2.data_ptr(), 4 * H * Kx, Kx, H * Kx, Kx, dW_hh2.data_ptr(), 4 * H * H, H, H * H, 2, st)
+        lib.linear_x3p_batched_split_alt(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), Hp * KB * 64, zero_bias.data_ptr(), N1, 4,
+                                         dW_hh2.data_ptr(), 4 * H * H, H, H * H, Hp, dW_ih2.data_ptr(), 4 * H * Kx, Kx, H * Kx, Kx,
+                                         2, st)
     else:
+        w1 = torch.empty(2, N1, KB, 2, 32, device=dev, dtype=torch.int16)           # per direction: [x | h of the step before]
+        for d in range(2):
+            lib.x3_image_t(xp.data_ptr(), xp.stride(0), Kx, TB, 0, w1[d].data_ptr(), st)
+            lib.x3_image_t(y2[:, d * Hp:].data_ptr(), 2 * Hp, Hp, TB, -B if d == 0 else B, w1[d, Kx:].data_ptr(), st)
         out1 = torch.empty(2, NP, N1, device=dev, dtype=torch.float32)
         lib.linear_x3p_batched(a_t.data_ptr(), NP * KB * 64, NP, TB, w1.data_ptr(), N1 * KB * 64, zero_bias.data_ptr(), N1,
                                out1.data_ptr(), NP * N1, N1, 2, st)
@@ -137,10 +144,11 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     else:      # padded [fwd(Hp) | rev(Hp)] -> the reference's [fwd(H) | rev(H)]
         feat = _const(("feat", H, Hp, str(dev)), lambda: torch.cat([torch.arange(H, device=dev), Hp + torch.arange(H, device=dev)]))
     grads = []
+    if direct:      # b_ih and b_hh of both directions receive the same sums: ONE gather into four rows (no clones)
+        idx4 = _const(("cols4", H, Hp, ug, NP, str(dev)), lambda: torch.cat([cols, cols, cols + NP, cols + NP]))
+        db4 = db2[idx4].view(4, 4 * H)
+        return dx, [(dW_ih2[d], dW_hh2[d], db4[2 * d], db4[2 * d + 1]) for d in range(2)]
     for d in range(2):
-        if direct:
-            grads.append((dW_ih2[d], dW_hh2[d], db2[cols_d[d]]))
-            continue
         rows = out1[d].index_select(0, cols)                                     # (4H, N1) in nn.LSTM row order
         dW_ih = rows[:, :Kx] if feat is None else rows[:, :Kx].index_select(1, feat)
         dW_hh = rows[:, Kx:Kx + H]
@@ -269,7 +277,8 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 dx_rows, g = layer_gradients(gates, x_rows, y, w_ih, H, ug)
             for d in range(2):
                 o = (2 * l + d) * 4
-                grads[o], grads[o + 1], grads[o + 2], grads[o + 3] = g[d][0], g[d][1], g[d][2], g[d][2].clone()
+                grads[o], grads[o + 1], grads[o + 2] = g[d][0], g[d][1], g[d][2]
+                grads[o + 3] = g[d][3] if len(g[d]) > 3 else g[d][2].clone()
             if LAYER_GRAD_REDUCER[0] is not None:     # data parallel: this layer's exchange runs under the layers below
                 LAYER_GRAD_REDUCER[0].layer_hook(grads[(2 * l) * 4:(2 * l + 2) * 4], flat[(2 * l) * 4:(2 * l + 2) * 4])
             if l > 0:
@@ -384,6 +393,52 @@ def l2_normalize(x, eps=1e-12):
     if x.is_cuda and x.dtype == torch.float32 and D % 4 == 0 and D <= 64 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
         return _L2NormRows.apply(x, eps)
     return Fn.normalize(x, p=2, dim=-1, eps=eps)
+
+
+class LinearNormalizeFunction(torch.autograd.Function):
+    """``F.normalize(F.linear(x, W, b).reshape(..., D), dim=-1)`` of the embedding head (onssen/nn/deep_clustering.py:39-41) in ONE
+    GEMM: its epilogue normalises each bin's D features and leaves 1 / max(||.||, eps) per bin (onssen_linear_x3p_norms), the
+    backward of the normalisation works from those (onssen_l2norm_rows_grad_y_f32) -- the raw product is never written, the
+    separate normalisation pass of the forward is gone."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, D, eps):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x2d = x.reshape(-1, x.shape[-1]).contiguous()
+        w = weight.detach().contiguous()
+        M, K = x2d.shape
+        N = w.shape[0]
+        e = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        inv = torch.empty(M, N // D, device=x.device, dtype=torch.float32)
+        a, wi = _x3_image(lib, st, x2d), _x3_image(lib, st, w)
+        lib.linear_x3p_norms(a.data_ptr(), M, K, wi.data_ptr(), bias.detach().contiguous().data_ptr(), N, D, eps, e.data_ptr(),
+                             inv.data_ptr(), st)
+        ctx.save_for_backward(x2d, w, e, inv)
+        ctx.dims = (x.shape, D, eps)
+        return e.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib, st = get_lib(), torch.cuda.current_stream().cuda_stream
+        x2d, w, e, inv = ctx.saved_tensors
+        xshape, D, eps = ctx.dims
+        g2 = g.float().reshape(e.shape).contiguous()
+        d_raw = torch.empty_like(e)
+        lib.l2norm_rows_grad_y(e.data_ptr(), inv.data_ptr(), g2.data_ptr(), e.numel() // D, D, eps, d_raw.data_ptr(), st)
+        dx, dW, db = linear_x3_backward(lib, st, d_raw, x2d, w, ctx.needs_input_grad[0])
+        return (dx.view(xshape) if dx is not None else None), dW, db, None, None
+
+
+def head_linear_normalized(lin, x, D, eps=1e-12):
+    """``F.normalize(lin(x).reshape(..., D), p=2, dim=-1, eps)`` flattened back to lin's output shape: one GEMM with the
+    normalising epilogue in a training forward on a ROCm device, else head_linear + l2_normalize."""
+    N = lin.out_features
+    if (x.is_cuda and x.dtype == torch.float32 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" and D % 4 == 0 and 80 % D == 0
+            and 80 // D <= 4 and N % D == 0 and os.environ.get("ONSSEN_TRAIN_FUSED_NORM", "1") == "1"):
+        return LinearNormalizeFunction.apply(x, lin.weight, lin.bias, D, eps)
+    y = head_linear(lin, x)
+    return l2_normalize(y.reshape(*y.shape[:-1], N // D, D), eps).reshape(y.shape)
 
 
 class _BnRowsTrain(torch.autograd.Function):

@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._train import head_linear, l2_normalize
+from ._train import head_linear, head_linear_normalized
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
                     as_frames, heads_take_image, require_device, run_blstm, run_head, run_head_pair, use_hip_path)
 
@@ -62,6 +62,6 @@ class chimera(PackedWeightsMixin, nn.Module):
     def _autograd_forward(self, x):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
-        e = l2_normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1)).reshape(B, T, Fq, -1)
+        e = head_linear_normalized(self.fc_dc, r, self.embedding_dim).reshape(B, T, Fq, -1)
         m = torch.sigmoid(head_linear(self.fc_mi, r)).reshape(B, T, Fq, -1)
         return [e, m[:, :, :, 0], m[:, :, :, 1]]

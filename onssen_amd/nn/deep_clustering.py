@@ -2,7 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._train import batch_norm_rows, head_linear, l2_normalize
+from ._train import batch_norm_rows, head_linear_normalized
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     as_frames, heads_take_image, require_device, run_blstm, run_head, use_hip_path)
 
@@ -52,5 +52,5 @@ class deep_clustering(PackedWeightsMixin, nn.Module):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)
         r = batch_norm_rows(self.bn, r)
-        e = l2_normalize(head_linear(self.fc_dc, r).reshape(B, T * Fq, -1))
+        e = head_linear_normalized(self.fc_dc, r, self.embedding_dim)
         return e.reshape(B, T, Fq, -1)

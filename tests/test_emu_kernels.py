@@ -634,7 +634,8 @@ def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
-@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4)])     # the last one: D + C = 34, two tasks per thread
+# (1, 300, 30, 4): D + C = 34 > 32 -- the LDS form, two tasks per thread; the others: the MFMA form (9000 bins: several strips per wave)
+@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4), (2, 9000, 20, 2), (1, 515, 28, 4)])
 def test_loss_dc_value(lib, B, TF, D, C):
     """onssen_loss_dc_f32 against the NumPy restatement of loss_dc (Frobenius norms of the weighted affinity blocks)."""
     rng = np.random.default_rng(5)
@@ -1017,6 +1018,76 @@ def test_l2norm_rows_forward_and_gradient(lib, rows, D):
     ok = np.arange(rows) != 3
     np.testing.assert_allclose(dx[ok], xt.grad.numpy()[ok], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(dx[3], g[3] / np.float32(1e-12), rtol=1e-6)
+
+
+def test_batched_gemm_with_two_outputs_and_overlapping_windows(lib):
+    """onssen_linear_x3p_batched_split and _alt (the weight-gradient GEMMs of both directions in one launch): rows mapped
+    4u + gate -> gate*H + u into two dense outputs; _alt: the problems read overlapping windows of ONE operand image
+    [h_f | x | h_r] and their outputs change places."""
+    rng = np.random.default_rng(31)
+    H, Kx, TB = 12, 40, 70
+    NP, N1 = 4 * H, Kx + H
+    KB = (TB + 31) // 32
+    dP = rand(rng, 2, NP, TB)                          # per direction: rows of the transposed pre-activation gradient
+    hf, hr, x = rand(rng, H, TB), rand(rng, H, TB), rand(rng, Kx, TB)
+    img = lambda m: (lambda o: (lib.x3_image(P(m), m.shape[1], 0, 1, m.shape[0], m.shape[1], P(o), None), o)[1])(
+        np.zeros((m.shape[0], KB, 2, 32), np.uint16))
+    a = np.stack([img(np.ascontiguousarray(dP[0])), img(np.ascontiguousarray(dP[1]))])
+    zero = np.zeros(N1, np.float32)
+    to_lstm = lambda m: m.reshape(H, 4, -1).transpose(1, 0, 2).reshape(4 * H, -1)      # packed row 4u + gate -> gate*H + u
+    ref_ih = [to_lstm(dP[d].astype(np.float64) @ x.T.astype(np.float64)) for d in range(2)]
+    ref_hh = [to_lstm(dP[d].astype(np.float64) @ (hf, hr)[d].T.astype(np.float64)) for d in range(2)]
+    # plain: per direction [x | h_d]
+    w = np.stack([img(np.concatenate([x, hf])), img(np.concatenate([x, hr]))])
+    ih, hh = np.full((2, 4 * H, Kx), np.nan, np.float32), np.full((2, 4 * H, H), np.nan, np.float32)
+    lib.linear_x3p_batched_split(P(a), NP * KB * 64, NP, TB, P(w), N1 * KB * 64, P(zero), N1, 4, P(ih), 4 * H * Kx, Kx, H * Kx, Kx,
+                                 P(hh), 4 * H * H, H, H * H, 2, None)
+    for d in range(2):
+        np.testing.assert_allclose(ih[d], ref_ih[d], atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(hh[d], ref_hh[d], atol=2e-4, rtol=1e-4)
+    # alternating: one image [h_f | x | h_r], windows H rows apart
+    w1 = img(np.concatenate([hf, x, hr]))
+    ih2, hh2 = np.full((2, 4 * H, Kx), np.nan, np.float32), np.full((2, 4 * H, H), np.nan, np.float32)
+    lib.linear_x3p_batched_split_alt(P(a), NP * KB * 64, NP, TB, P(w1), H * KB * 64, P(zero), N1, 4, P(hh2), 4 * H * H, H, H * H, H,
+                                     P(ih2), 4 * H * Kx, Kx, H * Kx, Kx, 2, None)
+    np.testing.assert_array_equal(ih2, ih)
+    np.testing.assert_array_equal(hh2, hh)
+
+
+@pytest.mark.parametrize("M,tile", [(273, "256"), (150, "128")])
+def test_embedding_head_with_norms_and_its_backward(lib, M, tile, monkeypatch):
+    """onssen_linear_x3p_norms (fc_dc + F.normalize in one GEMM that also leaves 1 / max(||.||, eps) per bin) and
+    onssen_l2norm_rows_grad_y_f32 (the normalisation's backward from its output) against F.normalize(F.linear(.)) under float64
+    autograd; a bin whose raw product is exactly zero takes the clamped branch (dx = g / eps)."""
+    import torch
+    monkeypatch.setenv("ONSSEN_X3Q_BM", tile)
+    rng = np.random.default_rng(21)
+    K, D, N = 75, 20, 440
+    x, W, bias, g = rand(rng, M, K), rand(rng, N, K), rand(rng, N), rand(rng, M, N)
+    W[40:60] = 0.0; bias[40:60] = 0.0                          # bin 2 of every row: raw product 0
+    KB = (K + 31) // 32
+    a_img, w_img = np.zeros((M, KB, 2, 32), np.uint16), np.zeros((N, KB, 2, 32), np.uint16)
+    lib.x3_image(P(x), K, 0, 1, M, K, P(a_img), None)
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    e, inv = np.full((M, N), np.nan, np.float32), np.full((M, N // D), np.nan, np.float32)
+    lib.linear_x3p_norms(P(a_img), M, K, P(w_img), P(bias), N, D, 1e-12, P(e), P(inv), None)
+    xt = torch.from_numpy(x).double()
+    raw = (xt @ torch.from_numpy(W).double().t() + torch.from_numpy(bias).double()).reshape(M, N // D, D).requires_grad_(True)
+    et = torch.nn.functional.normalize(raw, p=2, dim=-1, eps=1e-12)
+    (et * torch.from_numpy(g).double().reshape(M, N // D, D)).sum().backward()
+    nrm = raw.detach().norm(dim=-1).numpy()
+    ok = np.ones(N // D, bool); ok[2] = False
+    err = np.abs(e.reshape(M, N // D, D) - et.detach().numpy()) * np.maximum(nrm, 1e-12)[..., None]
+    assert not np.isnan(e).any() and err.max() <= 3e-4
+    np.testing.assert_allclose(inv[:, ok], 1.0 / nrm[:, ok], rtol=3e-4)
+    assert np.all(inv[:, 2] == np.float32(1e12)) and not e[:, 40:60].any()
+    d_raw = np.full((M, N), np.nan, np.float32)
+    lib.l2norm_rows_grad_y(P(e), P(inv), P(g), M * (N // D), D, 1e-12, P(d_raw), None)
+    d = d_raw.reshape(M, N // D, D)
+    ref = raw.grad.numpy()
+    # (a short vector's gradient is large and as uncertain as its direction: error relative to 1 / ||x||)
+    np.testing.assert_allclose(d[:, ok] * nrm[:, ok, None], ref[:, ok] * nrm[:, ok, None], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(d[:, 2], g.reshape(M, N // D, D)[:, 2] * np.float32(1e12), rtol=1e-6)
 
 
 @pytest.mark.parametrize("M,C", [(300, 40), (129, 7)])

@@ -35,5 +35,9 @@ find gpurun_out/prof_train -name "*kernel_trace.csv" -delete
 timeout 300 python tools/eval_probe.py 2>&1 | grep -v Warning | grep "batch" | tee gpurun_out/eval_probe.txt
 HEAVY=1 timeout 200 python tools/cotenant_probe.py > gpurun_out/cotenant_probe.txt 2>/dev/null; tail -12 gpurun_out/cotenant_probe.txt
 timeout 100 python tools/cluster_probe.py 2>/dev/null | head -3 | cut -c1-200 | tee gpurun_out/cluster_probe.txt
+timeout 200 python tools/wide_layer_probe.py 2>/dev/null | tail -1 | tee gpurun_out/wide_probe.json
+rm -rf gpurun_out/prof_wide; cd /tmp; WIDE_ONLY=768 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_wide -- python $GRAFT_REPO_ROOT/tools/wide_layer_probe.py > $GRAFT_REPO_ROOT/gpurun_out/prof_wide.log 2>&1 < /dev/null; cd $GRAFT_REPO_ROOT
+f=$(find gpurun_out/prof_wide -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then head -6 $f | cut -c1-160 | tee gpurun_out/wide_kernel_stats.txt; fi
+find gpurun_out/prof_wide -name "*kernel_trace.csv" -delete
 bash tools/profile_round.sh $tag > gpurun_out/profile_round.log 2>&1
 head -9 gpurun_out/prof_$tag/kernel_stats.csv | cut -c1-170

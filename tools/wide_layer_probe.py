@@ -8,11 +8,12 @@ from onssen_amd import nn as onn
 
 dev = torch.device("cuda:0")
 out = {}
-for H in (600, 640, 704, 768):
+only = os.environ.get("WIDE_ONLY")        # e.g. WIDE_ONLY=768 under rocprofv3: that width on the persistent form only
+for H in ((int(only),) if only else (600, 640, 704, 768)):
     torch.manual_seed(H)
     m = onn.deep_clustering(129, H, 2, 20).to(dev).eval()
     x = torch.randn(32, 400, 129, device=dev)
-    for xcd in ("1", "0"):
+    for xcd in (("1",) if only else ("1", "0")):
         os.environ["ONSSEN_XCD"] = xcd
         with torch.no_grad():
             for _ in range(3):
