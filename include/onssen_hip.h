@@ -285,11 +285,11 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
  *   operands as onssen_blstm_forward_f32 with L = 1: wih_img = x3 image of the packed [2*NP][in_dim] projection,
  *   whh_x3 = the two directions' onssen_lstm_pack_whh_bf16x3 images, bias_p [2*NP]; ws as for L = 1).  Besides
  *   y [T][B][2][Hp] it leaves gates [T][B][2][NP] = the activations (i, f, g, o) of every unit in the packed column
- *   layout of G (column = ugi*4*ug + ju*4 + gate) and cs [T][B][2][Hp] = the cell states c_t.
+ *   layout of G (column = ugi*4*ug + ju*4 + gate) and cs [T][B][2][Hp] = the cell states c_t.  H <= 768 (ug = 24 above 640).
  * onssen_lstm_train_backward_f32: given dy [T][B][2][Hp] = dL/dy (padded units 0), overwrites `gates_dp` in place with
  *   dL/d(pre-activation) (same layout) -- the operand of the weight / input gradient GEMMs:
  *     dW_ih(packed) = dP^T x,  dW_hh(packed, per direction) = dP_d^T h_prev,  db = sum_rows dP,  dx = dP W_ih(packed).
- *   form ONSSEN_LSTM_BWD_XCD (default of the Python layer): ONE persistent launch per layer, every (direction, row
+ *   form ONSSEN_LSTM_BWD_XCD (default of the Python layer; H <= 640): ONE persistent launch per layer, every (direction, row
  *     group) inside one XCD like the forward; each member keeps the rows of W_hh of its own gate columns in registers,
  *     multiplies them with the dP it has just produced and the members reduce-scatter fp32 partial sums of dh through
  *     the XCD's L2.  whh_img = the two directions' onssen_lstm_pack_whhR_bf16x3 images (onssen_lstm_whhR_elems uint16

@@ -900,7 +900,7 @@ static int blstm_forward_impl(const float* x, int64_t xs_b, int64_t xs_t, int B,
       // split-bf16: H <= 768 (ug = 24: 32 members of 24 units = every CU of an XCD; round 4), exact fp32 and the forms that fuse
       // the first layer / save state: H <= 640 (ug <= 20)
       if (ug > 24 || Hp / ug > 32 || KQ2 > 24 || (!x3 && (save_g || save_c))) return ONSSEN_E_ARG;
-      if (ug > 20 && (!x3 || fuse0 || save_g || save_c || (flags & ONSSEN_BLSTM_BF16))) return ONSSEN_E_ARG;
+      if (ug > 20 && (!x3 || fuse0 || (flags & ONSSEN_BLSTM_BF16))) return ONSSEN_E_ARG;
       // bounded waits: ~0.2 s of polling on the GPU; ONSSEN_XCD_SPIN_LIMIT overrides (the host-side emulation, where a
       // 'workgroup' is a process at the mercy of the OS scheduler, raises it)
       const unsigned xcd_spin = xcd_spin_limit();

@@ -303,15 +303,15 @@ class BLSTMParams(nn.Module):
 
     def autograd_forward(self, x, training):
         """Training path (needs autograd).  On a ROCm device: ALWAYS the HIP kernels (nn/_train.py) -- the
-        persistent forward with saved state + the persistent backward recurrence where they apply (H <= 640, no abort
+        persistent forward with saved state (H <= 768) + the persistent backward recurrence (H <= 640) where they apply (no abort
         back-off in force), otherwise the launch-per-step forward with saved state (split-bf16 up to H = 640, exact fp32
         above) + the launch-per-step backward: the re-run of a training step whose persistent launch aborted and wide layers
         stay inside the library (round 4; rounds 1-3 fell back to the stock ATen / MIOpen LSTM there).  A CPU tensor takes
         ATen's LSTM (gloo tests, CPU-only debugging): there is no HIP device to run on."""
         if x.is_cuda:
             from ._train import BLSTMTrainFunction
-            persistent = (self.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed())
-            if self.hidden_size <= 640 and os.environ.get("ONSSEN_XCD", "1") == "1":
+            persistent = (self.hidden_size <= 768 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed())
+            if self.hidden_size <= 768 and os.environ.get("ONSSEN_XCD", "1") == "1":
                 _XcdPolicy.note_launch(persistent)
             if getattr(self, "_train_packed", None) is None:
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))

@@ -181,16 +181,17 @@ class BLSTMTrainFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, packed, p_drop, persistent, *flat):
-        """``persistent``: the XCD-local persistent kernels (H <= 640); otherwise the launch-per-step forms of the same
-        recurrences -- split-bf16 up to H = 640, exact-fp32 forward above -- with the same saved state and gradient GEMMs."""
+        """``persistent``: the XCD-local persistent kernels (forward with saved state: H <= 768; backward: H <= 640, wider
+        layers take the launch-per-step backward behind the persistent forward); otherwise the launch-per-step forms of the
+        same recurrences -- split-bf16 up to H = 640, exact-fp32 forward above -- with the same saved state and gradient GEMMs."""
         lib = get_lib()
         prm = packed.p
         H, L = prm.hidden_size, prm.num_layers
         B, T, In = x.shape
-        if persistent and H > 640:
-            raise RuntimeError("HIP training path: the persistent recurrences hold H <= 640")
+        if persistent and H > 768:
+            raise RuntimeError("HIP training path: the persistent forward recurrence holds H <= 768")
         ug = 4 * -(-H // 128) if persistent else int(os.environ.get("ONSSEN_UG", "8"))
-        x3 = H <= 640
+        x3 = H <= 640 or persistent
         fwd_flags = (_abi.BLSTM_XCD | _abi.BLSTM_BF16X3) if persistent else _abi.BLSTM_BF16X3 if x3 else 0
         _XcdStatus.poll()
         pk = packed.get(ug)
@@ -252,7 +253,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
         dy = dy_bt.transpose(0, 1).reshape(T, B, 2, H)
         dy = Fn.pad(dy, (0, Hp - H)).contiguous() if Hp != H else dy.contiguous()
         # the persistent backward launch where the forward was persistent (ONSSEN_BWD_XCD=0: one launch per time step anyway)
-        form = _abi.LSTM_BWD_XCD if ctx.persistent and os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
+        form = _abi.LSTM_BWD_XCD if ctx.persistent and H <= 640 and os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
         wsb = _Workspace.get(("bwd", B, H, form, ug), lib.lstm_train_backward_workspace_bytes(B, H, ug, form), dev, zero=True)
         whh_img = pk.whh_bwd(form)
         grads = [None] * (8 * L)

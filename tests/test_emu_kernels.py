@@ -794,7 +794,9 @@ _TRAIN_CASES = [(H, ug, B, T, _abi.LSTM_BWD_XCD, "0") for H, ug, B, T in
                [(24, 8, 18, 3, _abi.LSTM_BWD_XCD, "1"), (8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0")]
 _TRAIN_CASES = [c + ("xcd",) for c in _TRAIN_CASES] + \
                [(8, 4, 3, 5, _abi.LSTM_BWD_STEPS, "0", "steps_x3"), (24, 8, 18, 3, _abi.LSTM_BWD_STEPS, "0", "steps_f32"),
-                (12, 8, 20, 4, _abi.LSTM_BWD_STEPS, "0", "steps_x3")]
+                (12, 8, 20, 4, _abi.LSTM_BWD_STEPS, "0", "steps_x3"),
+                # 24-unit members (640 < H <= 768 on the device): persistent forward with saved state, launch-per-step backward
+                (48, 24, 5, 4, _abi.LSTM_BWD_STEPS, "0", "xcd"), (40, 24, 18, 3, _abi.LSTM_BWD_STEPS, "0", "xcd")]
 
 
 @pytest.mark.parametrize("H,ug,B,T,form,scramble,fwd", _TRAIN_CASES)

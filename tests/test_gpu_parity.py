@@ -995,7 +995,9 @@ def test_blstm_training_gradients_match_autograd(dev, monkeypatch, B, T, F, H, L
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,F,H,L,forced", [(3, 12, 40, 768, 2, False),      # H > 640: exact-fp32 launch-per-step forward + launch-per-step backward
+@pytest.mark.parametrize("B,T,F,H,L,forced", [(3, 12, 40, 800, 2, False),      # H > 768: exact-fp32 launch-per-step forward + launch-per-step backward
+                                              (5, 30, 40, 768, 2, False),      # 640 < H <= 768: persistent forward (24-unit members) + launch-per-step backward
+                                              (18, 9, 33, 700, 1, False),
                                               (5, 20, 129, 600, 2, True),      # H <= 640 inside forced_steps(): what an aborted step is re-run on
                                               (18, 9, 33, 128, 1, True)])
 def test_training_without_the_persistent_kernels_stays_on_hip(dev, monkeypatch, B, T, F, H, L, forced):
@@ -1024,7 +1026,10 @@ def test_training_without_the_persistent_kernels_stays_on_hip(dev, monkeypatch, 
         yg = rnn.autograd_forward(xg, True)
         (yg * R.float().to(dev)).sum().backward()
     torch.cuda.synchronize()
-    assert _XcdPolicy.persistent_launches == n_p
+    if 640 < H <= 768 and not forced:
+        assert _XcdPolicy.persistent_launches > n_p          # the forward with saved state ran on the persistent kernel
+    else:
+        assert _XcdPolicy.persistent_launches == n_p
     assert (yg.detach().cpu().double() - yr.detach()).abs().max() < 2e-5
     bad = []
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--hidden", type=int, default=600, help="BLSTM width (640 < H <= 768: persistent forward + launch-per-step backward)")
     ap.add_argument("--dropout", type=float, default=0.3, help="nn.LSTM inter-layer dropout (0 makes the HIP and ATen paths comparable step for step)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -35,7 +36,7 @@ def main():
     from onssen_amd.loss import loss_dc
     fo = dict(batch_size=16, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
     torch.manual_seed(0)
-    model = onn.deep_clustering(129, 600, args.layers, 20, dropout=args.dropout).to(dev).train()
+    model = onn.deep_clustering(129, args.hidden, args.layers, 20, dropout=args.dropout).to(dev).train()
     from onssen_amd.utils import build_optimizer
     opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})      # egs/*/config.json: adam, 1e-3
     loader = wsj0_2mix_dataloader("dc", fo, "tr", device=str(dev))
@@ -78,7 +79,7 @@ def main():
                                     if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "f32 (ATen / MIOpen autograd path)"),
                           "blstm_path": "hip" if os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" else "aten",
                           "data": "synthetic", "last_loss": loss,
-                          "config": {"workload": f"deep_clustering {args.layers}xBLSTM-600 training, 16 x 400-frame chunks per GPU, features + labels from the HIP front end",
+                          "config": {"workload": f"deep_clustering {args.layers}xBLSTM-{args.hidden} training, 16 x 400-frame chunks per GPU, features + labels from the HIP front end",
                                      "parallelism": f"data parallel x{world}, RCCL all-reduce of per-layer gradient buckets before clipping"}}))
     if world > 1:
         dist.destroy_process_group()
