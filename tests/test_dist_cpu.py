@@ -208,7 +208,7 @@ def test_loss_dc_gram_form_equals_the_literal_form():
 def test_two_process_bench_selftest_record():
     """bench.py with WORLD_SIZE = 2 has run on hardware (two processes on ONE MI355X, ONSSEN_BENCH_ONE_DEVICE=1, gloo for the
     harness' barrier / gathers, launch-per-step kernels so that two processes' persistent launches do not starve each other:
-    tools/gpu_r4b.sh).  The committed record must be what the driver's N > 1 contract asks for: one JSON line from rank 0, the
+    tools/gpu_two_process_selftest.sh).  The committed record must be what the driver's N > 1 contract asks for: one JSON line from rank 0, the
     whole-job value over both ranks, every rank's own step time, the roofline block."""
     import json
     import os
