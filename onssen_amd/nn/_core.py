@@ -55,8 +55,8 @@ class _XcdPolicy:
     longer than the bounded wait, two persistent launches overlapped, ...): the abort is *per launch*, not a property of
     the process, so the persistent form stays enabled --
 
-      * the call that aborted is re-run by its owner inside ``forced_steps()`` (launch-per-step recurrence for
-        inference, the ATen LSTM for training), see ``recovering``;
+      * the call that aborted is re-run by its owner inside ``forced_steps()`` (the launch-per-step recurrences, inference
+        and training alike), see ``recovering``;
       * the next call tries the persistent form again; only consecutive aborts back off: after the k-th abort in a row
         the next 2^(k-1) - 1 BLSTM launches (at most 63) skip it, a persistent launch that completes resets the streak.
     Counters are for tests / bench output."""
@@ -154,6 +154,44 @@ def recurrence_plan(B, H):
     if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
         flags |= _abi.BLSTM_SPLIT_ROWS
     return int(os.environ.get("ONSSEN_UG", "8")), flags
+
+
+class _XcdSerial:
+    """ONSSEN_XCD_SERIALIZE=1 (opt-in): one persistent launch in flight per device.  The persistent kernels' members spin on
+    each other and need their whole exchange group resident; two of them issued on DIFFERENT streams of one process can be
+    dispatched interleaved, each holding CUs the other's groups need, until the bounded waits give up (both abort, both are
+    re-run: correct, but a 0.2 s latency spike).  With the switch on, every persistent launch records an event behind itself and
+    a persistent launch on another stream first makes its stream wait for it (stream-ordered on the device, no host
+    synchronisation).  Off by default because the hazard is rare and the overlap is worth having: exchange groups are
+    independent chains, a group that finds its XCD taken simply starts when the other kernel's group has finished
+    (`tools/two_stream_probe.py`: two models on two streams, 20 rounds: 39.5 ms unserialised with no abort, 51.5 ms serialised).
+    Not applied while a hipGraph is being captured.  Other PROCESSES on the same GPU are outside its reach: see _XcdPolicy /
+    INTEGRATION.md."""
+    last = {}                # device index -> (raw stream handle, event behind the last persistent launch)
+
+    @staticmethod
+    def enabled():
+        return os.environ.get("ONSSEN_XCD_SERIALIZE", "0") == "1"
+
+    @classmethod
+    def before(cls, device):
+        if not cls.enabled() or torch.cuda.is_current_stream_capturing():
+            return
+        rec = cls.last.get(device.index)
+        if rec is not None:
+            cur = torch.cuda.current_stream(device)
+            if rec[0] != cur.cuda_stream:
+                cur.wait_event(rec[1])
+
+    @classmethod
+    def after(cls, device):
+        if not cls.enabled() or torch.cuda.is_current_stream_capturing():
+            return
+        cur = torch.cuda.current_stream(device)
+        rec = cls.last.get(device.index)
+        ev = rec[1] if rec is not None else torch.cuda.Event()     # one event per device, re-recorded
+        ev.record(cur)
+        cls.last[device.index] = (cur.cuda_stream, ev)
 
 
 class _XcdStatus:
@@ -597,6 +635,8 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
         if pk.bias0_tail is not None:
             flags |= _abi.BLSTM_FUSE_TAIL
             bias = [pk.bias0_tail] + list(pk.bias[1:])
+    if flags & _abi.BLSTM_XCD:
+        _XcdSerial.before(x.device)
     lib.blstm_forward(x.data_ptr(), x.stride(0), x.stride(1), B, T, In, p.hidden_size, p.num_layers, pk.ug,
                       [t.data_ptr() for t in wih],
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
@@ -611,6 +651,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
         off, _ = lib.blstm_y_image(B, T, In, p.hidden_size, p.num_layers, pk.ug)
         y.x3_image = (wsb, off)                        # keeps the workspace alive with y
     if flags & _abi.BLSTM_XCD:
+        _XcdSerial.after(x.device)
         _XcdStatus.post(wsb)
         if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
             _XcdStatus.flush()

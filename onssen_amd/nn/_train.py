@@ -16,7 +16,7 @@ import torch.nn.functional as Fn
 
 from .. import _abi
 from ..hip import get_lib
-from ._core import _XcdStatus
+from ._core import _XcdSerial, _XcdStatus
 
 
 _CONST = {}       # small index / zero tensors that every backward pass needs again: built once per (shape, device)
@@ -212,10 +212,13 @@ class BLSTMTrainFunction(torch.autograd.Function):
             cs = torch.empty(T, B, 2, Hp, device=dev, dtype=torch.float32)
             wih = pk.wih_img[l] if persistent else pk.wih_x3[l] if x3 else pk.wih[l]
             whh = pk.whh_x3[l] if x3 else pk.whh[l]
+            if persistent:
+                _XcdSerial.before(dev)
             lib.lstm_train_forward_form(xin.data_ptr(), xs_b, xs_t, B, T, in_l, H, ug, wih.data_ptr(), whh.data_ptr(),
                                         pk.bias[l].data_ptr(), y.data_ptr(), gates.data_ptr(), cs.data_ptr(), ws.data_ptr(),
                                         ws.numel(), fwd_flags, st)
             if persistent:
+                _XcdSerial.after(dev)
                 _XcdStatus.post(ws)       # an aborted exchange is reported at the next poll (never silently)
             mask = None
             if l < L - 1:
@@ -265,9 +268,12 @@ class BLSTMTrainFunction(torch.autograd.Function):
             xp, y, gates, cs, mask = ctx.saved_layers[l]
             # the persistent kernel also leaves sum_t dP per batch row: the bias gradient without a pass over all of dP
             db_rows = torch.empty(B, 2 * NP, device=dev, dtype=torch.float32) if form == _abi.LSTM_BWD_XCD else None
+            if form == _abi.LSTM_BWD_XCD:
+                _XcdSerial.before(dev)
             lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
                                     wsb.data_ptr(), wsb.numel(), form, st, db_rows.data_ptr() if db_rows is not None else None)
             if form == _abi.LSTM_BWD_XCD:
+                _XcdSerial.after(dev)
                 _XcdStatus.post(wsb)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if use_x3:

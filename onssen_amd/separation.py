@@ -75,7 +75,7 @@ def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=No
     computes the embedding and calls ``dc_masks``."""
     import os
     from .hip import get_lib
-    from .nn._core import (_XcdPolicy, _XcdStatus, _stream, as_frames, heads_take_image, precision, run_blstm, use_hip_path)
+    from .nn._core import (_XcdPolicy, _XcdSerial, _XcdStatus, _stream, as_frames, heads_take_image, precision, run_blstm, use_hip_path)
     from .nn.deep_clustering import deep_clustering
     B, T, F = logmag.shape
     D = getattr(model, "embedding_dim", 0)
@@ -103,7 +103,9 @@ def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=No
     lib.linear_x3p_compact(wsb.data_ptr() + off, T * B, 2 * Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
                            ws.data_ptr() + dest_off, T * F, F, ws.data_ptr() + comp_off, B, T * F * D, precision() == "bf16", st)
     masks = torch.empty(B, T, F, 2, device=logmag.device, dtype=torch.float32)
+    _XcdSerial.before(logmag.device)            # the persistent Lloyd launch wants its workgroups resident together too
     lib.dc_cluster_compact(B, T, F, D, iters, masks.data_ptr(), ws.data_ptr(), nb, st, tol=float(tol))
+    _XcdSerial.after(logmag.device)
     _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
 
@@ -125,7 +127,7 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None, tol=1e-4):
     import os
     from . import _abi
     from .hip import get_lib
-    from .nn._core import _XcdPolicy, _XcdStatus
+    from .nn._core import _XcdPolicy, _XcdSerial, _XcdStatus
     lib = get_lib()
     B, T, F, D = emb.shape
     emb, logmag = emb.contiguous(), logmag.contiguous()
@@ -136,11 +138,14 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None, tol=1e-4):
     if frames is not None:
         from .features import _lengths_i32
         frames = _lengths_i32(frames, B, T, emb.device, "frames")
+    if persistent:
+        _XcdSerial.before(emb.device)
     lib.dc_cluster(emb.data_ptr(), logmag.data_ptr(), B, T, F, D, float(db_threshold), iters, masks.data_ptr(),
                    ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream,
                    flags=0 if persistent else _abi.DC_CLUSTER_LAUNCH_PER_ITERATION,
                    frames=frames.data_ptr() if frames is not None else None, tol=float(tol))
     if persistent:
+        _XcdSerial.after(emb.device)
         _XcdStatus.post_cluster(ws, int(lib.dll.onssen_dc_cluster_status_offset(B, D)))
     return masks
 

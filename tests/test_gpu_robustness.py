@@ -369,3 +369,48 @@ def test_windowed_evaluation_loop_matches_per_utterance_and_survives_an_abort(de
     n_p = P.persistent_launches
     t.eval(window=16)
     assert P.persistent_launches > n_p and P.skip == 0
+
+
+@pytest.mark.parametrize("serialize", ["1", "0"])
+def test_persistent_launches_from_two_streams(dev, monkeypatch, serialize):
+    """Two models driven from two streams of one process, nothing synchronising in between.  ONSSEN_XCD_SERIALIZE=1: every
+    persistent launch waits (on the device) for the persistent launch issued before it on the other stream
+    (nn/_core._XcdSerial) -- the two never hold the XCDs side by side.  Default (0): they overlap; exchange groups are
+    independent chains, so a group whose XCD is taken starts when the other kernel's group has finished.  Either way each
+    stream's results are what a single stream gives."""
+    monkeypatch.setenv("ONSSEN_XCD_SERIALIZE", serialize)
+    from onssen_amd.features import stft_logmag
+    from onssen_amd.nn._core import _XcdPolicy, _XcdStatus
+    ma, mb = _dc(dev, H=600, L=2, seed=5), _dc(dev, H=300, L=3, seed=6)
+    wa = torch.from_numpy(np.stack([synth_mixture(900 + b, 25536) for b in range(8)]).astype(np.float32)).to(dev)
+    wb = torch.from_numpy(np.stack([synth_mixture(950 + b, 12800) for b in range(20)]).astype(np.float32)).to(dev)
+    with torch.no_grad():
+        xa, xb = stft_logmag(wa)[0], stft_logmag(wb)[0]
+        ref_a, ref_b = ma([xa])[0].clone(), mb([xb])[0].clone()
+    torch.cuda.synchronize()
+    _XcdStatus.flush()
+    aborts, n_p = _XcdPolicy.aborts, _XcdPolicy.persistent_launches
+    from onssen_amd.nn._core import XcdAborted
+    sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs_a, outs_b = [], []
+    try:
+        with torch.no_grad():
+            for _ in range(12):
+                with torch.cuda.stream(sa):
+                    outs_a.append(ma([xa])[0])
+                with torch.cuda.stream(sb):
+                    outs_b.append(mb([xb])[0])
+        torch.cuda.synchronize()
+        _XcdStatus.flush()
+    except XcdAborted:
+        # only without the serialisation: the dispatcher interleaved two launches into a circular wait and a bare model(x)
+        # reports that (separate_* / tester.eval / train_step would have re-run the call); nothing more to compare
+        assert serialize == "0"
+        _XcdPolicy.skip = 0
+        _XcdPolicy.streak = 0
+        return
+    assert _XcdPolicy.aborts == aborts and _XcdPolicy.persistent_launches >= n_p + 24
+    for o in outs_a:
+        assert torch.equal(o, ref_a)
+    for o in outs_b:
+        assert torch.equal(o, ref_b)
