@@ -1172,9 +1172,12 @@ int onssen_l2norm_rows_f32(const float* x, int64_t rows, int D, float eps, float
   if (!x || !y || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
   if (!aligned16(x) || !aligned16(y)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
-  const long nb = (rows + 255) / 256;
-  hipLaunchKernelGGL((l2norm_rows_kernel<false>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x,
-                     (const float*)nullptr, (long)rows, D, eps, y);
+  const int dq = D <= 20 ? 5 : D <= 32 ? 8 : 16;
+  const long nb = (rows + 4 * (64 / dq) - 1) / (4 * (64 / dq));      // 4 waves per workgroup, 64 / dq rows per wave and pass
+#define ONSSEN_L2N(DQ_) hipLaunchKernelGGL((l2norm_rows_kernel<false, DQ_>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x, \
+                                           (const float*)nullptr, (long)rows, D, eps, y)
+  if (dq == 5) ONSSEN_L2N(5); else if (dq == 8) ONSSEN_L2N(8); else ONSSEN_L2N(16);
+#undef ONSSEN_L2N
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -1183,9 +1186,12 @@ int onssen_l2norm_rows_grad_f32(const float* x, const float* g, int64_t rows, in
   if (!x || !g || !dx || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
   if (!aligned16(x) || !aligned16(g) || !aligned16(dx)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
-  const long nb = (rows + 255) / 256;
-  hipLaunchKernelGGL((l2norm_rows_kernel<true>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x, g,
-                     (long)rows, D, eps, dx);
+  const int dq = D <= 20 ? 5 : D <= 32 ? 8 : 16;
+  const long nb = (rows + 4 * (64 / dq) - 1) / (4 * (64 / dq));      // 4 waves per workgroup, 64 / dq rows per wave and pass
+#define ONSSEN_L2N(DQ_) hipLaunchKernelGGL((l2norm_rows_kernel<true, DQ_>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, x, g, \
+                                           (long)rows, D, eps, dx)
+  if (dq == 5) ONSSEN_L2N(5); else if (dq == 8) ONSSEN_L2N(8); else ONSSEN_L2N(16);
+#undef ONSSEN_L2N
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
@@ -1195,9 +1201,12 @@ int onssen_l2norm_rows_grad_y_f32(const float* y, const float* inv_norm, const f
   if (!y || !inv_norm || !g || !dx || rows <= 0 || D <= 0 || D > 64 || (D % 4) != 0 || !(eps > 0.0f)) return ONSSEN_E_ARG;
   if (!aligned16(y) || !aligned16(g) || !aligned16(dx)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
-  const long nb = (rows + 255) / 256;
-  hipLaunchKernelGGL(l2norm_rows_grad_y_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, y,
-                     inv_norm, g, (long)rows, D, eps, dx);
+  const int dq = D <= 20 ? 5 : D <= 32 ? 8 : 16;
+  const long nb = (rows + 4 * (64 / dq) - 1) / (4 * (64 / dq));      // 4 waves per workgroup, 64 / dq rows per wave and pass
+#define ONSSEN_L2N(DQ_) hipLaunchKernelGGL((l2norm_rows_grad_y_kernel<DQ_>), dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, (hipStream_t)stream, y, \
+                                           inv_norm, g, (long)rows, D, eps, dx)
+  if (dq == 5) ONSSEN_L2N(5); else if (dq == 8) ONSSEN_L2N(8); else ONSSEN_L2N(16);
+#undef ONSSEN_L2N
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }
