@@ -21,6 +21,7 @@ def load(name):
 for cfg, cls, tcls in (("config_dc.json", "deep_clustering", tester_dc), ("config_chimera_psa.json", "chimera", tester_chimera)):
     args = load(cfg)
     dev = torch.device("cuda:0")
+    torch.manual_seed(0)                           # (random-init weights: the SI-SDR printed is only a fingerprint of the run)
     args.model = getattr(onn, cls)(**args["model_options"]).to(dev)
     args.checkpoint_path = None
     args.test_loader = list(wsj0_2mix_dataloader(args.model_name, args.feature_options, "tt", dev)) * 4    # resident: the loop itself is what is timed
