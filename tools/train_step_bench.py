@@ -3,7 +3,8 @@
 all-reduce of the gradients, clip, Adam -- on synthetic wsj0-2mix batches whose features and labels come from the HIP
 front end (STFT + label kernels).  The BLSTM stack runs on the HIP training path (saved-state forward + backward
 recurrence, onssen_amd/nn/_train.py; ONSSEN_TRAIN_HIP=0 selects the stock ATen LSTM for comparison); BatchNorm, the
-embedding head and loss_dc run on ATen autograd.  One JSON line like bench.py.
+embedding head and loss_dc run on the package's HIP kernels behind autograd Functions, clipping and Adam on ATen.  One
+JSON line like bench.py.
 
     python tools/train_step_bench.py [--steps K --warmup W]            # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py --gpus N
