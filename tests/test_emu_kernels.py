@@ -415,7 +415,7 @@ def _shm(shape, fill=0.0, dtype=np.float32):
 
 # (more than 8 utterances per launch -- the second block of the workgroup -> utterance map -- run on the GPU at B = 32: forking
 #  9 x 8 workgroups of 512 threads takes the emulation a minute)
-@pytest.mark.parametrize("B,T,F,D,scramble", [(2, 20, 33, 20, "0"), (3, 9, 40, 12, "0"), (2, 20, 33, 20, "1")])
+@pytest.mark.parametrize("B,T,F,D,scramble", [(2, 20, 33, 20, "0"), (2, 9, 40, 12, "0"), (1, 20, 33, 20, "1")])
 def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
     """Default form of onssen_dc_cluster_f32: count + order-preserving compaction of the active bins, then ALL Lloyd
     iterations in one persistent launch whose 8 workgroups per utterance meet at a counter (forked workgroups over shared
@@ -430,7 +430,7 @@ def test_dc_cluster_persistent_lloyd(lib, monkeypatch, B, T, F, D, scramble):
     nb = lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D)
     ws = _shm((nb // 4 + 64,))
     masks = _shm((B, T, F, 2), fill=np.nan)
-    iters = 12
+    iters = 8
     lib.dc_cluster(P(emb), P(feat), B, T, F, D, 40.0, iters, P(masks), P(ws), nb, None)
     so = lib.dll.onssen_dc_cluster_status_offset(B, D)
     assert ws.view(np.uint32)[so // 4] == 0
@@ -634,8 +634,8 @@ def test_blstm_xcd_exact_fp32(lib, monkeypatch, H, ug, B, T, scramble):
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
-# (1, 300, 30, 4): D + C = 34 > 32 -- the LDS form, two tasks per thread; the others: the MFMA form (9000 bins: several strips per wave)
-@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4), (2, 9000, 20, 2), (1, 515, 28, 4)])
+# (1, 300, 30, 4): D + C = 34 > 32 -- the LDS form, two tasks per thread; the others: the MFMA form (4000 bins: several strips per wave)
+@pytest.mark.parametrize("B,TF,D,C", [(2, 150, 20, 2), (1, 700, 6, 3), (1, 300, 30, 4), (1, 4000, 20, 2), (1, 515, 28, 4)])
 def test_loss_dc_value(lib, B, TF, D, C):
     """onssen_loss_dc_f32 against the NumPy restatement of loss_dc (Frobenius norms of the weighted affinity blocks)."""
     rng = np.random.default_rng(5)
