@@ -47,7 +47,9 @@ def test_c_host_program_reproduces_separate_dc(dev, tmp_path, monkeypatch, B, n,
     from onssen_amd.separation import separate_dc
     from onssen_amd.synthetic import synth_mixture
     if not os.path.exists(EXE):
-        pytest.fail("examples/separate_dc is not built: run __graft_entry__.build()")
+        import __graft_entry__ as g          # (normally built beforehand; gcc and the library are on the GPU box too)
+        g.build()
+    assert os.path.exists(EXE), "examples/separate_dc is not built: run __graft_entry__.build()"
     monkeypatch.setenv("ONSSEN_FUSE_IN0", "0")          # the example runs the unfused launch sequence (the default up to 16 rows)
     torch.manual_seed(B + H)
     model = onn.deep_clustering(129, H, L, 20).to(dev).eval()
