@@ -28,7 +28,7 @@ for cfg in "1 3" "0 3" "1 2"; do
 import json; r=json.load(open('gpurun_out/train_hip${mode}_l$layers.json')); print('train_step dc_l$layers hip=$mode ms/step %.2f xRT %.0f loss %.2f' % (r['ms_per_step'], r['value'], r['last_loss']))" 2>&1 | tail -1
 done
 timeout 200 python tools/train_soak.py --steps 100 2>&1 < /dev/null | tail -1 | cut -c1-400 | tee gpurun_out/train_soak.txt
-timeout 200 python tools/xcd_soak.py 2>&1 < /dev/null | tail -2 | cut -c1-400 | tee gpurun_out/xcd_soak.txt
+timeout 300 python tools/xcd_soak.py 2>&1 < /dev/null | tail -4 | cut -c1-400 | tee gpurun_out/xcd_soak.txt
 cd /tmp; timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_train -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py --layers 3 --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_train.log 2>&1 < /dev/null; cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); if [ -n "$f" ]; then cp $f gpurun_out/train_kernel_stats.csv; fi
 find gpurun_out/prof_train -name "*kernel_trace.csv" -delete

@@ -8,7 +8,8 @@ from onssen_amd import nn as onn
 from onssen_amd.synthetic import make_state_dict
 dev = torch.device("cuda:0")
 N = int(os.environ.get("N", 1500))
-for kind, H, L, B, T in (("deep_clustering", 600, 2, 32, 400), ("chimera", 600, 4, 64, 400), ("deep_clustering", 300, 3, 33, 50)):
+for kind, H, L, B, T in (("deep_clustering", 600, 2, 32, 400), ("chimera", 600, 4, 64, 400), ("deep_clustering", 300, 3, 33, 50),
+                         ("deep_clustering", 768, 2, 32, 400)):          # (the last: 24-unit members, every CU of the XCDs)
     sd = make_state_dict(kind, 129, H, L, 20, 2, seed=2)
     m = getattr(onn, kind)(129, H, L, 20)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); m = m.to(dev).eval()
