@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -204,6 +204,10 @@ int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shif
  * (what onssen_x3_image_f32 gives), img_t = the image of its transpose [M][ceil(K/32)][2][32] (onssen_x3_image_t_f32 with
  * k_shift 0).  The training path's dP feeds the input-gradient GEMM as the first and the weight-gradient GEMM as the second. */
 int onssen_x3_image_both_f32(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, void* stream);
+/* ... also leaving colsum [ceil(K/32)][M]: the column sums of every 32-row block of src -- their sum over the blocks is the
+ * column sum of src (the bias gradient of the layer whose output gradient src is) without another pass over it. */
+int onssen_x3_image_both_colsum_f32(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, float* colsum,
+                                    void* stream);
 
 /* Split-bf16 GEMM over PRE-SPLIT operands.  An "x3 image" of a row-major [rows][K] fp32 matrix is
  * [rows][KB][2][32] bf16, KB = ceil(K/32): per row and 32-wide k block, 32 x hi = bf16(x) then 32 x lo =

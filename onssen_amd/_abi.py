@@ -53,6 +53,7 @@ SIGNATURES = {
                                                  _i64, _i, _i, _vp]),
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_x3_image_both_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "onssen_x3_image_both_colsum_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_lstm_train_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "onssen_lstm_train_forward_form_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "onssen_lstm_whhT_elems": (_i64, [_i, _i]),
@@ -260,6 +261,10 @@ class Lib:
 
     def x3_image_both(self, src, ld, M, K, img_rows, img_t, stream):
         self.check(self.dll.onssen_x3_image_both_f32(src, ld, M, K, img_rows, img_t, stream), "onssen_x3_image_both_f32")
+
+    def x3_image_both_colsum(self, src, ld, M, K, img_rows, img_t, colsum, stream):
+        self.check(self.dll.onssen_x3_image_both_colsum_f32(src, ld, M, K, img_rows, img_t, colsum, stream),
+                   "onssen_x3_image_both_colsum_f32")
 
     def lstm_train_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates, cs, ws, ws_bytes, stream):
         self.check(self.dll.onssen_lstm_train_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, wih_img, whh_x3, bias, y, gates,

@@ -405,15 +405,26 @@ int onssen_x3_image_t_f32(const float* src, int64_t ld, int M, int K, int k_shif
   return ONSSEN_OK;
 }
 
-int onssen_x3_image_both_f32(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, void* stream) {
+static int x3_image_both_impl(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, float* colsum,
+                              void* stream) {
   if (!src || !img_rows || !img_t || M <= 0 || K <= 0 || ld < M) return ONSSEN_E_ARG;
   if (!aligned16(img_rows) || !aligned16(img_t)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   const int KB = ceil_div(K, 32), MB = ceil_div(M, 32);
   hipLaunchKernelGGL(x3_image_both_kernel, dim3((unsigned)ceil_div(M, 64), (unsigned)KB), dim3(256), 0, (hipStream_t)stream, src,
-                     (long)ld, M, K, KB, MB, img_rows, img_t);
+                     (long)ld, M, K, KB, MB, img_rows, img_t, colsum);
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
+}
+
+int onssen_x3_image_both_f32(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, void* stream) {
+  return x3_image_both_impl(src, ld, M, K, img_rows, img_t, nullptr, stream);
+}
+
+int onssen_x3_image_both_colsum_f32(const float* src, int64_t ld, int M, int K, uint16_t* img_rows, uint16_t* img_t, float* colsum,
+                                    void* stream) {
+  if (!colsum) return ONSSEN_E_ARG;
+  return x3_image_both_impl(src, ld, M, K, img_rows, img_t, colsum, stream);
 }
 
 static int linear_x3p_batched_impl(const uint16_t* a_img, int64_t a_bs, int M, int K, const uint16_t* w_img, int64_t w_bs,

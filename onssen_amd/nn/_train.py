@@ -325,12 +325,16 @@ def linear_x3_backward(lib, st, dy, x2d, weight, need_dx=True):
     dx = None
     KB = (M + 31) // 32
     dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
+    db = None
     if need_dx:
         wt = torch.empty(K, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
         lib.x3_image_t(weight.data_ptr(), K, K, N, 0, wt.data_ptr(), st)                     # image of W^T: rows k, contraction over n
         dx = torch.empty(M, K, device=dev, dtype=torch.float32)
         a = torch.empty(M, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
-        lib.x3_image_both(dy.data_ptr(), N, N, M, a.data_ptr(), dyt.data_ptr(), st)          # dy feeds both products: one pass over it
+        # dy feeds both products AND the bias gradient: one pass over it (the column sums of its 32-row blocks come with the images)
+        part = torch.empty(KB, N, device=dev, dtype=torch.float32)
+        lib.x3_image_both_colsum(dy.data_ptr(), N, N, M, a.data_ptr(), dyt.data_ptr(), part.data_ptr(), st)
+        db = part.sum(0)
         lib.linear_x3p(a.data_ptr(), M, N, wt.data_ptr(), zero.data_ptr(), K, 0, 0, 0.0, dx.data_ptr(), 1, K, 0, st)
     else:
         lib.x3_image_t(dy.data_ptr(), N, N, M, 0, dyt.data_ptr(), st)
@@ -338,7 +342,7 @@ def linear_x3_backward(lib, st, dy, x2d, weight, need_dx=True):
     lib.x3_image_t(x2d.data_ptr(), K, K, M, 0, xt.data_ptr(), st)
     dW = torch.empty(N, K, device=dev, dtype=torch.float32)
     lib.linear_x3p(dyt.data_ptr(), N, M, xt.data_ptr(), zero.data_ptr(), K, 0, 0, 0.0, dW.data_ptr(), 1, K, 0, st)
-    return dx, dW, dy.sum(0)
+    return dx, dW, db if db is not None else dy.sum(0)
 
 
 class LinearX3Function(torch.autograd.Function):

@@ -352,6 +352,13 @@ def test_x3_image_both_equals_the_two_single_image_kernels(lib, K, M):
     lib.x3_image_t(P(src), ld, M, K, 0, P(t_b), None)
     np.testing.assert_array_equal(rows_a, rows_b)
     np.testing.assert_array_equal(t_a, t_b)
+    # ... and with the column sums of every 32-row block (the bias gradient's operand): same images, sums to fp32 rounding
+    rows_c, t_c, part = np.full_like(rows_a, 0x7fc0), np.full_like(t_a, 0x7fc0), np.full((KB, M), np.nan, np.float32)
+    lib.x3_image_both_colsum(P(src), ld, M, K, P(rows_c), P(t_c), P(part), None)
+    np.testing.assert_array_equal(rows_c, rows_a)
+    np.testing.assert_array_equal(t_c, t_a)
+    blocks = np.stack([src[32 * kb:32 * kb + 32, :M].astype(np.float64).sum(0) for kb in range(KB)])
+    np.testing.assert_allclose(part, blocks, rtol=1e-5, atol=1e-5)
 
 
 def test_label_features_match_oracle(lib):
