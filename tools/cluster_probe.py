@@ -37,3 +37,16 @@ with torch.no_grad():
     iw = ws[so - B * 72 * 4:so].view(torch.int32).view(B, 72).cpu().numpy()
     print("active fraction per utterance:", np.round(iw[:, 64] / (T * F), 3).tolist())
     print("Lloyd generation word (iterations | 0x10000 converged):", [hex(int(v)) for v in iw[:, 66]])
+    # the persistent launch by the number of Lloyd iterations: intercept = start-up + loading the rows + pass 0, slope = one pass
+    os.environ["ONSSEN_DC_PERSISTENT"] = "1"
+    for iters in (0, 1, 5, 10, 20):
+        for _ in range(3):
+            dc_masks(emb, logmag, iters=iters, tol=0.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dc_masks(emb, logmag, iters=iters, tol=0.0)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"iters={iters:2d}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us per call")
