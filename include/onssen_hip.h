@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -434,6 +434,15 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
  * partial Grams are reused); the embedding is read once and d_emb written once.  C <= 4. */
 int onssen_loss_dc_grad_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
                             const float* g_per_utt, float* d_emb, void* ws, size_t ws_bytes, void* stream);
+/* Fusion at the train-step level (the labels are in hand there): from the normalised embedding `emb` [B*T][F*D] and the
+ * reciprocal norms `inv_norm` [B*T][F] of onssen_linear_x3p_norms, with the partial Grams onssen_loss_dc_f32 left in ws, straight
+ * to the operands of fc_dc's gradient GEMMs -- the gradient of loss_dc w.r.t. the embedding, taken through F.normalize, written as
+ * the row-major x3 image [B*T][ceil(F*D/32)][2][32] (dx = draw W), the transposed x3 image [F*D][ceil(B*T/32)][2][32]
+ * (dW = draw^T x) and colsum [ceil(B*T/32)][F*D] (db = its sum over the blocks).  Neither d(loss)/d(embedding) nor the gradient of
+ * the raw product exists in memory.  D = 20, C <= 4, T >= 32.  g_per_utt [B]: dL/d(per-utterance loss). */
+int onssen_dc_head_grad_images_f32(const float* emb, const float* inv_norm, const float* one_hot, const float* mag, int B, int T,
+                                   int F, int D, int C, float eps, const float* g_per_utt, void* ws, size_t ws_bytes,
+                                   uint16_t* img_rows, uint16_t* img_t, float* colsum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N4  batch SI-SDR with the best source permutation (evaluation metric of tester.eval):

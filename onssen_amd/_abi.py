@@ -85,6 +85,7 @@ SIGNATURES = {
     "onssen_batch_sdr_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "onssen_loss_dc_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "onssen_dc_head_grad_images_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _sz, _i, _vp]),
     "onssen_mask_istft_f32": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     # deep-clustering separation without the embedding round trip (round 4)
@@ -309,6 +310,10 @@ class Lib:
 
     def l2norm_rows_grad(self, x, g, rows, D, eps, dx, stream):
         self.check(self.dll.onssen_l2norm_rows_grad_f32(x, g, rows, D, eps, dx, stream), "onssen_l2norm_rows_grad_f32")
+
+    def dc_head_grad_images(self, emb, inv_norm, one_hot, mag, B, T, F, D, Cc, eps, g_per_utt, ws, ws_bytes, img_rows, img_t, colsum, stream):
+        self.check(self.dll.onssen_dc_head_grad_images_f32(emb, inv_norm, one_hot, mag, B, T, F, D, Cc, eps, g_per_utt, ws, ws_bytes,
+                                                           img_rows, img_t, colsum, stream), "onssen_dc_head_grad_images_f32")
 
     def l2norm_rows_grad_y(self, y, inv_norm, g, rows, D, eps, dx, stream):
         self.check(self.dll.onssen_l2norm_rows_grad_y_f32(y, inv_norm, g, rows, D, eps, dx, stream), "onssen_l2norm_rows_grad_y_f32")

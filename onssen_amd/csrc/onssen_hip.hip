@@ -671,6 +671,25 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
 }
 
 
+int onssen_dc_head_grad_images_f32(const float* emb, const float* inv_norm, const float* one_hot, const float* mag, int B, int T,
+                                   int F, int D, int C, float eps, const float* g_per_utt, void* ws, size_t ws_bytes,
+                                   uint16_t* img_rows, uint16_t* img_t, float* colsum, void* stream) {
+  if (!emb || !inv_norm || !one_hot || !mag || !g_per_utt || !ws || !img_rows || !img_t || !colsum || B <= 0 || F <= 0 || C <= 0 ||
+      C > 4 || D != 20 || T < 32 || !(eps > 0.0f) || (long)B * T > 0x7fffffffL / 64)
+    return ONSSEN_E_ARG;
+  if (!aligned16(emb) || !aligned16(img_rows) || !aligned16(img_t)) return ONSSEN_E_ALIGN;
+  if (ws_bytes < onssen_loss_dc_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  float* gm = (float*)ws + (size_t)B * lossdc::NBLK * (lossdc::ZMAX * lossdc::ZMAX + 1);
+  hipLaunchKernelGGL(loss_dc_gradm_kernel, dim3((unsigned)B), dim3(256), 0, st, (const float*)ws, D, C, gm);
+  const dim3 grid((unsigned)ceil_div(F, 8), (unsigned)ceil_div(B * T, 32));
+  hipLaunchKernelGGL(dc_head_grad_images_kernel, grid, dim3(256), 0, st, emb, inv_norm, one_hot, mag, (const float*)gm, g_per_utt, B, T,
+                     F, C, eps, img_rows, img_t, colsum);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_loss_dc_grad_f32(const float* emb, const float* one_hot, const float* mag, int B, int TF, int D, int C,
                             const float* g_per_utt, float* d_emb, void* ws, size_t ws_bytes, void* stream) {
   if (!emb || !one_hot || !mag || !g_per_utt || !d_emb || !ws || B <= 0 || TF <= 0 || D <= 0 || C <= 0 || C > 4 ||

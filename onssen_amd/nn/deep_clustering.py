@@ -48,6 +48,25 @@ class deep_clustering(PackedWeightsMixin, nn.Module):
         emb = run_head(self._head, y, batch_size, frame, EPI_L2NORM, group=self.embedding_dim, eps=1e-12)
         return [emb.view(batch_size, frame, frequency, -1)]
 
+    def fused_loss_dc(self, input, label):
+        """``loss_dc(self(input), label)`` (onssen/loss/loss_dc.py:6-44 on onssen/nn/deep_clustering.py:32-43) as ONE autograd node
+        behind the BLSTM stack and the BatchNorm -- the fusion a train step can make because it holds the labels when the
+        forward runs (``onssen_amd.dist.train_step`` does, for this model with ``onssen_amd.loss.loss_dc``): the embedding is
+        written once and read twice, d loss / d embedding is never written.  Returns the (B, B) loss tensor of upstream's
+        broadcast, or None when this batch cannot take the fused kernels (the caller then runs model + loss as usual)."""
+        from ._train import DcHeadLossFunction, dc_head_loss_applies
+        assert len(input) == 1 and len(label) == 2
+        x = input[0].float()
+        one_hot, mag_mix = label
+        if not (self.training and dc_head_loss_applies(self.fc_dc, x, one_hot, self.embedding_dim)):
+            return None
+        B, T, Fq = x.shape
+        r = self.rnn.autograd_forward(x, True)
+        r = batch_norm_rows(self.bn, r)
+        per_utt, total = DcHeadLossFunction.apply(r, self.fc_dc.weight, self.fc_dc.bias, one_hot.reshape(B, T * Fq, -1),
+                                                  mag_mix.reshape(B, T * Fq), self.embedding_dim, 1e-12)
+        return per_utt * total.unsqueeze(1)
+
     def _autograd_forward(self, x):
         B, T, Fq = x.shape
         r = self.rnn.autograd_forward(x, self.training)

@@ -1099,6 +1099,56 @@ def test_embedding_head_with_norms_and_its_backward(lib, M, tile, monkeypatch):
     np.testing.assert_allclose(d[:, 2], g.reshape(M, N // D, D)[:, 2] * np.float32(1e12), rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,T,F,C", [(2, 40, 13, 2), (3, 33, 9, 3)])
+def test_dc_head_gradient_straight_into_gemm_operands(lib, B, T, F, C):
+    """onssen_dc_head_grad_images_f32 (train-step-level fusion): from the normalised embedding + reciprocal norms + the forward's
+    partial Grams to the row-major image, the transposed image and the block column sums of d(loss_dc)/d(fc_dc output) in one
+    pass -- against the chain it replaces (onssen_loss_dc_grad_f32 -> onssen_l2norm_rows_grad_y_f32 ->
+    onssen_x3_image_both_colsum_f32).  T is not a multiple of 32: row tiles span two utterances."""
+    rng = np.random.default_rng(B + T)
+    D, N, M = 20, F * 20, B * T
+    raw = rand(rng, M, F, D)
+    raw[5, 2] = 0.0                                              # a clamped norm
+    nrm = np.maximum(np.linalg.norm(raw, axis=-1), 1e-12).astype(np.float32)
+    emb = (raw / nrm[..., None]).astype(np.float32).reshape(M, N)
+    inv = (1.0 / nrm).astype(np.float32)
+    lab = rng.integers(0, C + 1, (B, T * F))                     # C = silent bin
+    one_hot = np.zeros((B, T * F, C), np.float32)
+    for c in range(C):
+        one_hot[..., c] = lab == c
+    mag = (rng.random((B, T * F)) + 0.1).astype(np.float32)
+    g = (rand(rng, B) + 2.0).astype(np.float32)
+    embv = np.ascontiguousarray(emb.reshape(B, T * F, D))
+    per_utt, total = np.zeros(B, np.float32), np.zeros(B, np.float32)
+    ws = aligned_f32(lib.loss_dc_workspace_bytes(B) // 4 + 64)
+    lib.loss_dc(P(embv), P(one_hot), P(mag), B, T * F, D, C, P(per_utt), P(total), P(ws), ws.nbytes, None)
+    # the chain
+    dV = np.full((B, T * F, D), np.nan, np.float32)
+    lib.loss_dc_grad(P(embv), P(one_hot), P(mag), B, T * F, D, C, P(g), P(dV), P(ws), ws.nbytes, None)
+    d_raw = np.full((M, N), np.nan, np.float32)
+    lib.l2norm_rows_grad_y(P(emb), P(inv), P(dV), M * F, D, 1e-12, P(d_raw), None)
+    KB, NB = (M + 31) // 32, (N + 31) // 32
+    rows_a, t_a, part_a = np.zeros((M, NB, 2, 32), np.uint16), np.zeros((N, KB, 2, 32), np.uint16), np.zeros((KB, N), np.float32)
+    lib.x3_image_both_colsum(P(d_raw), N, N, M, P(rows_a), P(t_a), P(part_a), None)
+    # the fused pass
+    rows_b, t_b = np.full_like(rows_a, 0x7fc0), np.full_like(t_a, 0x7fc0)
+    part_b = np.full((KB, N), np.nan, np.float32)
+    lib.dc_head_grad_images(P(emb), P(inv), P(one_hot), P(mag), B, T, F, D, C, 1e-12, P(g), P(ws), ws.nbytes, P(rows_b), P(t_b),
+                            P(part_b), None)
+    f = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
+    val = lambda img: (f(img[:, :, 0]).astype(np.float64) + f(img[:, :, 1])).reshape(img.shape[0], -1)
+    scale = np.abs(d_raw).max()
+    ra, rb, ta, tb = val(rows_a), val(rows_b), val(t_a), val(t_b)
+    assert np.abs(ra[:, :N] - d_raw).max() <= 2e-5 * scale       # (the images carry the values to 2^-16)
+    np.testing.assert_allclose(rb, ra, atol=3e-5 * scale)        # same arithmetic, a different summation order of the row dot product
+    np.testing.assert_allclose(tb, ta, atol=3e-5 * scale)
+    assert not rb[:, N:].any() and not tb[:, M:].any()           # zero padding of both images
+    np.testing.assert_allclose(part_b, part_a, atol=2e-4 * scale)
+    with pytest.raises(_abi.OnssenError):                        # row tiles may span two utterances, not more
+        lib.dc_head_grad_images(P(emb), P(inv), P(one_hot), P(mag), B * 2, T // 2, F, D, C, 1e-12, P(g), P(ws), ws.nbytes, P(rows_b),
+                                P(t_b), P(part_b), None)
+
+
 @pytest.mark.parametrize("M,C", [(300, 40), (129, 7)])
 def test_bn_rows_train_forward_and_gradient(lib, M, C):
     """onssen_bn_rows_train_f32 / _grad_f32 against nn.BatchNorm1d in training mode under float64 autograd, applied the
