@@ -61,6 +61,19 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x8 a, s16x8 b, f32x4 c) {
                                                  0, 0);
 }
 
+// gfx950's transposing LDS read (ds_read_b64_tr_b16): every lane supplies the address of FOUR consecutive 16-bit elements; inside a
+// 16-lane group, lane c receives element c % 4 of the rows addressed by lanes 4 j + c / 4, j = 0..3 (measured:
+// tools/micro/tr16_probe.hip).  With the lanes of a group addressing a [4 k][16 m] block row by row, lane c gets column c of
+// the block: four consecutive k of one m -- half an MFMA fragment from a tile that was stored as it came from memory.
+typedef short s16x4 __attribute__((vector_size(8)));
+#ifdef ONSSEN_HOST_EMULATION
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned short* p) { return emu_ds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+#endif
+
 // hipGetLastError() is sticky per thread: other libraries' failed probes (e.g. a device query before
 // the runtime is initialised) linger.  Every ABI entry clears it first, then checks its own launches.
 #define ONSSEN_CLEAR_ERROR() ((void)hipGetLastError())
@@ -472,6 +485,36 @@ int onssen_linear_x3p_batched_split_alt(const uint16_t* a_img, int64_t a_bs, int
   if (!C2 || n_split_odd <= 0) return ONSSEN_E_ARG;
   return linear_x3p_batched_impl(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, C, c_bs, c_s0, c_s1, n_split, C2, c2_bs, c2_s0, c2_s1,
                                  batch, stream, n_split_odd);
+}
+
+// dW of one bidirectional LSTM layer from ROW-MAJOR images (linear_x3t_kernel): dp_img [K = T*B][2*NP / 32][2][32] (dL/d pre-activation),
+// y_img [K][2*Hp / 32][2][32] (the layer's output), x_img [K][ceil(Kx / 32)][2][32] (its input); per direction
+//   dW_hh[d] (R-mapped rows, Hp columns) = dP_d^T h_prev_d,   dW_ih[d] (Kx columns) = dP_d^T x
+// with h_prev = y rows shifted by -B (forward) / +B (reverse).
+int onssen_lstm_wgrad_images_f32(const uint16_t* dp_img, const uint16_t* y_img, const uint16_t* x_img, int K, int B, int NP, int Hp,
+                                 int Kx, const float* zero16, int R, float* dW_ih, int64_t ih_bs, int64_t ih_s0, int64_t ih_s1,
+                                 float* dW_hh, int64_t hh_bs, int64_t hh_s0, int64_t hh_s1, void* stream) {
+  if (!dp_img || !y_img || !x_img || !zero16 || !dW_ih || !dW_hh || K <= 0 || B <= 0 || R <= 0 || NP <= 0 || Hp <= 0 || Kx <= 0 ||
+      (NP % 32) != 0 || (Hp % 8) != 0 || (Kx % 8) != 0 || (long)K * ((2 * NP) / 32) * 128 > 0x7fffffffL)
+    return ONSSEN_E_ARG;
+  if (!aligned16(dp_img) || !aligned16(y_img) || !aligned16(x_img) || !aligned16(zero16)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  LinearXtArgs p;
+  p.A = dp_img; p.a_pitch = (long)(2 * NP / 32) * 128; p.a_col0[0] = 0; p.a_col0[1] = NP;
+  const long y_pitch = (long)ceil_div(2 * Hp, 32) * 128, x_pitch = (long)ceil_div(Kx, 32) * 128;
+  // forward direction: [h_prev (y columns [0, Hp), rows k - B) | x];  reverse: [x | h_prev (y columns [Hp, 2 Hp), rows k + B)]
+  p.seg[0][0] = XtSeg{y_img, y_pitch, 0, Hp, -B};   p.seg[0][1] = XtSeg{x_img, x_pitch, 0, Kx, 0};
+  p.seg[1][0] = XtSeg{x_img, x_pitch, 0, Kx, 0};    p.seg[1][1] = XtSeg{y_img, y_pitch, Hp, Hp, B};
+  p.zero = (const unsigned short*)zero16;
+  p.M = NP; p.N = Hp + Kx; p.K = K; p.R = R; p.tile_group = 4;
+  p.C[0][0] = dW_hh;           p.s0[0][0] = hh_s0; p.s1[0][0] = hh_s1;
+  p.C[0][1] = dW_ih;           p.s0[0][1] = ih_s0; p.s1[0][1] = ih_s1;
+  p.C[1][0] = dW_ih + ih_bs;   p.s0[1][0] = ih_s0; p.s1[1][0] = ih_s1;
+  p.C[1][1] = dW_hh + hh_bs;   p.s0[1][1] = hh_s0; p.s1[1][1] = hh_s1;
+  const dim3 grid((unsigned)ceil_div(p.N, 160), (unsigned)ceil_div(p.M, 256), 2);
+  hipLaunchKernelGGL((linear_x3t_kernel<3>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
 }
 
 static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,

@@ -94,10 +94,19 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     KB = (TB + 31) // 32
     N1 = Kx + Hp                                   # per direction: [dW_ih | dW_hh] columns
     dp2 = dP.view(TB, 2 * NP)
-    # operands contracted over the T*B rows: transposed images straight from the row-major activations
-    a_t = torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
+    direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
+    # round 4, opt-in (ONSSEN_TRAIN_WGRAD_ROWS=1): the weight-gradient GEMM that contracts over the ROWS of row-major images
+    # (onssen_lstm_wgrad_images_f32: gfx950's transposing LDS read; h of the step before is a row shift of y's image) -- no
+    # transposed image of dP, x or y is made.  Bit-identical gradients; measured neutral (7.29 against 7.27-7.32 ms per step: the
+    # GEMM is 12 % slower on these operands than the one on transposed images and the row-major images cost what the
+    # transposed ones did), so the transposed-image route stays the default
+    rows_gemm = (direct and NP % 32 == 0 and Hp % 8 == 0 and Kx % 8 == 0 and xp.is_contiguous()
+                 and os.environ.get("ONSSEN_TRAIN_WGRAD_ROWS", "0") == "1")
+    a_t = None if rows_gemm else torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
     a_rows = None
-    if need_dx:       # dP is the operand of both gradient GEMMs: its row-major and its transposed image from ONE pass over it
+    if rows_gemm:
+        a_rows = _x3_image(lib, st, dp2)
+    elif need_dx:     # dP is the operand of both gradient GEMMs: its row-major and its transposed image from ONE pass over it
         a_rows = torch.empty(TB, (2 * NP + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
         lib.x3_image_both(dp2.data_ptr(), 2 * NP, 2 * NP, TB, a_rows.data_ptr(), a_t.data_ptr(), st)
     else:
@@ -105,8 +114,13 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     y2 = y.view(TB, 2 * Hp)
     zero_bias = _zeros(max(N1, wih_p.shape[2]), dev)                      # (read-only operand of the GEMMs)
     # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
-    direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
-    if direct:
+    if rows_gemm:
+        y_img, x_img = _x3_image(lib, st, y2), _x3_image(lib, st, xp)
+        dW_ih2 = torch.empty(2, 4 * H, Kx, device=dev, dtype=torch.float32)
+        dW_hh2 = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
+        lib.lstm_wgrad_images(a_rows.data_ptr(), y_img.data_ptr(), x_img.data_ptr(), TB, B, NP, Hp, Kx, zero_bias.data_ptr(), 4,
+                              dW_ih2.data_ptr(), 4 * H * Kx, Kx, H * Kx, dW_hh2.data_ptr(), 4 * H * H, H, H * H, st)
+    elif direct:
         # ONE image of the layer input for both directions: rows [h_prev forward | x | h_prev reverse], direction 0 contracts
         # with rows [0, Hp + Kx), direction 1 with rows [Hp, Hp + Kx + Hp) -- overlapping windows, the outputs alternate
         # (the forward direction looks B rows back, the reverse direction B rows ahead)

@@ -1063,6 +1063,48 @@ def test_batched_gemm_with_two_outputs_and_overlapping_windows(lib):
     np.testing.assert_array_equal(hh2, hh)
 
 
+@pytest.mark.parametrize("H,Kx,T,B", [(16, 40, 9, 5), (24, 48, 5, 18)])
+def test_weight_gradients_from_row_major_images(lib, H, Kx, T, B):
+    """onssen_lstm_wgrad_images_f32 (linear_x3t_kernel: contraction over the ROWS of row-major x3 images, fragments through the
+    transposing LDS read, h_prev as a row shift of y) against onssen_linear_x3p_batched_split_alt on the transposed images:
+    the same MFMA sequence on the same operand values -- bit for bit."""
+    rng = np.random.default_rng(H + T)
+    NP, Hp, K = 4 * H, H, T * B                          # (NP % 32 == 0 for these H)
+    dP, y, x = rand(rng, K, 2 * NP), rand(rng, K, 2 * Hp), rand(rng, K, Kx)
+    KB = (K + 31) // 32
+    def rows_img(m):
+        o = np.zeros((m.shape[0], (m.shape[1] + 31) // 32, 2, 32), np.uint16)
+        lib.x3_image(P(m), m.shape[1], 0, 1, m.shape[0], m.shape[1], P(o), None)
+        return o
+    def t_img(m, cols, shift):                           # transposed image of m[:, cols] with the row shift of "h of the step before"
+        sub = np.ascontiguousarray(m[:, cols])
+        o = np.zeros((sub.shape[1], KB, 2, 32), np.uint16)
+        lib.x3_image_t(P(sub), sub.shape[1], sub.shape[1], K, shift, P(o), None)
+        return o
+    # reference: the transposed-image route of the training path
+    a_t = t_img(dP, slice(0, 2 * NP), 0)
+    w1 = np.concatenate([t_img(y, slice(0, Hp), -B), t_img(x, slice(0, Kx), 0), t_img(y, slice(Hp, 2 * Hp), B)])
+    zero = np.zeros(max(Hp + Kx, 8), np.float32)
+    ih_a, hh_a = np.full((2, 4 * H, Kx), np.nan, np.float32), np.full((2, 4 * H, H), np.nan, np.float32)
+    lib.linear_x3p_batched_split_alt(P(a_t), NP * KB * 64, NP, K, P(w1), Hp * KB * 64, P(zero), Hp + Kx, 4, P(hh_a), 4 * H * H, H, H * H, Hp,
+                                     P(ih_a), 4 * H * Kx, Kx, H * Kx, Kx, 2, None)
+    # the row-major route
+    dp_img, y_img, x_img = rows_img(dP), rows_img(y), rows_img(x)
+    ih_b, hh_b = np.full_like(ih_a, np.nan), np.full_like(hh_a, np.nan)
+    lib.lstm_wgrad_images(P(dp_img), P(y_img), P(x_img), K, B, NP, Hp, Kx, P(zero), 4, P(ih_b), 4 * H * Kx, Kx, H * Kx,
+                          P(hh_b), 4 * H * H, H, H * H, None)
+    assert not np.isnan(ih_b).any() and not np.isnan(hh_b).any()
+    np.testing.assert_array_equal(ih_b, ih_a)
+    np.testing.assert_array_equal(hh_b, hh_a)
+    # ... and it is the right product: nn.LSTM's row order gate*H + u from packed rows 4u + gate
+    to_lstm = lambda m: m.reshape(H, 4, -1).transpose(1, 0, 2).reshape(4 * H, -1)
+    hprev = np.zeros((K, Hp)); hprev[B:] = y[:-B, :Hp]
+    np.testing.assert_allclose(hh_b[0], to_lstm(dP[:, :NP].T.astype(np.float64) @ hprev), atol=3e-4, rtol=1e-4)
+    hnext = np.zeros((K, Hp)); hnext[:-B] = y[B:, Hp:]
+    np.testing.assert_allclose(hh_b[1], to_lstm(dP[:, NP:].T.astype(np.float64) @ hnext), atol=3e-4, rtol=1e-4)
+    np.testing.assert_allclose(ih_b[1], to_lstm(dP[:, NP:].T.astype(np.float64) @ x.astype(np.float64)), atol=3e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("M,tile", [(273, "256"), (150, "128")])
 def test_embedding_head_with_norms_and_its_backward(lib, M, tile, monkeypatch):
     """onssen_linear_x3p_norms (fc_dc + F.normalize in one GEMM that also leaves 1 / max(||.||, eps) per bin) and

@@ -1248,6 +1248,61 @@ def test_fused_head_and_loss_of_the_train_step(dev, monkeypatch, B, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,Kx,T,B", [(600, 1200, 400, 16), (600, 1200, 37, 5), (64, 128, 50, 3)])
+def test_weight_gradients_from_row_major_images(dev, H, Kx, T, B):
+    """onssen_lstm_wgrad_images_f32 (contraction over the rows of row-major x3 images: gfx950's transposing LDS read, h_prev as
+    a row shift) against the transposed-image route (onssen_x3_image_t_f32 + onssen_linear_x3p_batched_split_alt): bit for bit,
+    at the shipped training shape; both timed."""
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(H + T)
+    NP, Hp, K = 4 * H, H, T * B
+    dP, y, x = (torch.randn(K, n, device=dev) for n in (2 * NP, 2 * Hp, Kx))
+    KB = (K + 31) // 32
+    def rows_img(m):
+        o = torch.empty(m.shape[0], (m.shape[1] + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image(m.data_ptr(), m.shape[1], 0, 1, m.shape[0], m.shape[1], o.data_ptr(), st)
+        return o
+    zero = torch.zeros(max(Hp + Kx, 8), device=dev)
+    def transposed_route():
+        a_t = torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_t(dP.data_ptr(), 2 * NP, 2 * NP, K, 0, a_t.data_ptr(), st)
+        w1 = torch.empty(Hp + Kx + Hp, KB, 2, 32, device=dev, dtype=torch.int16)
+        lib.x3_image_t(y.data_ptr(), 2 * Hp, Hp, K, -B, w1.data_ptr(), st)
+        lib.x3_image_t(x.data_ptr(), Kx, Kx, K, 0, w1[Hp:].data_ptr(), st)
+        lib.x3_image_t(y[:, Hp:].data_ptr(), 2 * Hp, Hp, K, B, w1[Hp + Kx:].data_ptr(), st)
+        ih, hh = torch.empty(2, 4 * H, Kx, device=dev), torch.empty(2, 4 * H, H, device=dev)
+        lib.linear_x3p_batched_split_alt(a_t.data_ptr(), NP * KB * 64, NP, K, w1.data_ptr(), Hp * KB * 64, zero.data_ptr(), Hp + Kx, 4,
+                                         hh.data_ptr(), 4 * H * H, H, H * H, Hp, ih.data_ptr(), 4 * H * Kx, Kx, H * Kx, Kx, 2, st)
+        return ih, hh
+    dp_img, y_img, x_img = rows_img(dP), rows_img(y), rows_img(x)
+    def row_major_route():
+        ih, hh = torch.empty(2, 4 * H, Kx, device=dev), torch.empty(2, 4 * H, H, device=dev)
+        lib.lstm_wgrad_images(dp_img.data_ptr(), y_img.data_ptr(), x_img.data_ptr(), K, B, NP, Hp, Kx, zero.data_ptr(), 4,
+                              ih.data_ptr(), 4 * H * Kx, Kx, H * Kx, hh.data_ptr(), 4 * H * H, H, H * H, st)
+        return ih, hh
+    ih_a, hh_a = transposed_route()
+    ih_b, hh_b = row_major_route()
+    assert torch.equal(ih_b, ih_a) and torch.equal(hh_b, hh_a)
+    hprev = torch.zeros(K, Hp, device=dev, dtype=torch.float64); hprev[B:] = y[:-B, :Hp].double()
+    ref = (dP[:, :NP].double().t() @ hprev).reshape(H, 4, Hp).transpose(0, 1).reshape(4 * H, Hp)
+    assert ((hh_b[0].double() - ref).norm() / ref.norm()).item() < 1e-5
+    times = {}
+    for name, fn in (("transposed images + GEMM", transposed_route), ("row-major GEMM", row_major_route)):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times[name] = e0.elapsed_time(e1) * 100
+    print(f"H={H} Kx={Kx} T={T} B={B}: " + ", ".join(f"{k} {v:.1f} us" for k, v in times.items()))
+
+
+@pytest.mark.gpu
 def test_chimera_training_step_hip_vs_aten(dev, monkeypatch):
     """chimera++ (4 x BLSTM-600, no BatchNorm) + loss_chimera_msa: the HIP training path against the stock ATen LSTM,
     dropout off.  Same bound as the deep-clustering test: 2e-3 of each gradient tensor's largest entry."""
