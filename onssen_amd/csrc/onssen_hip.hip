@@ -400,7 +400,7 @@ int onssen_x3_image_f32(const float* src, int64_t s0, int64_t s1, int R, int row
   if (!aligned16(img)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   const int KB = ceil_div(K, 32);
-  const long n = (long)rows * KB * 32;
+  const long n = (long)rows * KB * 4;
   hipLaunchKernelGGL(x3_image_kernel, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, src, (long)s0, (long)s1, R, rows, K, KB, img);
   ONSSEN_LAUNCH_CHECK();
