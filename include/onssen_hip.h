@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -201,7 +201,7 @@ int onssen_linear_x3p_batched_split_alt(const uint16_t* a_img, int64_t a_bs, int
  *   y_img  [K][ceil(2*Hp / 32)][2][32]   the layer's output (onssen_blstm_y_image),   x_img [K][ceil(Kx / 32)][2][32]  its input
  *   dW_hh[d] = dP_d^T h_prev_d (h_prev = y rows k - B for the forward, k + B for the reverse direction),  dW_ih[d] = dP_d^T x,
  *   direction d at dW_* + d*bs, packed row m at (m / R)*s0 + (m % R)*s1 (R = 4, s0 = ld, s1 = H*ld writes nn.LSTM's row order).
- * NP % 32 == 0, Hp % 8 == 0, Kx % 8 == 0.  zero16: 16 readable zero bytes.  Bit-identical to
+ * NP % 32 == 0, Hp % 8 == 0 (x_img's zero padding past Kx is read up to the next multiple of 8, never stored).  zero16: 16 readable zero bytes.  Bit-identical to
  * onssen_linear_x3p_batched_split_alt on the transposed images. */
 int onssen_lstm_wgrad_images_f32(const uint16_t* dp_img, const uint16_t* y_img, const uint16_t* x_img, int K, int B, int NP, int Hp,
                                  int Kx, const float* zero16, int R, float* dW_ih, int64_t ih_bs, int64_t ih_s0, int64_t ih_s1,
@@ -288,6 +288,9 @@ size_t onssen_blstm_workspace_bytes(int B, int T, int in_dim, int H, int L, int 
 /* Where the ONSSEN_BLSTM_XCD form leaves the x3 image [T*B][KB][2][32] (row m = t*B + b, KB = ceil(2*Hp/32),
  * k = d*Hp + j) of the LAST layer's output: byte offset inside the workspace.  Feed it to onssen_linear_x3p. */
 int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t* offset_bytes, int* KB);
+/* ... and the x3 image [T*B][ceil(in_dim/32)][2][32] of the stack's INPUT (row m = t*B + b), made by the XCD form for its first
+ * projection GEMM (not with ONSSEN_BLSTM_FUSE_IN0): the training path's weight-gradient GEMM over row-major images reads it back. */
+int onssen_blstm_x_image(int B, int T, int in_dim, int H, int L, int ug, size_t* offset_bytes, int* KB);
 int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int L,
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,

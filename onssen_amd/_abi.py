@@ -45,6 +45,7 @@ SIGNATURES = {
     "onssen_linear_x3p_pair": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _i64, _i64, _vp, _i64, _i64, _i, _vp]),
     "onssen_blstm_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "onssen_blstm_x_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
     "onssen_linear_x3p_batched": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
@@ -182,6 +183,12 @@ class Lib:
         """(byte offset inside the workspace, KB) of the last layer's x3 output image (ONSSEN_BLSTM_XCD form)."""
         off, kb = C.c_size_t(0), C.c_int(0)
         self.check(self.dll.onssen_blstm_y_image(B, T, in_dim, H, L, ug, C.byref(off), C.byref(kb)), "onssen_blstm_y_image")
+        return int(off.value), int(kb.value)
+
+    def blstm_x_image(self, B, T, in_dim, H, L, ug):
+        """(byte offset inside the workspace, KB) of the last layer's x3 output image (ONSSEN_BLSTM_XCD form)."""
+        off, kb = C.c_size_t(0), C.c_int(0)
+        self.check(self.dll.onssen_blstm_x_image(B, T, in_dim, H, L, ug, C.byref(off), C.byref(kb)), "onssen_blstm_x_image")
         return int(off.value), int(kb.value)
 
     # ---- kernels (pointers are ints) --------------------------------------

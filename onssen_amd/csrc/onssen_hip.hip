@@ -495,18 +495,19 @@ int onssen_lstm_wgrad_images_f32(const uint16_t* dp_img, const uint16_t* y_img, 
                                  int Kx, const float* zero16, int R, float* dW_ih, int64_t ih_bs, int64_t ih_s0, int64_t ih_s1,
                                  float* dW_hh, int64_t hh_bs, int64_t hh_s0, int64_t hh_s1, void* stream) {
   if (!dp_img || !y_img || !x_img || !zero16 || !dW_ih || !dW_hh || K <= 0 || B <= 0 || R <= 0 || NP <= 0 || Hp <= 0 || Kx <= 0 ||
-      (NP % 32) != 0 || (Hp % 8) != 0 || (Kx % 8) != 0 || (long)K * ((2 * NP) / 32) * 128 > 0x7fffffffL)
+      (NP % 32) != 0 || (Hp % 8) != 0 || (long)K * ((2 * NP) / 32) * 128 > 0x7fffffffL)
     return ONSSEN_E_ARG;
+  const int Kx8 = (Kx + 7) & ~7;          // x is read in 8-column pieces: up to 7 columns of its image's zero padding, never stored
   if (!aligned16(dp_img) || !aligned16(y_img) || !aligned16(x_img) || !aligned16(zero16)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   LinearXtArgs p;
   p.A = dp_img; p.a_pitch = (long)(2 * NP / 32) * 128; p.a_col0[0] = 0; p.a_col0[1] = NP;
   const long y_pitch = (long)ceil_div(2 * Hp, 32) * 128, x_pitch = (long)ceil_div(Kx, 32) * 128;
   // forward direction: [h_prev (y columns [0, Hp), rows k - B) | x];  reverse: [x | h_prev (y columns [Hp, 2 Hp), rows k + B)]
-  p.seg[0][0] = XtSeg{y_img, y_pitch, 0, Hp, -B};   p.seg[0][1] = XtSeg{x_img, x_pitch, 0, Kx, 0};
-  p.seg[1][0] = XtSeg{x_img, x_pitch, 0, Kx, 0};    p.seg[1][1] = XtSeg{y_img, y_pitch, Hp, Hp, B};
+  p.seg[0][0] = XtSeg{y_img, y_pitch, 0, Hp, -B, Hp};   p.seg[0][1] = XtSeg{x_img, x_pitch, 0, Kx8, 0, Kx};
+  p.seg[1][0] = XtSeg{x_img, x_pitch, 0, Kx8, 0, Kx};   p.seg[1][1] = XtSeg{y_img, y_pitch, Hp, Hp, B, Hp};
   p.zero = (const unsigned short*)zero16;
-  p.M = NP; p.N = Hp + Kx; p.K = K; p.R = R; p.tile_group = 4;
+  p.M = NP; p.N = Hp + Kx8; p.K = K; p.R = R; p.tile_group = 4;
   p.C[0][0] = dW_hh;           p.s0[0][0] = hh_s0; p.s1[0][0] = hh_s1;
   p.C[0][1] = dW_ih;           p.s0[0][1] = ih_s0; p.s1[0][1] = ih_s1;
   p.C[1][0] = dW_ih + ih_bs;   p.s0[1][0] = ih_s0; p.s1[1][0] = ih_s1;
@@ -856,6 +857,14 @@ int onssen_blstm_y_image(int B, int T, int in_dim, int H, int L, int ug, size_t*
     return ONSSEN_E_ARG;
   if (offset_bytes) *offset_bytes = w.off_imga;
   if (KB) *KB = ceil_div(2 * Hp, 32);
+  return ONSSEN_OK;
+}
+
+int onssen_blstm_x_image(int B, int T, int in_dim, int H, int L, int ug, size_t* offset_bytes, int* KB) {
+  BlstmWs w;
+  if (!blstm_ws_layout(B, T, in_dim, H, L, ug, &w)) return ONSSEN_E_ARG;
+  if (offset_bytes) *offset_bytes = w.off_imgx;
+  if (KB) *KB = ceil_div(in_dim, 32);
   return ONSSEN_OK;
 }
 

@@ -78,7 +78,7 @@ def _x3_image(lib, st, m):
     return img
 
 
-def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, db_rows=None):
+def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, db_rows=None, fwd_images=None):
     """The same contractions as layer_gradients on the split-bf16 MFMA GEMM (onssen_linear_x3p), in the packed layouts
     the kernels use, so that no gather of dP is needed:
 
@@ -95,13 +95,12 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     N1 = Kx + Hp                                   # per direction: [dW_ih | dW_hh] columns
     dp2 = dP.view(TB, 2 * NP)
     direct = Hp == H and (Kx == in_features)      # no padded units: the GEMM writes nn.LSTM's row order and two dense matrices itself
-    # round 4, opt-in (ONSSEN_TRAIN_WGRAD_ROWS=1): the weight-gradient GEMM that contracts over the ROWS of row-major images
-    # (onssen_lstm_wgrad_images_f32: gfx950's transposing LDS read; h of the step before is a row shift of y's image) -- no
-    # transposed image of dP, x or y is made.  Bit-identical gradients; measured neutral (7.29 against 7.27-7.32 ms per step: the
-    # GEMM is 12 % slower on these operands than the one on transposed images and the row-major images cost what the
-    # transposed ones did), so the transposed-image route stays the default
-    rows_gemm = (direct and NP % 32 == 0 and Hp % 8 == 0 and Kx % 8 == 0 and xp.is_contiguous()
-                 and os.environ.get("ONSSEN_TRAIN_WGRAD_ROWS", "0") == "1")
+    # round 4 (ONSSEN_TRAIN_WGRAD_ROWS=0 switches it off): the weight-gradient GEMM that contracts over the ROWS of row-major
+    # images (onssen_lstm_wgrad_images_f32: gfx950's transposing LDS read; h of the step before is a row shift of y's image) --
+    # no transposed image of dP, x or y is made, and x's and y's row-major images are the persistent forward's own, still in
+    # its workspace (``fwd_images``).  Bit-identical gradients; 7.25 -> 7.05 ms per training step on the same box
+    rows_gemm = (direct and NP % 32 == 0 and Hp % 8 == 0 and xp.is_contiguous()
+                 and os.environ.get("ONSSEN_TRAIN_WGRAD_ROWS", "1") == "1")
     a_t = None if rows_gemm else torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
     a_rows = None
     if rows_gemm:
@@ -115,10 +114,16 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     zero_bias = _zeros(max(N1, wih_p.shape[2]), dev)                      # (read-only operand of the GEMMs)
     # the two directions in one launch: each alone (10 x 12 tiles at H = 600) would leave half the chip idle
     if rows_gemm:
-        y_img, x_img = _x3_image(lib, st, y2), _x3_image(lib, st, xp)
+        if fwd_images is not None and _Workspace.gen.get(fwd_images[3]) == fwd_images[4]:
+            # the persistent forward's own images of its input and output, still in its workspace
+            fws, x_off, y_off = fwd_images[:3]
+            x_ptr, y_ptr = fws.data_ptr() + x_off, fws.data_ptr() + y_off
+        else:
+            y_img, x_img = _x3_image(lib, st, y2), _x3_image(lib, st, xp)
+            x_ptr, y_ptr = x_img.data_ptr(), y_img.data_ptr()
         dW_ih2 = torch.empty(2, 4 * H, Kx, device=dev, dtype=torch.float32)
         dW_hh2 = torch.empty(2, 4 * H, H, device=dev, dtype=torch.float32)
-        lib.lstm_wgrad_images(a_rows.data_ptr(), y_img.data_ptr(), x_img.data_ptr(), TB, B, NP, Hp, Kx, zero_bias.data_ptr(), 4,
+        lib.lstm_wgrad_images(a_rows.data_ptr(), y_ptr, x_ptr, TB, B, NP, Hp, Kx, zero_bias.data_ptr(), 4,
                               dW_ih2.data_ptr(), 4 * H * Kx, Kx, H * Kx, dW_hh2.data_ptr(), 4 * H * H, H, H * H, st)
     elif direct:
         # ONE image of the layer input for both directions: rows [h_prev forward | x | h_prev reverse], direction 0 contracts
@@ -173,6 +178,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
 class _Workspace:
     """Recurrence workspaces keyed by shape (their header must start out zero and is never zeroed again)."""
     cache = {}
+    gen = {}          # per forward workspace: how many forwards have written their images into it
 
     @classmethod
     def get(cls, key, nbytes, device, zero):
@@ -220,7 +226,9 @@ class BLSTMTrainFunction(torch.autograd.Function):
         xp = x.transpose(0, 1).reshape(T * B, In)                        # time-major rows for the weight gradients
         for l in range(L):
             nbytes = lib.blstm_workspace_bytes(B, T, in_l, H, 1, ug)
-            ws = _Workspace.get(("fwd", B, T, in_l, H, ug), nbytes, dev, zero=True)
+            # one workspace per layer: the persistent forward leaves the x3 images of its input and of its output there, and the
+            # backward's weight-gradient GEMM over row-major images reads them back (ONSSEN_TRAIN_WGRAD_ROWS)
+            ws = _Workspace.get(("fwd", l, B, T, in_l, H, ug), nbytes, dev, zero=True)
             y = torch.empty(T, B, 2, Hp, device=dev, dtype=torch.float32)
             gates = torch.empty(T, B, 2, NP, device=dev, dtype=torch.float32)
             cs = torch.empty(T, B, 2, Hp, device=dev, dtype=torch.float32)
@@ -231,9 +239,15 @@ class BLSTMTrainFunction(torch.autograd.Function):
             lib.lstm_train_forward_form(xin.data_ptr(), xs_b, xs_t, B, T, in_l, H, ug, wih.data_ptr(), whh.data_ptr(),
                                         pk.bias[l].data_ptr(), y.data_ptr(), gates.data_ptr(), cs.data_ptr(), ws.data_ptr(),
                                         ws.numel(), fwd_flags, st)
+            imgs = None
             if persistent:
                 _XcdSerial.after(dev)
                 _XcdStatus.post(ws)       # an aborted exchange is reported at the next poll (never silently)
+                # (the workspace is shared by every forward of this shape: the generation tells the backward whether a later
+                #  forward has overwritten the images -- two forwards before one backward -- and it must make its own)
+                wkey = ("fwd", l, B, T, in_l, H, ug)
+                _Workspace.gen[wkey] = gen = _Workspace.gen.get(wkey, 0) + 1
+                imgs = (ws, lib.blstm_x_image(B, T, in_l, H, 1, ug)[0], lib.blstm_y_image(B, T, in_l, H, 1, ug)[0], wkey, gen)
             mask = None
             if l < L - 1:
                 nxt = y.view(T, B, 2 * Hp)
@@ -243,11 +257,11 @@ class BLSTMTrainFunction(torch.autograd.Function):
                     mask = int(torch.randint(0, 2 ** 62, (1,)).item())
                     nxt = torch.empty_like(nxt)
                     lib.dropout(y.data_ptr(), y.numel(), float(p_drop), mask, nxt.data_ptr(), st)
-                saved.append((xp, y, gates, cs, mask))
+                saved.append((xp, y, gates, cs, mask, imgs))
                 xin, xs_b, xs_t, in_l = nxt, 2 * Hp, B * 2 * Hp, 2 * Hp
                 xp = nxt.view(T * B, 2 * Hp)                             # padded [fwd(Hp) | rev(Hp)] rows
             else:
-                saved.append((xp, y, gates, cs, None))
+                saved.append((xp, y, gates, cs, None, imgs))
         ctx.saved_layers = saved
         ctx.packed, ctx.ug, ctx.dims, ctx.p_drop, ctx.persistent = packed, ug, (B, T, In, H, L, Hp, NP), p_drop, bool(persistent)
         ctx.flat = flat
@@ -279,7 +293,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
         # (ONSSEN_TRAIN_GEMM=blas) fp32 library GEMMs on the reference's layouts
         use_x3 = os.environ.get("ONSSEN_TRAIN_GEMM", "x3") == "x3"
         for l in range(L - 1, -1, -1):
-            xp, y, gates, cs, mask = ctx.saved_layers[l]
+            xp, y, gates, cs, mask, imgs = ctx.saved_layers[l]
             # the persistent kernel also leaves sum_t dP per batch row: the bias gradient without a pass over all of dP
             db_rows = torch.empty(B, 2 * NP, device=dev, dtype=torch.float32) if form == _abi.LSTM_BWD_XCD else None
             if form == _abi.LSTM_BWD_XCD:
@@ -291,7 +305,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 _XcdStatus.post(wsb)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if use_x3:
-                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx, db_rows)
+                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx, db_rows, imgs)
             else:
                 w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
                 x_rows = xp if l == 0 or Hp == H else xp.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H)

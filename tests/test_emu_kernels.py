@@ -1063,7 +1063,7 @@ def test_batched_gemm_with_two_outputs_and_overlapping_windows(lib):
     np.testing.assert_array_equal(hh2, hh)
 
 
-@pytest.mark.parametrize("H,Kx,T,B", [(16, 40, 9, 5), (24, 48, 5, 18)])
+@pytest.mark.parametrize("H,Kx,T,B", [(16, 40, 9, 5), (24, 48, 5, 18), (16, 13, 7, 3)])      # (Kx = 13: a first layer's odd feature count)
 def test_weight_gradients_from_row_major_images(lib, H, Kx, T, B):
     """onssen_lstm_wgrad_images_f32 (linear_x3t_kernel: contraction over the ROWS of row-major x3 images, fragments through the
     transposing LDS read, h_prev as a row shift of y) against onssen_linear_x3p_batched_split_alt on the transposed images:

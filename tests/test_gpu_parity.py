@@ -1248,7 +1248,7 @@ def test_fused_head_and_loss_of_the_train_step(dev, monkeypatch, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,Kx,T,B", [(600, 1200, 400, 16), (600, 1200, 37, 5), (64, 128, 50, 3)])
+@pytest.mark.parametrize("H,Kx,T,B", [(600, 1200, 400, 16), (600, 1200, 37, 5), (64, 128, 50, 3), (600, 129, 400, 16)])
 def test_weight_gradients_from_row_major_images(dev, H, Kx, T, B):
     """onssen_lstm_wgrad_images_f32 (contraction over the rows of row-major x3 images: gfx950's transposing LDS read, h_prev as
     a row shift) against the transposed-image route (onssen_x3_image_t_f32 + onssen_linear_x3p_batched_split_alt): bit for bit,
@@ -1300,6 +1300,36 @@ def test_weight_gradients_from_row_major_images(dev, H, Kx, T, B):
         torch.cuda.synchronize()
         times[name] = e0.elapsed_time(e1) * 100
     print(f"H={H} Kx={Kx} T={T} B={B}: " + ", ".join(f"{k} {v:.1f} us" for k, v in times.items()))
+
+
+@pytest.mark.gpu
+def test_row_major_weight_gradients_in_the_training_path(dev, monkeypatch):
+    """ONSSEN_TRAIN_WGRAD_ROWS (default on): the layers' weight gradients from row-major images -- dP's, and the persistent
+    forward's OWN images of its input and output still sitting in its workspace -- against the transposed-image route: the same
+    gradients bit for bit, also when a second forward has overwritten the workspace before the first one's backward runs (the
+    backward then makes the images itself)."""
+    from onssen_amd.nn._core import BLSTMParams
+    B, T, F, H, L = 16, 64, 129, 600, 3
+    torch.manual_seed(7)
+    x1, x2 = torch.randn(B, T, F, device=dev), torch.randn(B, T, F, device=dev)
+    R1, R2 = torch.randn(B, T, 2 * H, device=dev), torch.randn(B, T, 2 * H, device=dev)
+    grads = {}
+    for rows in ("1", "0"):
+        monkeypatch.setenv("ONSSEN_TRAIN_WGRAD_ROWS", rows)
+        for two in (False, True):
+            torch.manual_seed(8)
+            rnn = BLSTMParams(F, H, L, dropout=0.0).to(dev)
+            y1 = rnn.autograd_forward(x1, True)
+            if two:
+                y2 = rnn.autograd_forward(x2, True)
+                ((y1 * R1).sum() + (y2 * R2).sum()).backward()
+            else:
+                (y1 * R1).sum().backward()
+            grads[(rows, two)] = [p.grad.clone() for p in rnn.parameters()]
+    for two in (False, True):
+        for a, b in zip(grads[("1", two)], grads[("0", two)]):
+            assert torch.equal(a, b)
+    assert not torch.equal(grads[("1", False)][0], grads[("1", True)][0])
 
 
 @pytest.mark.gpu
