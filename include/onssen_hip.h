@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -206,6 +206,10 @@ int onssen_linear_x3p_batched_split_alt(const uint16_t* a_img, int64_t a_bs, int
 int onssen_lstm_wgrad_images_f32(const uint16_t* dp_img, const uint16_t* y_img, const uint16_t* x_img, int K, int B, int NP, int Hp,
                                  int Kx, const float* zero16, int R, float* dW_ih, int64_t ih_bs, int64_t ih_s0, int64_t ih_s1,
                                  float* dW_hh, int64_t hh_bs, int64_t hh_s0, int64_t hh_s1, void* stream);
+/* The same kernel for one plain weight gradient: C [M][N] (row stride ldc) = A^T W, contraction over the K rows of the row-major
+ * x3 images A [K][ceil(M/32)][2][32] and W [K][ceil(N/32)][2][32] (their zero padding past M / N is read, never stored). */
+int onssen_linear_x3t(const uint16_t* a_img, const uint16_t* w_img, int K, int M, int N, const float* zero16, float* C, int64_t ldc,
+                      void* stream);
 
 /* x3 image of the TRANSPOSE of a row-major fp32 matrix src [K][ld >= M], optionally shifted along k: image row m
  * (0 <= m < M), element k (0 <= k < K) = src[(k + k_shift) * ld + m], 0 where k + k_shift is outside [0, K).  Operands of
@@ -453,7 +457,7 @@ int onssen_loss_dc_grad_f32(const float* emb, const float* one_hot, const float*
  * reciprocal norms `inv_norm` [B*T][F] of onssen_linear_x3p_norms, with the partial Grams onssen_loss_dc_f32 left in ws, straight
  * to the operands of fc_dc's gradient GEMMs -- the gradient of loss_dc w.r.t. the embedding, taken through F.normalize, written as
  * the row-major x3 image [B*T][ceil(F*D/32)][2][32] (dx = draw W), the transposed x3 image [F*D][ceil(B*T/32)][2][32]
- * (dW = draw^T x) and colsum [ceil(B*T/32)][F*D] (db = its sum over the blocks).  Neither d(loss)/d(embedding) nor the gradient of
+ * (dW = draw^T x; img_t may be NULL: onssen_linear_x3t takes the row-major one) and colsum [ceil(B*T/32)][F*D] (db = its sum over the blocks).  Neither d(loss)/d(embedding) nor the gradient of
  * the raw product exists in memory.  D = 20, C <= 4, T >= 32.  g_per_utt [B]: dL/d(per-utterance loss). */
 int onssen_dc_head_grad_images_f32(const float* emb, const float* inv_norm, const float* one_hot, const float* mag, int B, int T,
                                    int F, int D, int C, float eps, const float* g_per_utt, void* ws, size_t ws_bytes,

@@ -52,6 +52,7 @@ SIGNATURES = {
                                              _i, _vp]),
     "onssen_linear_x3p_batched_split_alt": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64,
                                                  _i64, _i, _i, _vp]),
+    "onssen_linear_x3t": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i64, _vp]),
     "onssen_lstm_wgrad_images_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp]),
     "onssen_x3_image_t_f32": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "onssen_x3_image_both_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp]),
@@ -264,6 +265,9 @@ class Lib:
         self.check(self.dll.onssen_linear_x3p_batched_split_alt(a_img, a_bs, M, K, w_img, w_bs, bias, N, R, out, c_bs, c_s0, c_s1,
                                                                 n_split, out2, c2_bs, c2_s0, c2_s1, n_split_odd, batch, stream),
                    "onssen_linear_x3p_batched_split_alt")
+
+    def linear_x3t(self, a_img, w_img, K, M, N, zero16, Cp, ldc, stream):
+        self.check(self.dll.onssen_linear_x3t(a_img, w_img, K, M, N, zero16, Cp, ldc, stream), "onssen_linear_x3t")
 
     def lstm_wgrad_images(self, dp_img, y_img, x_img, K, B, NP, Hp, Kx, zero16, R, dW_ih, ih_bs, ih_s0, ih_s1, dW_hh, hh_bs, hh_s0,
                           hh_s1, stream):

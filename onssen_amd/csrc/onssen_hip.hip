@@ -518,6 +518,33 @@ int onssen_lstm_wgrad_images_f32(const uint16_t* dp_img, const uint16_t* y_img, 
   return ONSSEN_OK;
 }
 
+// C [M][N] (row m at C + m*ldc) = A^T W for row-major x3 images A [K][ceil(M/32)][2][32] and W [K][ceil(N/32)][2][32] (columns past
+// M / N: the images' zero padding): a weight gradient dW = dy^T x from the images of dy and x as they were made for the forward /
+// input-gradient GEMMs (linear_x3t_kernel, one problem, one segment).
+int onssen_linear_x3t(const uint16_t* a_img, const uint16_t* w_img, int K, int M, int N, const float* zero16, float* C, int64_t ldc,
+                      void* stream) {
+  if (!a_img || !w_img || !zero16 || !C || K <= 0 || M <= 0 || N <= 0 || ldc < N || (long)K * ceil_div(M, 32) * 128 > 0x7fffffffL)
+    return ONSSEN_E_ARG;
+  if (!aligned16(a_img) || !aligned16(w_img) || !aligned16(zero16)) return ONSSEN_E_ALIGN;
+  ONSSEN_CLEAR_ERROR();
+  LinearXtArgs p;
+  p.A = a_img; p.a_pitch = (long)ceil_div(M, 32) * 128; p.a_col0[0] = p.a_col0[1] = 0;
+  const long w_pitch = (long)ceil_div(N, 32) * 128;
+  const int N8 = (N + 7) & ~7;
+  for (int zz = 0; zz < 2; ++zz) {
+    p.seg[zz][0] = XtSeg{w_img, w_pitch, 0, N8, 0, N};
+    p.seg[zz][1] = XtSeg{w_img, w_pitch, 0, 0, 0, 0};
+    p.C[zz][0] = p.C[zz][1] = C;
+    p.s0[zz][0] = p.s0[zz][1] = ldc; p.s1[zz][0] = p.s1[zz][1] = 0;
+  }
+  p.zero = (const unsigned short*)zero16;
+  p.M = M; p.N = N8; p.K = K; p.R = 1; p.tile_group = 4;
+  const dim3 grid((unsigned)ceil_div(p.N, 160), (unsigned)ceil_div(p.M, 256), 1);
+  hipLaunchKernelGGL((linear_x3t_kernel<3>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* w_img, const float* bias, int N, int mode,
                            int group, float eps, const float* resid, int resid_mod, float* C, int R, int64_t c_s0,
                            int64_t c_s1, void* stream, float* inv_norm = nullptr) {
@@ -718,10 +745,10 @@ int onssen_loss_dc_f32(const float* emb, const float* one_hot, const float* mag,
 int onssen_dc_head_grad_images_f32(const float* emb, const float* inv_norm, const float* one_hot, const float* mag, int B, int T,
                                    int F, int D, int C, float eps, const float* g_per_utt, void* ws, size_t ws_bytes,
                                    uint16_t* img_rows, uint16_t* img_t, float* colsum, void* stream) {
-  if (!emb || !inv_norm || !one_hot || !mag || !g_per_utt || !ws || !img_rows || !img_t || !colsum || B <= 0 || F <= 0 || C <= 0 ||
+  if (!emb || !inv_norm || !one_hot || !mag || !g_per_utt || !ws || !img_rows || !colsum || B <= 0 || F <= 0 || C <= 0 ||
       C > 4 || D != 20 || T < 32 || !(eps > 0.0f) || (long)B * T > 0x7fffffffL / 64)
     return ONSSEN_E_ARG;
-  if (!aligned16(emb) || !aligned16(img_rows) || !aligned16(img_t)) return ONSSEN_E_ALIGN;
+  if (!aligned16(emb) || !aligned16(img_rows) || (img_t && !aligned16(img_t))) return ONSSEN_E_ALIGN;
   if (ws_bytes < onssen_loss_dc_workspace_bytes(B)) return ONSSEN_E_WORKSPACE;
   ONSSEN_CLEAR_ERROR();
   hipStream_t st = (hipStream_t)stream;

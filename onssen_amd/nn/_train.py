@@ -528,9 +528,11 @@ class DcHeadLossFunction(torch.autograd.Function):
         dev = e.device
         KB = (M + 31) // 32
         a_rows = torch.empty(M, (N + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
-        dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
         part = torch.empty(KB, N, device=dev, dtype=torch.float32)
         g = g.float().contiguous()
+        # (dW = draw^T x stays on the transposed images: onssen_linear_x3t's 256 x 160 tiles give this shape -- 2580 x 1200 -- only
+        #  88 workgroups, 266 us against 125 + 20 for the 256 x 256-tile GEMM and the transposed image of x: measured, not used)
+        dyt = torch.empty(N, KB, 2, 32, device=dev, dtype=torch.int16)
         lib.dc_head_grad_images(e.data_ptr(), inv.data_ptr(), oh.data_ptr(), mg.data_ptr(), B, T, Fq, D, C, eps, g.data_ptr(),
                                 ws.data_ptr(), ws.numel(), a_rows.data_ptr(), dyt.data_ptr(), part.data_ptr(), st)
         dx, dW = linear_x3_backward_from_images(lib, st, a_rows, dyt, x2d, w, ctx.needs_input_grad[0])

@@ -1105,6 +1105,32 @@ def test_weight_gradients_from_row_major_images(lib, H, Kx, T, B):
     np.testing.assert_allclose(ih_b[1], to_lstm(dP[:, NP:].T.astype(np.float64) @ x.astype(np.float64)), atol=3e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("K,M,N", [(70, 44, 40), (45, 300, 170)])
+def test_plain_weight_gradient_from_row_major_images(lib, K, M, N):
+    """onssen_linear_x3t: C = A^T W over the rows of two row-major x3 images (M, N not multiples of 8: the images' zero padding
+    is read, never stored) -- bit for bit what onssen_linear_x3p gives on the transposed images."""
+    rng = np.random.default_rng(K + M)
+    A, W = rand(rng, K, M), rand(rng, K, N)
+    def rows_img(m):
+        o = np.zeros((m.shape[0], (m.shape[1] + 31) // 32, 2, 32), np.uint16)
+        lib.x3_image(P(m), m.shape[1], 0, 1, m.shape[0], m.shape[1], P(o), None)
+        return o
+    def t_img(m):
+        o = np.zeros((m.shape[1], (K + 31) // 32, 2, 32), np.uint16)
+        lib.x3_image_t(P(m), m.shape[1], m.shape[1], K, 0, P(o), None)
+        return o
+    zero = np.zeros(max(M, N, 8), np.float32)
+    ref = np.full((M, N), np.nan, np.float32)
+    a_t, w_t = t_img(A), t_img(W)
+    lib.linear_x3p(P(a_t), M, K, P(w_t), P(zero), N, _abi.EPI_BIAS, 0, 0.0, P(ref), 1, N, 0, None)
+    got = np.full((M, N + 3), np.nan, np.float32)
+    a_r, w_r = rows_img(A), rows_img(W)
+    lib.linear_x3t(P(a_r), P(w_r), K, M, N, P(zero), P(got), N + 3, None)
+    np.testing.assert_array_equal(got[:, :N], ref)
+    assert np.isnan(got[:, N:]).all()
+    np.testing.assert_allclose(ref, A.T.astype(np.float64) @ W.astype(np.float64), atol=3e-4, rtol=1e-4)
+
+
 @pytest.mark.parametrize("M,tile", [(273, "256"), (150, "128")])
 def test_embedding_head_with_norms_and_its_backward(lib, M, tile, monkeypatch):
     """onssen_linear_x3p_norms (fc_dc + F.normalize in one GEMM that also leaves 1 / max(||.||, eps) per bin) and
