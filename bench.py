@@ -191,6 +191,84 @@ def extra_configs(dev):
         out["cfg4_training_step_dc_l3_b16"] = training_leg(dev)
     except Exception as e:
         out["cfg4_training_step_dc_l3_b16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    try:
+        out["batch_sweep"] = batch_sweep(dev)
+    except Exception as e:
+        out["batch_sweep"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def geometry(wl):
+    """kernel_roofline reads the STFT geometry from module globals (set by main for the headline): swap in ``wl``'s."""
+    global SR, NFFT, HOP, T_FRAMES, N_SAMPLES
+    old = (SR, NFFT, HOP, T_FRAMES, N_SAMPLES)
+    SR, NFFT, HOP, T_FRAMES, N_SAMPLES = wl["SR"], wl["NFFT"], wl["HOP"], wl["T"], wl["N"]
+    try:
+        yield
+    finally:
+        SR, NFFT, HOP, T_FRAMES, N_SAMPLES = old
+
+
+def lloyd_iterations(B, T, F, D):
+    """Lloyd passes the device 2-means of the LAST separation step of this shape actually ran, per utterance, from the
+    header of its workspace (csrc/labels_cluster.inc: word 66 of an utterance's 72-word record = passes | 0x10000 once it
+    stopped by the tolerance rule / at the fixed point; word 64 = active bins)."""
+    from onssen_amd import separation
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    keys = [k for k in separation._CLUSTER_WS if tuple(k[1:5]) == (B, T, F, D)]
+    keys.sort(key=lambda k: k not in separation._CLUSTER_PINNED)          # the captured step's buffer first
+    for key in keys[:1]:
+        ws = separation._CLUSTER_WS[key]
+        if True:
+            so = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
+            iw = ws[so - B * 72 * 4:so].view(torch.int32).view(B, 72).cpu().numpy()
+            it = (iw[:, 66] & 0xffff).astype(int)
+            return {"per_utterance": it.tolist(), "min": int(it.min()), "max": int(it.max()), "mean": float(it.mean()),
+                    "stopped_before_the_cap": int(((iw[:, 66] >> 16) & 1).sum()), "cap": 20,
+                    "active_bin_fraction": float(iw[:, 64].sum()) / float(B * T * F)}
+    return None
+
+
+def batch_sweep(dev):
+    """the roofline fraction "at the config batch and additionally as a batch sweep" -- ONE model across
+    chunk counts: the headline network (dc_l2) at 8 .. 256 chunks and cfg5's phase_net at 32 .. 128, the whole step (hipGraph
+    replay) and the recurrence kernel by itself.  ``knee`` = the smallest batch within 10 % of the best x-real-time: the
+    chunks-per-GPU to shard cfg5 / the headline at."""
+    from onssen_amd.nn._core import _XcdStatus
+    out = {}
+    for config, Bs in (("dc_l2", (8, 16, 32, 64, 128, 256)), ("phase_l4", (32, 64, 128))):
+        rows = []
+        for B in Bs:
+            try:
+                with torch.no_grad():
+                    wl = build_workload(config, B, dev, 0)
+                    run, _ = capture(wl["step"])
+                    ms = time_replays(run, 5)
+                    kind = wl["kind"]
+                    with geometry(wl):
+                        roof = kernel_roofline(wl["model"].chimera if kind == "phase_net" else wl["model"], wl["wav"], dev,
+                                               "chimera" if kind == "phase_net" else kind, wl["F"], wl["H"], wl["L"], B, wl["D"],
+                                               recurrence_only=True)
+                torch.cuda.synchronize()
+                _XcdStatus.poll(wait=True)
+                audio = B * (wl["T"] * wl["HOP"] / wl["SR"])
+                rows.append({"chunks": B, "ms_per_step": ms, "x_real_time": audio / ms * 1e3, "frames_per_s": B * wl["T"] / ms * 1e3,
+                             "recurrence_us_per_time_step": roof["us_per_time_step"], "recurrence_frac_of_peak": roof["frac"],
+                             "recurrence_launches_per_layer": roof["launches_per_step"] // wl["L"] if kind != "phase_net" else roof["launches_per_step"] // wl["L"],
+                             "recurrence_TFLOPs": roof["achieved"]})
+                del wl, run
+            except Exception as e:
+                rows.append({"chunks": B, "error": f"{type(e).__name__}: {e}"[:200]})
+            torch.cuda.empty_cache()
+        ok = [r for r in rows if "x_real_time" in r]
+        best = max((r["x_real_time"] for r in ok), default=0.0)
+        knee = next((r["chunks"] for r in ok if r["x_real_time"] >= 0.9 * best), None)
+        out[config] = {"rows": rows, "knee_chunks": knee, "best_x_real_time": best}
     return out
 
 
@@ -253,6 +331,77 @@ def ragged_leg(dev, K=16, batches=6):
             "padding_overhead": sum(K * max(ns) for _, _, ns in sets) / sum(sum(ns) for _, _, ns in sets),
             "bucketed_by_length": {"ms_per_utterance": dts / (K * batches) * 1e3, "x_real_time": audio / dts,
                                    "padding_overhead": sum(K * max(ns) for _, _, ns in sets_sorted) / sum(sum(ns) for _, _, ns in sets_sorted)}}
+
+
+def dp_training_leg(dev, rank, world, one_dev, layers=3, B=16, steps=6, warmup=3):
+    """BASELINE config 4 data parallel (every rank calls this): ``dist.train_step`` -- forward -> loss_dc -> backward with the
+    per-layer gradient buckets all-reduced over RCCL while the layers below still back-propagate -> clip -> Adam
+    (onssen/utils/train.py:75-86, the exchange between :82 and :83) -- with B chunks per rank, identical replicas, every rank
+    its own synthetic batches.  Timed twice inside the same job, each between barriers, max over ranks: with the exchange
+    (world N) and, afterwards, every rank stepping alone (world 1: no collective); the difference is the all-reduce time the
+    overlap did NOT hide.  Also checks that the replicas are still bit-identical after the data-parallel steps."""
+    import torch.distributed as dist
+    from onssen_amd import nn as onn
+    from onssen_amd.data.synthetic_wsj0_2mix import SyntheticWsj02mix
+    from onssen_amd.dist import train_step
+    from onssen_amd.loss import loss_dc
+    from onssen_amd.nn._core import _XcdStatus
+    from onssen_amd.utils import build_optimizer
+    fo = dict(batch_size=B, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40)
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    model = onn.deep_clustering(129, 600, layers, 20, dropout=0.3).to(dev).train()
+    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
+    batches = []
+    for i, b in enumerate(SyntheticWsj02mix("dc", fo, "tr", device=str(dev), num_batches=3, seed=100_000 * rank)):
+        batches.append(b)
+    torch.manual_seed(1234 + rank)                         # dropout seeds differ per replica, like independent DataLoader workers
+    cpu_or_dev = "cpu" if one_dev else dev
+
+    def timed(w):
+        for i in range(warmup):
+            train_step(model, opt, loss_dc, *batches[i % len(batches)], world=w)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = train_step(model, opt, loss_dc, *batches[i % len(batches)], world=w)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        dist.barrier()
+        torch.cuda.synchronize()
+        span = time.perf_counter() - t0
+        te = torch.tensor([mine, span, loss], device=cpu_or_dev, dtype=torch.float64)
+        every = [torch.empty_like(te) for _ in range(world)]
+        dist.all_gather(every, te)
+        return ([1e3 * float(t[0]) / steps for t in every], 1e3 * max(float(t[1]) for t in every) / steps, [float(t[2]) for t in every])
+
+    per_rank_dp, ms_dp, losses = timed(world)
+    # replicas identical after the data-parallel steps?  (a checksum of every parameter, compared across ranks)
+    with torch.no_grad():
+        chk = torch.stack([p.double().sum() for p in model.parameters()]).sum().reshape(1).to(cpu_or_dev)
+    allchk = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(allchk, chk)
+    identical = all(float(c) == float(allchk[0]) for c in allchk)
+    reducer = getattr(model, "_onssen_reducer", None)
+    buckets = [sum(p.numel() for p in ps) * 4 for ps in reducer.buckets] if reducer is not None else []
+    issued = reducer.issued_in_backward if reducer is not None else 0
+    per_rank_alone, ms_alone, _ = timed(1)                 # (replicas drift apart from here on: nothing reads them afterwards)
+    _XcdStatus.poll(wait=True)
+    grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
+    return {"workload": f"deep_clustering {layers}xBLSTM-600 DATA-PARALLEL training step, {B} x 400-frame chunks per rank x {world} ranks, "
+                        "dropout 0.3, Adam; features + labels from the HIP front end; eager launches",
+            "collective": ("gloo all-reduce (ONSSEN_BENCH_ONE_DEVICE harness self-test: every rank on cuda:0, launch-per-step kernels, "
+                           "device tensors staged through the host by gloo -- ~1.4 s per bucket measured: the timings of this mode only "
+                           "show that the leg runs, 2 steps)" if one_dev
+                           else "RCCL all-reduce(sum) of per-layer gradient buckets, issued from inside the HIP backward, before clip_grad_norm_"),
+            "ms_per_step": ms_dp, "per_rank_ms_per_step": per_rank_dp,
+            "x_real_time": world * B * 3.2 / ms_dp * 1e3, "frames_per_s": world * B * 400 / ms_dp * 1e3,
+            "ms_per_step_without_exchange": ms_alone, "per_rank_ms_per_step_without_exchange": per_rank_alone,
+            "exposed_all_reduce_ms": ms_dp - ms_alone,
+            "all_reduce_bytes_per_step": grad_bytes, "bucket_bytes": buckets, "buckets_issued_inside_backward": issued,
+            "replicas_identical_after_dp_steps": identical, "last_loss_per_rank": losses,
+            "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS")}
 
 
 def training_leg(dev, layers=3, B=16, steps=6, warmup=3):
@@ -338,6 +487,40 @@ def training_leg(dev, layers=3, B=16, steps=6, warmup=3):
             "forward_layer_with_saved_state_ms": t_fwd_layer * 1e3}
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks of ONE node under
+    ``python -m torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1, a free port) and return its exit code.
+    Rank 0's JSON line goes to this process's stdout unchanged.  With fewer than N devices the run is refused unless
+    ONSSEN_BENCH_ONE_DEVICE=1 (harness self-test: every rank on cuda:0 over gloo, launch-per-step kernels -- two processes'
+    persistent launches on one device would starve each other's exchange groups)."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    one_dev = env.get("ONSSEN_BENCH_ONE_DEVICE") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not one_dev:
+        print(f"bench.py: --gpus {n} but this node shows {have} device(s); ONSSEN_BENCH_ONE_DEVICE=1 runs the {n} ranks on "
+              "cuda:0 as a harness self-test", file=sys.stderr)
+        return 2
+    if one_dev:
+        env.setdefault("ONSSEN_XCD", "0")
+        env.setdefault("ONSSEN_DC_PERSISTENT", "0")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(n, sys.argv[1:], port)
+    print("bench.py: launching " + " ".join(cmd[1:8]) + " ...", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_command(n, argv, port):
+    """The driver's own command line for N ranks (one process per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,19 +531,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (other BASELINE configs, B = 1 latency, training step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--dp-deadline", type=float, default=300.0, help="N > 1: seconds the data-parallel training leg may take before it is abandoned")
     ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
                     help="f32 = exact-fp32 MFMA; bf16x3 = split-bf16 (3 bf16 MFMAs per fp32 product, fp32 accumulate); "
                          "bf16 = opt-in plain bf16 products (fp32 accumulate), outside the 1e-4 parity contract")
     args = ap.parse_args()
 
     os.environ["ONSSEN_PRECISION"] = args.precision
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # plain `python bench.py --gpus N`: become the launcher
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
+    import datetime
     import torch.distributed as dist
     # ONSSEN_BENCH_ONE_DEVICE=1 (harness self-test on a 1-GPU box): every rank uses cuda:0 and the gloo backend
     one_dev = os.environ.get("ONSSEN_BENCH_ONE_DEVICE") == "1"
@@ -370,10 +555,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from onssen_amd.dist import init_process_group      # RCCL with its channel count capped beside the persistent recurrences
+        kw = dict(rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         if one_dev:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            init_process_group("gloo", **kw)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            init_process_group("nccl", device_id=dev, **kw)
 
     from onssen_amd import nn as onn
     from onssen_amd.features import mask_istft, stft_logmag
@@ -415,6 +602,22 @@ def main():
             per_rank_ms = [1e3 * float(t.item()) / args.steps for t in every]
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
+
+        # ---- the clustering's work depends on the data: Lloyd passes the timed replays actually ran, and the SAME captured step
+        #      on a second input set (B distinct utterances instead of 8 tiled over the batch), outside the timed region
+        lloyd, second = None, None
+        if kind == "deep_clustering" and rank == 0:
+            lloyd = lloyd_iterations(B, T_FRAMES, F, D)
+            try:
+                keep = wav.clone()
+                wav.copy_(torch.from_numpy(synth_batch(77, B, N_SAMPLES, SR)).to(dev))
+                ms2 = time_replays(run, 10)
+                second = {"inputs": f"{B} distinct synthetic utterances (seeds 77000..)", "ms_per_step": ms2,
+                          "x_real_time": B * (T_FRAMES * HOP / SR) / ms2 * 1e3, "lloyd_iterations": lloyd_iterations(B, T_FRAMES, F, D)}
+                wav.copy_(keep)
+                run()
+            except Exception as e:
+                second = {"error": f"{type(e).__name__}: {e}"[:200]}
 
         # ---- the step of rounds 1-3 (binary masks resident in HBM instead of the clustering): a named secondary, outside
         #      the timed region, rank 0 only; captured and replayed like the headline
@@ -481,21 +684,50 @@ def main():
     result["config"]["recurrence"] = ("XCD-local persistent kernel (one launch per layer)" if recurrence_plan(B, H)[1] & 4
                                       else "one launch per time step")
     result["config"]["xcd_placement_independent_protocol_used"] = _XcdStatus.safe_protocol_seen
+    if world > 1 and not args.no_extra:
+        # ---- data-parallel training leg (the only path with a collective): every rank takes part.  The headline above is
+        #      already final; a watchdog makes sure a wedged collective can only cost this leg, never the JSON line.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                result["roofline"] = roof
+                result["dp_training_step_dc_l3_b16"] = {"error": f"did not finish within {args.dp_deadline} s (a rank stuck in a collective?)"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)                  # (the error is IN the line; peers that are stuck leave through their own watchdog)
+        dog = threading.Timer(args.dp_deadline, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            dist.barrier()               # rank 0 comes from its per-kernel timing leg: start the steps together
+            dp = dp_training_leg(dev, rank, world, one_dev, **(dict(steps=2, warmup=1) if one_dev else {}))
+        except Exception as e:
+            dp = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:400]}
+        dog.cancel()
+        result["dp_training_step_dc_l3_b16"] = dp
     if rank == 0:
         result["roofline"] = roof
         if dc_e2e is not None:
             result["resident_mask_step"] = dc_e2e
+        if lloyd is not None:
+            result["lloyd_iterations"] = lloyd
+        if second is not None:
+            result["second_input_set"] = second
+        from onssen_amd import options as _opt
+        result["config"]["non_default_options"] = {k: v["value"] for k, v in _opt.describe().items() if v["value"] != v["default"] and k != "world_size"}
         if world == 1 and not args.no_extra and args.config == "dc_l2" and args.precision == "bf16x3":
             result["extra_configs"] = extra_configs(dev)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, kind, wav_np, bin_masks.cpu().numpy())
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        if "error" in result.get("dp_training_step_dc_l3_b16", {}):
+            os._exit(0)  # this rank left the leg early: peers may sit in a collective it will never join -- do not wait for them
         dist.barrier()   # rank 0 finishes its per-kernel timing leg before anyone tears the group down
         dist.destroy_process_group()
 
 
-def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
+def kernel_roofline(model, wav, dev, kind, F, H, L, B, D, recurrence_only=False):
     """Roofline block for the dominant kernel, timed live with HIP events on the launch stream
     (each call captured in its own hipGraph and replayed, so host launch cost is excluded).
 
@@ -620,8 +852,9 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / (reps * inner) * 1e-3
 
-    t_layer, t_gin, t_g0, t_head = timed(layer), timed(gemm_in), timed(gemm0), timed(head)
-    t_img = timed(image_in) if images and lyr else 0.0         # (for lyr == 0 the split is part of gemm0 = gemm_in)
+    only_rec = recurrence_only and bool(flags & _abi.BLSTM_XCD)      # (the batch sweep times the persistent launch directly)
+    t_layer, t_gin, t_g0, t_head = (0.0,) * 4 if only_rec else (timed(layer), timed(gemm_in), timed(gemm0), timed(head))
+    t_img = timed(image_in) if images and lyr and not only_rec else 0.0         # (for lyr == 0 the split is part of gemm0 = gemm_in)
     if flags & _abi.BLSTM_XCD:
         # the recurrence kernel BY ITSELF: the same call with ONSSEN_BLSTM_G_READY -- G is what `layer` left in the workspace,
         # no split, no GEMM.  (Rounds 1-2 reported t_layer - t_gin - t_img, which overstated the kernel by ~6 %.)
@@ -633,9 +866,17 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D):
         t_rec = timed(rec_only)
     else:
         t_rec = t_layer - t_gin - t_img                        # launch-per-step forms: by difference
+    if recurrence_only:                                        # the batch sweep: the dominant kernel's numbers only
+        flop_rec = 2.0 * 2 * B * 4 * H * H * T
+        xcd = bool(flags & _abi.BLSTM_XCD)
+        launches = -(-B // 64) if xcd else T
+        peak = BF16_MFMA_PEAK_TFLOPS if bf16_only else BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
+        return {"achieved": flop_rec / t_rec / 1e12, "peak": peak, "frac": flop_rec / t_rec / 1e12 / peak,
+                "us_per_time_step": t_rec / T * 1e6, "launches_per_step": launches * L}
     # does the step fuse the first layer's projection into its recurrence launch (run_blstm's rule)?  Then layer 0 is ONE call:
     # the feature split + the fused recurrence, and the layer-0 GEMM below is not part of the step
-    fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
+    from onssen_amd import options
+    fuse_env = options.get("fuse_first_layer")
     fused0 = bool(images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)))
     t_l0f = None
     if fused0:

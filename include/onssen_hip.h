@@ -32,12 +32,18 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 10   /* 10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader).  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
 #define ONSSEN_E_WORKSPACE (-2)   /* workspace too small */
 #define ONSSEN_E_ALIGN (-3)       /* pointer / stride alignment requirement violated */
+/* onssen_wav_*: per-file status / return codes (host-side reader, no device work) */
+#define ONSSEN_WAV_TRUNCATED 1          /* the file holds more frames than the row: the first row_stride frames were read */
+#define ONSSEN_WAV_E_OPEN (-16)         /* cannot open the file */
+#define ONSSEN_WAV_E_FORMAT (-17)       /* not RIFF/WAVE, no fmt / data chunk, malformed */
+#define ONSSEN_WAV_E_UNSUPPORTED (-18)  /* sample format other than PCM 8/16/24/32-bit or IEEE float 32/64 */
+#define ONSSEN_WAV_E_SOME_FAILED (-19)  /* onssen_wav_read_batch_f32: at least one status_host[i] < 0 */
 
 /* flags of onssen_blstm_forward_f32 */
 #define ONSSEN_BLSTM_SPLIT_ROWS 1 /* 16 batch rows per recurrence workgroup instead of 32: more workgroups */
@@ -553,6 +559,22 @@ int onssen_linear_x3p_compact(const uint16_t* a_img, int M, int K, const uint16_
                               int bf16_only, void* stream);
 int onssen_dc_cluster_compact_f32(int B, int T, int F, int D, int iters, float tol, float* masks, void* ws, size_t ws_bytes,
                                   int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * H1  host side of the data front end (round 5): a batch of RIFF/WAVE files -> float32 mono rows of one host buffer.
+ * Replaces `librosa.load(fn, sr=None)` (onssen/data/feature_utils.py:15), called three times per training sample from
+ * Dataset.__getitem__ on the training thread (onssen/data/wsj0_2mix.py:114-116, num_workers 0: :28-32).  HOST pointers
+ * only; no device work, no stream.  onssen_wav_read_batch_f32 reads `count` files on up to `threads` host threads into
+ * out_host + i * row_stride (floats; a pinned buffer makes the following H2D copy one asynchronous transfer):
+ *   frames_host[i] = frames written (<= row_stride), rates_host[i] = the file's sample rate (resampling, if the rate is not
+ *   the recipe's, stays with the caller as in feature_utils.py:17-20), status_host[i] = 0 | ONSSEN_WAV_TRUNCATED | ONSSEN_WAV_E_*.
+ * Samples: PCM 8-bit (x - 128) / 128, 16-bit x / 2^15, 24-bit (left-justified in 32) and 32-bit x / 2^31, IEEE float 32 / 64
+ * -> float32; several channels -> their float32 mean (what librosa.load(mono=True) returns for these files).
+ * Returns ONSSEN_OK, ONSSEN_E_ARG, or ONSSEN_WAV_E_SOME_FAILED when a file failed (the others were still read).
+ * onssen_wav_info: the header only; bits_host < 0 marks IEEE float. */
+int onssen_wav_info(const char* path_host, int64_t* frames_host, int32_t* rate_host, int32_t* channels_host, int32_t* bits_host);
+int onssen_wav_read_batch_f32(const char* const* paths_host, int count, float* out_host, int64_t row_stride, int32_t* frames_host,
+                              int32_t* rates_host, int32_t* status_host, int threads);
 
 /* Calibration probe (not part of the separation path): n dependent launches of a near-empty kernel with
  * `workgroups` x 256 threads on `stream`; bracket it with events to measure this box's launch-boundary floor. */

@@ -102,6 +102,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #include "lstm_bwd.inc"
 #include "fft.inc"
 #include "loss_sdr.inc"
+#include "wav_io.inc"      // host code: the batch RIFF reader of the file loader
 
 // Bounded waits of the persistent kernels: ~0.2 s of polling on the GPU by default.  A run-time setting of the library
 // (onssen_xcd_spin_limit), initialised from ONSSEN_XCD_SPIN_LIMIT: the host-side emulation -- where a 'workgroup' is a
@@ -181,6 +182,10 @@ const char* onssen_error_string(int code) {
     case ONSSEN_E_ARG: return "onssen: invalid argument or unsupported shape";
     case ONSSEN_E_WORKSPACE: return "onssen: workspace too small";
     case ONSSEN_E_ALIGN: return "onssen: pointer or stride alignment requirement violated";
+    case ONSSEN_WAV_E_OPEN: return "onssen: wav file could not be opened";
+    case ONSSEN_WAV_E_FORMAT: return "onssen: not a RIFF/WAVE file, or malformed";
+    case ONSSEN_WAV_E_UNSUPPORTED: return "onssen: wav sample format not supported (PCM 8/16/24/32-bit, IEEE float 32/64)";
+    case ONSSEN_WAV_E_SOME_FAILED: return "onssen: at least one file of the batch failed (see the per-file status)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "onssen: unknown error";
   }
 }

@@ -8,7 +8,8 @@ features and labels are computed on the GPU and the yield contract is the refere
 import glob
 import os
 
-from .synthetic_wsj0_2mix import SyntheticWsj02mix
+from .. import options
+from .synthetic_wsj0_2mix import SyntheticVoicePairs, SyntheticWsj02mix
 from .wsj0_2mix import Wsj02mixFiles, read_wav, write_wav
 
 
@@ -20,10 +21,10 @@ def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
     pattern = os.path.join(path, "wav8k", "min", partition, "mix", "*.wav")
     if glob.glob(pattern):
         return Wsj02mixFiles(model_name, feature_options, partition, device)
-    if os.environ.get("ONSSEN_SYNTHETIC_DATA", "0") not in ("", "0"):
+    if options.get("synthetic_data") not in ("", "0"):
         return SyntheticWsj02mix(model_name, feature_options, partition, device)
     raise FileNotFoundError(f"wsj0_2mix_dataloader: no files match {pattern!r} (data_path is set but holds nothing for partition "
                             f"{partition!r}); pass data_path='' / 'synthetic' or set ONSSEN_SYNTHETIC_DATA=1 for the synthetic corpus")
 
 
-__all__ = ["wsj0_2mix_dataloader", "SyntheticWsj02mix", "Wsj02mixFiles", "read_wav", "write_wav"]
+__all__ = ["wsj0_2mix_dataloader", "SyntheticVoicePairs", "SyntheticWsj02mix", "Wsj02mixFiles", "read_wav", "write_wav"]

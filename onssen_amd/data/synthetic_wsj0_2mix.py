@@ -85,6 +85,53 @@ class SyntheticWsj02mix:
                 raise ValueError(f"unknown model_name {self.model_name!r}")
 
 
+class SyntheticVoicePairs:
+    """An endless deep-clustering TRAINING corpus mixed on the device (round 5): ``voices`` synthetic voices are generated once
+    on the host (``synthetic.synth_voice``) and kept in HBM; every batch pairs two different voices per chunk at a relative
+    level drawn from U(-2.5, +2.5) dB (the wsj0-2mix convention), adds the -40 dB noise floor, peak-normalises,
+    and runs the same HIP front end as ``SyntheticWsj02mix`` (one batched STFT of (mix, s1, s2), a random crop, the label
+    kernel).  Yield contract of the reference's "dc" loader (onssen/data/wsj0_2mix.py:103-158):
+    ``[feature_mix (B,L,F)] , [one_hot (B,L,F,2) float64, mag_mix (B,L,F)]``.  ``voices * (voices - 1)`` pairings x levels x crops:
+    a network cannot memorise it in a few thousand steps, and the held-out mixtures of ``synthetic.synth_mixture`` (other
+    seeds: other voices) measure generalisation.  No host work per batch: it keeps up with a 5 ms training step."""
+
+    def __init__(self, feature_options, device="cuda:0", voices=96, seed=0):
+        from ..synthetic import synth_voice
+        fo = feature_options
+        g = (lambda k: fo[k]) if isinstance(fo, dict) else (lambda k: getattr(fo, k))
+        self.batch_size, self.frame_length = int(g("batch_size")), int(g("frame_length"))
+        self.sampling_rate, self.window_size, self.hop_size = int(g("sampling_rate")), int(g("window_size")), int(g("hop_size"))
+        self.db_threshold = float(g("db_threshold"))
+        self.device = torch.device(device)
+        self.n_samples = self.hop_size * (self.frame_length + 40)
+        host = np.stack([synth_voice(500_000 + seed * 10_000 + v, self.n_samples, self.sampling_rate) for v in range(voices)])
+        self.voices = torch.from_numpy(host).to(self.device)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        B, L, V, dev, g = self.batch_size, self.frame_length, self.voices.shape[0], self.device, self.gen
+        i = torch.randint(0, V, (B,), device=dev, generator=g)
+        j = (i + torch.randint(1, V, (B,), device=dev, generator=g)) % V            # a different voice
+        level = 10.0 ** ((torch.rand(B, device=dev, generator=g) * 5.0 - 2.5) / 20.0)
+        s1, s2 = self.voices[i], self.voices[j] * level[:, None]
+        clean = s1 + s2
+        noise = torch.randn(B, self.n_samples, device=dev, generator=g) * (1e-2 * clean.std(dim=1, keepdim=True))
+        mix = clean + noise
+        scale = 0.9 / mix.abs().amax(dim=1, keepdim=True)
+        wav = torch.stack([mix * scale, s1 * scale, s2 * scale], 1).contiguous()    # (B, 3, n)
+        logmag, ri = stft_logmag(wav.view(3 * B, -1), self.window_size, self.hop_size)
+        T, F = logmag.shape[1], logmag.shape[2]
+        logmag, ri = logmag.view(B, 3, T, F), ri.view(B, 3, T, F, 2)
+        start = int(torch.randint(0, T - L, (1,), device="cpu"))
+        feat = logmag[:, 0, start:start + L].contiguous()
+        mx, a, b = (ri[:, k, start:start + L].contiguous() for k in range(3))
+        one_hot, mm = training_labels(mx, a, b, feat, self.db_threshold)[:2]
+        return [feat], [one_hot.double(), mm]
+
+
 def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
     """Same call signature as onssen.data.wsj0_2mix_dataloader (wsj0_2mix.py:26); always synthetic -- the package-level factory
     (onssen_amd.data.wsj0_2mix_dataloader) reads real files when feature_options.data_path has them."""

@@ -231,6 +231,17 @@ def init_process_group(backend="nccl", **kwargs):
             lib.dll.onssen_xcd_spin_limit(TRAIN_SPIN_LIMIT)
 
 
+def _abort_group(group=None):
+    """Tear down this rank's communicator after a failure in the middle of a step's collectives (see ``train_step``)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        from torch.distributed.distributed_c10d import _abort_process_group
+        _abort_process_group(group)
+    except Exception:             # (gloo, or a torch without the private hook: the peers' timeouts are what is left)
+        pass
+
+
 def _forward_backward(model, optimizer, loss_fn, input, label, reducer):
     from .nn import _train
     loss = None
@@ -261,12 +272,17 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
 
     An aborted persistent recurrence launch (forward or backward; ``nn/_core._XcdPolicy``) never reaches the weights: the
     status words are examined BEFORE the optimizer step; with ``world > 1`` the ranks agree on the outcome through a
-    one-element MAX all-reduce of a status code (0 = fine, 1 = somebody's persistent launch aborted, 2 = somebody hit a
-    fatal error: non-finite activations, a second abort) -- an aborted rank's garbage is already inside everybody's averaged
-    gradients --, and then EVERY rank either runs forward / backward / exchange again (the rank that aborted on the
-    launch-per-step HIP recurrences: the training path never leaves the library, round 4) or raises: no rank is left
-    waiting inside a collective for a peer that has raised.  BatchNorm's running statistics are put back before the
-    re-run; the persistent form stays enabled for the next step."""
+    one-element MAX all-reduce of a status code (0 = fine, 1 = somebody's persistent launch aborted -- or, with
+    ``nonfinite="propagate"`` / ONSSEN_NONFINITE=propagate, saw non-finite activations --, 2 = somebody hit a fatal error:
+    non-finite activations in the default ``nonfinite="raise"`` mode, a second abort) -- an aborted rank's garbage is
+    already inside everybody's averaged gradients --, and then EVERY rank either runs forward / backward / exchange again
+    (the rank that aborted on the launch-per-step HIP recurrences, which also propagate NaNs like nn.LSTM: the training
+    path never leaves the library, round 4) or raises.  That agreement covers what the status words report.  An
+    EXCEPTION thrown inside forward / backward on one rank (a library error code, a HIP runtime error) is different: this
+    rank may have issued only some of the step's bucket all-reduces, so nothing it could issue next would pair with what
+    its peers are waiting in.  It aborts its communicator (round 5) and re-raises; the peers' pending collectives then fail
+    at the process group's timeout instead of pairing with an unrelated collective or waiting forever.  BatchNorm's running
+    statistics are put back before a re-run; the persistent form stays enabled for the next step."""
     from . import _abi
     from .nn._core import XcdAborted, _XcdPolicy, _XcdStatus
     reducer = _reducer_for(model, world, group) if world > 1 else None
@@ -294,7 +310,17 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
             return e
         return None
 
-    loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+    def guarded():
+        try:
+            return _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+        except BaseException:
+            if world > 1:
+                if reducer is not None:
+                    reducer._active = False
+                _abort_group(group)
+            raise
+
+    loss_avg = guarded()
     err = examine()
     code = agree(err)
     if code == 2:
@@ -310,7 +336,7 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
                 for b, old in zip(model.buffers(), bufs):
                     b.copy_(old)
         with (_XcdPolicy.forced_steps() if err is not None else contextlib.nullcontext()):
-            loss_avg = _forward_backward(model, optimizer, loss_fn, input, label, reducer)
+            loss_avg = guarded()
         err = examine()               # a second abort (only possible on a rank that did not abort the first time) is fatal,
         if agree(err, fatal_if_aborted=True) == 2:     # ... and every rank learns of it before anybody raises
             raise err if err is not None else _abi.OnssenError("onssen_amd.train_step: another rank failed in the re-run of this step")

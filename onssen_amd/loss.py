@@ -15,6 +15,8 @@ import os
 
 import torch
 
+from . import options
+
 
 def _fro(x):
     return torch.sqrt((x * x).flatten(1).sum(dim=1))
@@ -29,7 +31,7 @@ def loss_dc(output, label):
     B, T, F, C = one_hot.shape
     D = embedding.shape[-1]
     needs_grad = torch.is_grad_enabled() and embedding.requires_grad
-    if embedding.is_cuda and D + C <= 34 and (not needs_grad or (C <= 4 and os.environ.get("ONSSEN_LOSS_HIP", "1") == "1")):
+    if embedding.is_cuda and D + C <= 34 and (not needs_grad or (C <= 4 and options.get("loss") == "1")):
         emb, oh, mag = embedding.float().contiguous(), one_hot.contiguous(), mag_mix.float().contiguous()
         if not needs_grad:
             return _loss_dc_hip(emb, oh, mag, B, T * F, D, C)
@@ -220,7 +222,7 @@ def _mask_term_hip_autograd(mask_A, mask_B, mag_mix, s1, s2, c1=None, c2=None):
 
 
 def _use_hip_mask_grad(mask_A):
-    return mask_A.is_cuda and os.environ.get("ONSSEN_LOSS_HIP", "1") == "1"
+    return mask_A.is_cuda and options.get("loss") == "1"
 
 
 def loss_chimera_msa(output, label):

@@ -11,7 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _abi
+from .. import _abi, options
 from ..hip import get_lib
 
 
@@ -27,7 +27,7 @@ def precision():
     "bf16" = OPT-IN reduced precision (BASELINE cfg2's literal dtype): plain bf16 products with fp32 accumulation in
     the XCD-form recurrence and the image GEMMs, bf16-grade results (~1e-2 relative), outside the 1e-4 parity
     contract; gates, cell state, normalisation, FFTs stay fp32."""
-    p = os.environ.get("ONSSEN_PRECISION", "bf16x3")
+    p = options.get("precision")
     if p not in ("f32", "bf16x3", "bf16"):
         raise ValueError(f"ONSSEN_PRECISION={p!r}: expected 'f32', 'bf16x3' or 'bf16'")
     return p
@@ -139,8 +139,8 @@ def recurrence_plan(B, H):
     launch per time step with 8 hidden units per workgroup (split-bf16 up to H = 640, exact fp32 above).  ONSSEN_XCD=0 forces the per-step form (so does a
     ``_XcdPolicy.forced_steps()`` scope or a back-off after consecutive aborts), ONSSEN_UG overrides its unit-group
     size, ONSSEN_ABLATE sets the profiling-only ablation bits."""
-    flags = int(os.environ.get("ONSSEN_ABLATE", "0")) << 8
-    xcd = persistent_capable(H) and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed()
+    flags = int(options.get("ablate")) << 8
+    xcd = persistent_capable(H) and options.get("recurrence") == "1" and _XcdPolicy.persistent_allowed()
     x3 = _split_bf16() and (H <= 640 or xcd)
     if x3:
         flags |= _abi.BLSTM_BF16X3
@@ -148,12 +148,13 @@ def recurrence_plan(B, H):
         # (precision f32: the same persistent launch in exact fp32 -- flags carry BLSTM_XCD without BLSTM_BF16X3)
         if precision() == "bf16":
             flags |= _abi.BLSTM_BF16
-        return 4 * -(-H // 128), flags | _abi.BLSTM_XCD
+        ug = int(options.get("recurrence_unit_group"))      # 0 = the default; 24 at H <= 640: the 25-member A/B form (round 5)
+        return (ug if ug > 0 and precision() == "bf16x3" else 4 * -(-H // 128)), flags | _abi.BLSTM_XCD
     if precision() == "bf16":
         raise RuntimeError("ONSSEN_PRECISION=bf16 exists only in the XCD-form recurrence (H <= 640, ONSSEN_XCD=1)")
-    if os.environ.get("ONSSEN_SPLIT_ROWS") == "1":
+    if options.get("split_rows") == "1":
         flags |= _abi.BLSTM_SPLIT_ROWS
-    return int(os.environ.get("ONSSEN_UG", "8")), flags
+    return int(options.get("step_unit_group")), flags
 
 
 class _XcdSerial:
@@ -171,7 +172,7 @@ class _XcdSerial:
 
     @staticmethod
     def enabled():
-        return os.environ.get("ONSSEN_XCD_SERIALIZE", "0") == "1"
+        return options.get("serialize_persistent") == "1"
 
     @classmethod
     def before(cls, device):
@@ -270,7 +271,7 @@ class _XcdStatus:
                     err = err if isinstance(err, XcdAborted) else XcdAborted(
                         f"XCD-local persistent recurrence aborted (code {int(host[0])}): a bounded wait gave up, the outputs "
                         "(and, in training, the gradients) of that call are invalid.")
-                elif os.environ.get("ONSSEN_NONFINITE", "raise") == "propagate":
+                elif options.get("nonfinite") == "propagate":
                     err = err or XcdNonFinite(
                         "non-finite activations inside the persistent recurrence: re-run on the launch-per-step recurrence, "
                         "which propagates them like nn.LSTM (ONSSEN_NONFINITE=propagate).")
@@ -348,8 +349,8 @@ class BLSTMParams(nn.Module):
         ATen's LSTM (gloo tests, CPU-only debugging): there is no HIP device to run on."""
         if x.is_cuda:
             from ._train import BLSTMTrainFunction
-            persistent = (self.hidden_size <= 768 and os.environ.get("ONSSEN_XCD", "1") == "1" and _XcdPolicy.persistent_allowed())
-            if self.hidden_size <= 768 and os.environ.get("ONSSEN_XCD", "1") == "1":
+            persistent = (self.hidden_size <= 768 and options.get("recurrence") == "1" and _XcdPolicy.persistent_allowed())
+            if self.hidden_size <= 768 and options.get("recurrence") == "1":
                 _XcdPolicy.note_launch(persistent)
             if getattr(self, "_train_packed", None) is None:
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))
@@ -379,7 +380,7 @@ def invalidate_packed_weights():
 
 def _version_key(tensors):
     key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors) + (_WEIGHT_EPOCH[0],)
-    if os.environ.get("ONSSEN_CHECK_WEIGHTS") == "1" and not torch.cuda.is_current_stream_capturing():
+    if options.get("check_weights") == "1" and not torch.cuda.is_current_stream_capturing():
         key += (float(torch.stack([t.detach().double().abs().sum() for t in tensors]).sum()),)
     return key
 
@@ -628,7 +629,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
     # measured (dc / chimera, H=600; round 3, with the x products formed in the window after the barrier): fused is 1.7 %
     # faster at B=64, 1.0 % at B=32 (it lost 2.4 % there before), 1.6 % SLOWER at B=16 -- the fused MFMAs cost every
     # time step the same, the GEMM (and the 246 MB of G) they replace shrink with the batch
-    fuse_env = os.environ.get("ONSSEN_FUSE_IN0", "auto")
+    fuse_env = options.get("fuse_first_layer")
     if frames is None and images and pk.wih_frag0 is not None and (fuse_env == "1" or (fuse_env == "auto" and B > 16)):
         flags |= _abi.BLSTM_FUSE_IN0                     # first layer's x W_ih^T inside its recurrence launch
         wih = [pk.wih_frag0] + list(wih[1:])
@@ -642,7 +643,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
                       [t.data_ptr() for t in (pk.whh_x3 if flags & _abi.BLSTM_BF16X3 else pk.whh)],
                       [t.data_ptr() for t in bias], y.data_ptr() if need_y or not images else None,
                       wsb.data_ptr(), wsb.numel(), flags, _stream(), frames=frames.data_ptr() if frames is not None else None)
-    if persistent_capable(p.hidden_size) and os.environ.get("ONSSEN_XCD", "1") == "1":
+    if persistent_capable(p.hidden_size) and options.get("recurrence") == "1":
         _XcdPolicy.note_launch(bool(flags & _abi.BLSTM_XCD))
     y.x3_image = None
     y.fp32_valid = bool(need_y or not images)
@@ -653,7 +654,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
     if flags & _abi.BLSTM_XCD:
         _XcdSerial.after(x.device)
         _XcdStatus.post(wsb)
-        if os.environ.get("ONSSEN_CHECK") == "1":      # debug / tests: synchronise and examine now
+        if options.get("check") == "1":      # debug / tests: synchronise and examine now
             _XcdStatus.flush()
     return y
 

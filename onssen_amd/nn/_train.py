@@ -14,7 +14,7 @@ import os
 import torch
 import torch.nn.functional as Fn
 
-from .. import _abi
+from .. import _abi, options
 from ..hip import get_lib
 from ._core import _XcdSerial, _XcdStatus
 
@@ -100,7 +100,7 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     # no transposed image of dP, x or y is made, and x's and y's row-major images are the persistent forward's own, still in
     # its workspace (``fwd_images``).  Bit-identical gradients; 7.25 -> 7.05 ms per training step on the same box
     rows_gemm = (direct and NP % 32 == 0 and Hp % 8 == 0 and xp.is_contiguous()
-                 and os.environ.get("ONSSEN_TRAIN_WGRAD_ROWS", "1") == "1")
+                 and options.get("train_wgrad_rows") == "1")
     a_t = None if rows_gemm else torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
     a_rows = None
     if rows_gemm:
@@ -210,7 +210,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
         B, T, In = x.shape
         if persistent and H > 768:
             raise RuntimeError("HIP training path: the persistent forward recurrence holds H <= 768")
-        ug = 4 * -(-H // 128) if persistent else int(os.environ.get("ONSSEN_UG", "8"))
+        ug = 4 * -(-H // 128) if persistent else int(options.get("step_unit_group"))
         x3 = H <= 640 or persistent
         fwd_flags = (_abi.BLSTM_XCD | _abi.BLSTM_BF16X3) if persistent else _abi.BLSTM_BF16X3 if x3 else 0
         _XcdStatus.poll()
@@ -284,14 +284,14 @@ class BLSTMTrainFunction(torch.autograd.Function):
         dy = dy_bt.transpose(0, 1).reshape(T, B, 2, H)
         dy = Fn.pad(dy, (0, Hp - H)).contiguous() if Hp != H else dy.contiguous()
         # the persistent backward launch where the forward was persistent (ONSSEN_BWD_XCD=0: one launch per time step anyway)
-        form = _abi.LSTM_BWD_XCD if ctx.persistent and H <= 640 and os.environ.get("ONSSEN_BWD_XCD", "1") == "1" else _abi.LSTM_BWD_STEPS
+        form = _abi.LSTM_BWD_XCD if ctx.persistent and H <= 640 and options.get("train_backward") == "1" else _abi.LSTM_BWD_STEPS
         wsb = _Workspace.get(("bwd", B, H, form, ug), lib.lstm_train_backward_workspace_bytes(B, H, ug, form), dev, zero=True)
         whh_img = pk.whh_bwd(form)
         grads = [None] * (8 * L)
         dx_rows = None
         # weight / input gradient contractions: the split-bf16 MFMA GEMM of this package on packed layouts, or
         # (ONSSEN_TRAIN_GEMM=blas) fp32 library GEMMs on the reference's layouts
-        use_x3 = os.environ.get("ONSSEN_TRAIN_GEMM", "x3") == "x3"
+        use_x3 = options.get("train_gemm") == "x3"
         for l in range(L - 1, -1, -1):
             xp, y, gates, cs, mask, imgs = ctx.saved_layers[l]
             # the persistent kernel also leaves sum_t dP per batch row: the bias gradient without a pass over all of dP
@@ -416,7 +416,7 @@ class LinearX3Function(torch.autograd.Function):
 
 def head_linear(lin, x):
     """nn.Linear `lin` applied to x in a training forward: the HIP GEMM on a ROCm device (ONSSEN_TRAIN_HIP=1), else ATen."""
-    if x.is_cuda and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+    if x.is_cuda and options.get("train_blstm") == "1":
         return LinearX3Function.apply(x, lin.weight, lin.bias)
     return Fn.linear(x, lin.weight, lin.bias)
 
@@ -449,7 +449,7 @@ class _L2NormRows(torch.autograd.Function):
 def l2_normalize(x, eps=1e-12):
     """F.normalize(x, p=2, dim=-1, eps) of a training forward: the HIP kernels on a ROCm device (fp32, D % 4 == 0, D <= 64), else ATen."""
     D = x.shape[-1]
-    if x.is_cuda and x.dtype == torch.float32 and D % 4 == 0 and D <= 64 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1":
+    if x.is_cuda and x.dtype == torch.float32 and D % 4 == 0 and D <= 64 and options.get("train_blstm") == "1":
         return _L2NormRows.apply(x, eps)
     return Fn.normalize(x, p=2, dim=-1, eps=eps)
 
@@ -542,16 +542,16 @@ class DcHeadLossFunction(torch.autograd.Function):
 def dc_head_loss_applies(lin, r, one_hot, D):
     """Can DcHeadLossFunction take this head / batch?  (fp32 on a ROCm device, D = 20, at most 4 speakers, >= 32 frames)"""
     return (r.is_cuda and r.dtype == torch.float32 and r.dim() == 3 and r.shape[1] >= 32 and D == 20 and lin.out_features % D == 0
-            and one_hot.shape[-1] <= 4 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"
-            and os.environ.get("ONSSEN_TRAIN_FUSED_LOSS", "1") == "1")
+            and one_hot.shape[-1] <= 4 and options.get("train_blstm") == "1"
+            and options.get("train_fused_loss") == "1")
 
 
 def head_linear_normalized(lin, x, D, eps=1e-12):
     """``F.normalize(lin(x).reshape(..., D), p=2, dim=-1, eps)`` flattened back to lin's output shape: one GEMM with the
     normalising epilogue in a training forward on a ROCm device, else head_linear + l2_normalize."""
     N = lin.out_features
-    if (x.is_cuda and x.dtype == torch.float32 and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1" and D % 4 == 0 and 80 % D == 0
-            and 80 // D <= 4 and N % D == 0 and os.environ.get("ONSSEN_TRAIN_FUSED_NORM", "1") == "1"):
+    if (x.is_cuda and x.dtype == torch.float32 and options.get("train_blstm") == "1" and D % 4 == 0 and 80 % D == 0
+            and 80 // D <= 4 and N % D == 0 and options.get("train_fused_norm") == "1"):
         return LinearNormalizeFunction.apply(x, lin.weight, lin.bias, D, eps)
     y = head_linear(lin, x)
     return l2_normalize(y.reshape(*y.shape[:-1], N // D, D), eps).reshape(y.shape)
@@ -599,7 +599,7 @@ def batch_norm_rows(bn, r):
     C = r.shape[-1]
     x2 = r.reshape(-1, C)
     if (bn.training and r.is_cuda and r.dtype == torch.float32 and bn.affine and bn.track_running_stats and x2.shape[0] > 1
-            and os.environ.get("ONSSEN_TRAIN_HIP", "1") == "1"):
+            and options.get("train_blstm") == "1"):
         y, mean, invstd = _BnRowsTrain.apply(x2, bn.weight, bn.bias, float(bn.eps))
         with torch.no_grad():
             M = x2.shape[0]

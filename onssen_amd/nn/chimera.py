@@ -2,6 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import options
 from ._train import head_linear, head_linear_normalized
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, EPI_SIGMOID,
                     as_frames, heads_take_image, require_device, run_blstm, run_head, run_head_pair, use_hip_path)
@@ -14,8 +15,9 @@ class chimera(PackedWeightsMixin, nn.Module):
     the masks are strided views of one (B,T,F,C) buffer exactly as upstream.
     """
 
-    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, num_speaker=2):
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, num_speaker=2, **hip_options):
         super().__init__()
+        options.constructor_options(type(self).__name__, hip_options)      # optional config keys (precision, recurrence, ...)
         self.input_dim, self.hidden_dim = input_dim, hidden_dim
         self.num_layers, self.embedding_dim, self.num_speaker = num_layers, embedding_dim, num_speaker
         self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))

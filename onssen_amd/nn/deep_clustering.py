@@ -2,6 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import options
 from ._train import batch_norm_rows, head_linear_normalized
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM,
                     as_frames, heads_take_image, require_device, run_blstm, run_head, use_hip_path)
@@ -17,8 +18,9 @@ class deep_clustering(PackedWeightsMixin, nn.Module):
     into the fc_dc GEMM whose epilogue normalises each bin).
     """
 
-    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3):
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, **hip_options):
         super().__init__()
+        options.constructor_options(type(self).__name__, hip_options)      # optional config keys (precision, recurrence, ...)
         self.input_dim, self.hidden_dim = input_dim, hidden_dim
         self.num_layers, self.embedding_dim = num_layers, embedding_dim
         self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))

@@ -1,6 +1,8 @@
 import torch
 import torch.nn as nn
 
+from .. import options
+
 from ._train import batch_norm_rows
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_RELU, EPI_SIGMOID, _stream, _version_key,
                     heads_take_image, require_device, run_blstm, run_head, use_hip_path)
@@ -17,8 +19,9 @@ class enhance(PackedWeightsMixin, nn.Module):
     folded into fc_mi); the two F x F "restoration" layers are exact-fp32 GEMMs whose epilogue applies the ReLU and,
     for fc_pre, the multiplication by the mask (ONSSEN_EPI_RELU)."""
 
-    def __init__(self, input_dim, hidden_dim=300, num_layers=3, dropout=0.3):
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, dropout=0.3, **hip_options):
         super().__init__()
+        options.constructor_options(type(self).__name__, hip_options)      # optional config keys (precision, recurrence, ...)
         self.input_dim, self.hidden_dim, self.num_layers = input_dim, hidden_dim, num_layers
         self.add_module("rnn", BLSTMParams(input_dim, hidden_dim, num_layers, dropout))
         self.add_module("bn", nn.BatchNorm1d(hidden_dim * 2))

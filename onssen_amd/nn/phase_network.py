@@ -2,6 +2,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import options
 from ..hip import get_lib
 from ._train import batch_norm_rows
 from ._core import (PackedWeightsMixin, needs_graph, BLSTMParams, PackedBLSTM, PackedHead, _Workspaces, EPI_L2NORM, _stream,
@@ -21,8 +22,9 @@ class phase_net(PackedWeightsMixin, nn.Module):
         [embedding, mask_A, mask_B, phase_A (B,T,F,2), phase_B (B,T,F,2)]
     """
 
-    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, num_speaker=2):
+    def __init__(self, input_dim, hidden_dim=300, num_layers=3, embedding_dim=20, dropout=0.3, num_speaker=2, **hip_options):
         super().__init__()
+        options.constructor_options(type(self).__name__, hip_options)      # optional config keys (precision, recurrence, ...)
         self.input_dim, self.hidden_dim, self.num_speaker = input_dim, hidden_dim, num_speaker
         chimera_net = chimera(input_dim, hidden_dim, num_layers, embedding_dim, dropout, num_speaker)
         self.add_module("rnn", BLSTMParams(input_dim * 3, hidden_dim, num_layers, dropout))

@@ -6,6 +6,7 @@ with the device->host->device hop removed for the mask-inference models."""
 import numpy as np
 import torch
 
+from . import options
 from .features import mask_istft, stft_logmag
 from .nn._core import _XcdStatus, recovering
 
@@ -32,30 +33,43 @@ def separate_chimera(model, wav, window_size=256, hop_size=64, lengths=None):
     return out
 
 
-_CLUSTER_WS = {}
-_CLUSTER_SCRATCH = {}      # device -> grow-only buffer of the ragged / shape-changing calls (see dc_masks)
+_CLUSTER_WS = {}           # (device, B, T, F, D[, "compact"], stream) -> buffer of a uniform shape
+_CLUSTER_SCRATCH = {}      # (device, stream) -> grow-only buffer of the ragged / shape-changing calls (see dc_masks)
+_CLUSTER_PINNED = set()    # keys of _CLUSTER_WS handed out for / during a hipGraph capture: never evicted
 
 
 def _cluster_ws(device, key, nb, head, ragged):
-    """Workspace of the clustering back end.  Uniform shapes: one buffer per shape (hipGraph-capturable), most recently used
-    last, at most 8.  Ragged batches bring a new longest utterance every time: ONE grow-only buffer per device.  Either way
-    it is allocated uninitialised and only its first ``head`` bytes (centroids, counters, the status word -- everything in front
-    of the compacted array, which is as large as the embedding and is written before it is read) are zeroed."""
+    """Workspace of the clustering back end, private to the calling STREAM (round 5: every call rewrites the header --
+    centroids, counters, the status word -- so two streams of one process separating at once must not share a buffer; work
+    on one stream is ordered and reuses its own).  Uniform shapes: one buffer per (shape, stream) (hipGraph-capturable),
+    most recently used last, at most 8 that no graph points into.  Ragged batches bring a new longest utterance every time:
+    ONE grow-only buffer per (device, stream).  Either way it is allocated uninitialised and only its first ``head`` bytes
+    (the library's ``comp_offset``: everything in front of the compacted array, which is as large as the embedding and is
+    written before it is read) are zeroed."""
     capturing = torch.cuda.is_current_stream_capturing()
+    stream = torch.cuda.current_stream(device).cuda_stream
     if ragged:
         if capturing:
             raise RuntimeError("dc_masks: ragged batches (frames=...) cannot be captured in a hipGraph (shared grow-only workspace)")
-        ws = _CLUSTER_SCRATCH.get(device)
+        ws = _CLUSTER_SCRATCH.get((device, stream))
         if ws is None or ws.numel() < nb:
-            ws = _CLUSTER_SCRATCH[device] = torch.empty(max(nb, int(nb * 1.25)), dtype=torch.uint8, device=device)
+            ws = _CLUSTER_SCRATCH[(device, stream)] = torch.empty(max(nb, int(nb * 1.25)), dtype=torch.uint8, device=device)
         ws[:head].zero_()                  # (the status word of an earlier call was examined by _XcdStatus before this one is issued)
         return ws
+    if capturing:
+        # a capture replays on whatever stream the graph is launched on: the buffer of the eager warm-up call of this shape
+        # (any stream) is the one to capture, and from then on it belongs to the graph
+        hit = next((k for k in _CLUSTER_WS if k[:-1] == key), None)
+        if hit is None:
+            raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
+        _CLUSTER_PINNED.add(hit)
+        return _CLUSTER_WS[hit]
+    key = key + (stream,)
     ws = _CLUSTER_WS.pop(key, None)
     if ws is None:
-        if capturing:
-            raise RuntimeError("dc_masks: call it once eagerly for this shape before capturing it in a hipGraph (workspace allocation)")
-        while len(_CLUSTER_WS) >= 8:
-            _CLUSTER_WS.pop(next(iter(_CLUSTER_WS)))
+        loose = [k for k in _CLUSTER_WS if k not in _CLUSTER_PINNED]
+        while len(loose) >= 8:
+            _CLUSTER_WS.pop(loose.pop(0))
         ws = torch.empty(nb, dtype=torch.uint8, device=device)
         ws[:head].zero_()                  # status word starts out zero
     _CLUSTER_WS[key] = ws
@@ -81,7 +95,7 @@ def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=No
     D = getattr(model, "embedding_dim", 0)
     if (not isinstance(model, deep_clustering) or not use_hip_path(model) or F != model.input_dim or precision() == "f32"
             or (frames is not None and precision() == "bf16")
-            or os.environ.get("ONSSEN_DC_PERSISTENT", "1") != "1" or os.environ.get("ONSSEN_DC_COMPACT", "1") != "1"
+            or options.get("dc_cluster") != "1" or options.get("dc_compact") != "1"
             or _XcdPolicy.force_steps != 0 or not heads_take_image(B, model.hidden_dim, (D,)) or D > 32):
         return None
     lib = get_lib()
@@ -132,8 +146,9 @@ def dc_masks(emb, logmag, db_threshold=40.0, iters=20, frames=None, tol=1e-4):
     B, T, F, D = emb.shape
     emb, logmag = emb.contiguous(), logmag.contiguous()
     nb = int(lib.dll.onssen_dc_cluster_workspace_bytes(B, T, F, D))
-    ws = _cluster_ws(emb.device, (emb.device, B, T, F, D), nb, nb - B * T * F * D * 4, frames is not None)
-    persistent = os.environ.get("ONSSEN_DC_PERSISTENT", "1") == "1" and _XcdPolicy.force_steps == 0
+    head = lib.dc_compact_layout(B, T, F, D)[1]        # the library's own offset of the compacted array = the header's size
+    ws = _cluster_ws(emb.device, (emb.device, B, T, F, D), nb, head, frames is not None)
+    persistent = options.get("dc_cluster") == "1" and _XcdPolicy.force_steps == 0
     masks = torch.empty(B, T, F, 2, device=emb.device, dtype=torch.float32)
     if frames is not None:
         from .features import _lengths_i32

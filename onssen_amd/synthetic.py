@@ -97,6 +97,13 @@ def _speaker(rng, n, sr):
     return sig * env * gate
 
 
+def synth_voice(seed, n_samples, sr=8000):
+    """One synthetic voice by itself (unit standard deviation, float32): the building block of ``synth_mixture``, for
+    corpora that pair voices on the fly (``onssen_amd.data.synthetic_wsj0_2mix.SyntheticVoicePairs``)."""
+    v = _speaker(np.random.default_rng(seed), n_samples, sr)
+    return (v / (np.std(v) + 1e-9)).astype(np.float32)
+
+
 def synth_mixture(seed, n_samples=25536, sr=8000, return_sources=False):
     """2-speaker mixture, float32 in [-1, 1], peak 0.9.  25 536
     samples at hop 64 give exactly 400 STFT frames."""

@@ -6,6 +6,8 @@ import os
 
 import torch
 
+from . import options
+
 
 class AttrDict(dict):
     """Dictionary whose keys are also attributes, nested -- what ``attrdict.AttrDict`` gives the reference's run.py
@@ -35,7 +37,7 @@ def build_optimizer(params, optimizer_options):
     if name == "adam":
         # same update rule; on a GPU the whole step is ONE multi-tensor kernel instead of ~10 (ONSSEN_FUSED_ADAM=0: torch's default)
         params = list(params)
-        fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("ONSSEN_FUSED_ADAM", "1") == "1"
+        fused = bool(params) and all(p.is_cuda for p in params) and options.get("fused_adam") == "1"
         return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
     if name == "sgd":
         return torch.optim.SGD(params, lr=lr, momentum=0.9)

@@ -74,3 +74,71 @@ def test_recipe_flow_from_config_on_the_gpu(monkeypatch):
         args.checkpoint_path = None
         sdr = tester_cls(args).eval()
         assert sdr == sdr and -60.0 < sdr < 60.0                        # random weights: a finite, unremarkable SI-SDR
+
+
+# ---------------------------------------------------------------- optional hip_options keys (round 5; onssen_amd/options.py)
+@pytest.fixture
+def clean_options(monkeypatch):
+    from onssen_amd import options
+    for env, *_ in options.TABLE.values():
+        monkeypatch.delenv(env, raising=False)
+    saved = dict(options._configured)
+    options._configured.clear()
+    yield options
+    options._configured.clear()
+    options._configured.update(saved)
+
+
+def test_reference_configs_load_unchanged_and_set_nothing(clean_options):
+    """The reference's own config files carry none of the optional keys: they load as before and leave every switch at its default."""
+    for cfg in ("config_dc.json", "config_chimera_psa.json"):
+        args = load(cfg)
+        kwargs = clean_options.apply_config(args)
+        assert kwargs == dict(args["model_options"])
+    assert all(v["source"] == "default" for v in clean_options.describe().values())
+    assert clean_options.get("precision") == "bf16x3" and clean_options.get("recurrence") == "1"
+
+
+def test_optional_keys_in_the_config_select_the_switches(clean_options, monkeypatch):
+    args = load("config_dc.json")
+    args["hip_options"] = {"precision": "f32", "recurrence": "steps", "dc_cluster": "steps", "fused_adam": False}
+    args["model_options"]["fuse_first_layer"] = "auto"                 # the same keys may sit in model_options ...
+    kwargs = clean_options.apply_config(args)
+    assert "fuse_first_layer" not in kwargs and kwargs["hidden_dim"] == 600        # ... and are stripped for the constructor
+    assert clean_options.get("precision") == "f32" and clean_options.get("recurrence") == "0"
+    assert clean_options.get("dc_cluster") == "0" and clean_options.get("fused_adam") == "0"
+    from onssen_amd.nn._core import precision
+    assert precision() == "f32"
+    # the constructors accept them too: nn.deep_clustering(**args['model_options']) keeps working with the extra keys
+    m = onn.deep_clustering(129, 32, 2, 20, precision="bf16x3")
+    assert clean_options.get("precision") == "bf16x3" and m.hidden_dim == 32
+    with pytest.raises(TypeError, match="unexpected keyword argument 'hiden_dim'"):
+        onn.deep_clustering(129, hiden_dim=32)
+    with pytest.raises(ValueError, match="precision"):
+        clean_options.configure(precision="fp8")
+    # an environment variable that is set wins over the config (the operator's override for one run)
+    monkeypatch.setenv("ONSSEN_PRECISION", "f32")
+    assert clean_options.get("precision") == "f32" and clean_options.describe()["precision"]["source"] == "env"
+
+
+def test_stated_world_size_must_match_the_launcher(clean_options, monkeypatch):
+    args = load("config_dc.json")
+    args["hip_options"] = {"world_size": 8}
+    with pytest.raises(RuntimeError, match="world_size = 8"):
+        clean_options.apply_config(args)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    clean_options.apply_config(args)
+
+
+def test_every_onssen_switch_read_by_the_package_is_in_the_table():
+    """No stray ``os.environ.get("ONSSEN_...")`` in the product path: one table, one resolution order."""
+    import re
+    root = os.path.join(os.path.dirname(HERE), "onssen_amd")
+    stray = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py") and f != "options.py":
+                for m in re.finditer(r'environ(?:\.get)?[\[(]\s*"(ONSSEN_[A-Z0-9_]+)"', open(os.path.join(d, f)).read()):
+                    if m.group(1) not in ("ONSSEN_HIP_LIB",):             # where the library lives: read before anything else exists
+                        stray.append((f, m.group(1)))
+    assert not stray, stray
