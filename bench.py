@@ -192,6 +192,10 @@ def extra_configs(dev):
     except Exception as e:
         out["cfg4_training_step_dc_l3_b16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     try:
+        out["trained_weights_dc_l2_b32"] = trained_leg(dev)
+    except Exception as e:
+        out["trained_weights_dc_l2_b32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    try:
         out["batch_sweep"] = batch_sweep(dev)
     except Exception as e:
         out["batch_sweep"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -270,6 +274,61 @@ def batch_sweep(dev):
         knee = next((r["chunks"] for r in ok if r["x_real_time"] >= 0.9 * best), None)
         out[config] = {"rows": rows, "knee_chunks": knee, "best_x_real_time": best}
     return out
+
+
+def trained_leg(dev, B=32, steps=1000):
+    """The headline step on a TRAINED network (the headline itself runs random-init weights of the named architecture: there
+    is no checkpoint in the image).  The clustering's cost depends on the embeddings: a random-init network gives 2-means
+    nothing to find (15-17 Lloyd passes of the 20 allowed), a trained one converges in 5-6.  So: ``steps`` optimizer steps of
+    dc_l2 on the synthetic voice-pair corpus with the package's own training step (~5 s), then the SAME captured step as the
+    headline on B held-out synthetic mixtures; reports its time, the Lloyd passes it ran and the SI-SDR of what it separated
+    (egs/wsj0-2mix/deep_clustering/evaluate.py:31-45; tools/trained_probe.py is the long form)."""
+    from onssen_amd import nn as onn
+    from onssen_amd.data import SyntheticVoicePairs
+    from onssen_amd.dist import train_step
+    from onssen_amd.evaluate import batch_SDR_torch
+    from onssen_amd.features import mask_istft, stft_logmag
+    from onssen_amd.loss import loss_dc
+    from onssen_amd.nn._core import _XcdStatus
+    from onssen_amd.separation import dc_masks, dc_masks_from_features
+    from onssen_amd.synthetic import synth_mixture
+    from onssen_amd.utils import build_optimizer
+    F, H, L, D, n = 129, 600, 2, 20, 25536
+    torch.manual_seed(0)
+    model = onn.deep_clustering(F, H, L, D, dropout=0.3).to(dev).train()
+    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
+    data = SyntheticVoicePairs(dict(batch_size=16, frame_length=400, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40), device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [train_step(model, opt, loss_dc, *next(data)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    model.eval()
+    trips = [synth_mixture(910_000 + u, n, 8000, return_sources=True) for u in range(B)]      # held out: other seeds, other voices
+    wav = torch.from_numpy(np.stack([t[0] for t in trips])).to(dev)
+    ref = torch.from_numpy(np.stack([np.stack(t[1:]) for t in trips])).to(dev)
+
+    def step():
+        logmag, ri = stft_logmag(wav, 256, 64)
+        masks = dc_masks_from_features(model, logmag)
+        if masks is None:
+            e, = model([logmag])
+            masks = dc_masks(e, logmag)
+        return mask_istft(ri, masks, 64, n)
+    with torch.no_grad():
+        run, _ = capture(step)
+        ms = time_replays(run, 10)
+        sig = step()
+        sdr = batch_SDR_torch(sig, ref)
+        sdr_mix = batch_SDR_torch(torch.stack([wav, wav], 1), ref)
+    torch.cuda.synchronize()
+    _XcdStatus.poll(wait=True)
+    return {"workload": f"the headline step (dc_l2, {B} x 400-frame chunks, hipGraph replay) with weights from {steps} training steps on the "
+                        "synthetic voice-pair corpus, on held-out synthetic mixtures",
+            "training": {"steps": steps, "seconds": train_s, "ms_per_step_with_corpus": train_s / steps * 1e3,
+                         "loss_first_100": float(np.mean(losses[:100])), "loss_last_100": float(np.mean(losses[-100:]))},
+            "ms_per_step": ms, "x_real_time": B * 3.2 / ms * 1e3, "lloyd_iterations": lloyd_iterations(B, 400, F, D),
+            "si_sdr_db": {"separated_mean": float(sdr.mean()), "separated_min": float(sdr.min()), "mixture_mean": float(sdr_mix.mean())}}
 
 
 def ragged_leg(dev, K=16, batches=6):
@@ -392,8 +451,7 @@ def dp_training_leg(dev, rank, world, one_dev, layers=3, B=16, steps=6, warmup=3
     return {"workload": f"deep_clustering {layers}xBLSTM-600 DATA-PARALLEL training step, {B} x 400-frame chunks per rank x {world} ranks, "
                         "dropout 0.3, Adam; features + labels from the HIP front end; eager launches",
             "collective": ("gloo all-reduce (ONSSEN_BENCH_ONE_DEVICE harness self-test: every rank on cuda:0, launch-per-step kernels, "
-                           "device tensors staged through the host by gloo -- ~1.4 s per bucket measured: the timings of this mode only "
-                           "show that the leg runs, 2 steps)" if one_dev
+                           "device tensors staged through the host by gloo: the timings of this mode only show that the leg runs, 2 steps)" if one_dev
                            else "RCCL all-reduce(sum) of per-layer gradient buckets, issued from inside the HIP backward, before clip_grad_norm_"),
             "ms_per_step": ms_dp, "per_rank_ms_per_step": per_rank_dp,
             "x_real_time": world * B * 3.2 / ms_dp * 1e3, "frames_per_s": world * B * 400 / ms_dp * 1e3,

@@ -6,6 +6,7 @@ imports torch, so the same binding drives the product library
 (tests/emu, host pointers).
 """
 import ctypes as C
+import os
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
@@ -78,6 +79,8 @@ SIGNATURES = {
     "onssen_debug_launch_chain": (_i, [_vp, _i, _i, _vp]),
     "onssen_debug_cotenant_spin": (_i, [_i, _i, C.c_longlong, _i, _vp]),
     "onssen_xcd_spin_limit": (C.c_longlong, [C.c_longlong]),
+    "onssen_wav_info": (_i, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "onssen_wav_read_batch_f32": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i64, _vp, _vp, _vp, _i]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_dc_cluster_status_offset": (_sz, [_i, _i]),
@@ -144,6 +147,22 @@ class Lib:
 
     def lstm_pack_wih_bf16x3(self, w_ih, in_dim, H, ug, out, stream):
         self.check(self.dll.onssen_lstm_pack_wih_bf16x3(w_ih, in_dim, H, ug, out, stream), "onssen_lstm_pack_wih_bf16x3")
+
+    # ---- host-side wav reader (no device work) ---------------------------
+    def wav_info(self, path):
+        """(frames, rate, channels, bits) of a RIFF/WAVE file's header; bits < 0 marks IEEE float."""
+        fr, rate, ch, bits = _i64(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.check(self.dll.onssen_wav_info(os.fsencode(path), fr, rate, ch, bits), f"onssen_wav_info({path!r})")
+        return fr.value, rate.value, ch.value, bits.value
+
+    def wav_read_batch(self, paths, out_ptr, row_stride, frames_ptr, rates_ptr, status_ptr, threads):
+        """Read ``paths`` into rows of a host float32 buffer (see include/onssen_hip.h).  Returns the library's code: 0, or
+        ONSSEN_WAV_E_SOME_FAILED (-19) with the per-file status telling which; other codes raise."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        rc = self.dll.onssen_wav_read_batch_f32(arr, len(paths), out_ptr, row_stride, frames_ptr, rates_ptr, status_ptr, threads)
+        if rc not in (0, -19):
+            self.check(rc, "onssen_wav_read_batch_f32")
+        return rc
 
     def batch_sdr_workspace_bytes(self, B):
         return int(self.dll.onssen_batch_sdr_workspace_bytes(B))

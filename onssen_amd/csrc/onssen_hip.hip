@@ -1191,6 +1191,7 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     const unsigned xcd_spin = xcd_spin_limit();
     static const int ablate_env = ONSSEN_KNOB_INT("ONSSEN_BWD_ABLATE", 0);
     static const int delay_env = ONSSEN_KNOB_INT("ONSSEN_BWD_DELAY", 0);
+    static const bool bwd_unstacked = ONSSEN_KNOB_INT("ONSSEN_BWD_UNSTACKED", 0) != 0;      // debug builds: the three-term form of rounds 2-4, for A/B
     XcdBwdArgs xa;
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
@@ -1209,9 +1210,13 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
       xa.nbg = ceil_div(rows, xa.RG);
 #define ONSSEN_BWD_UG(UG_)                                                                                   \
   do {                                                                                                       \
-    if (parts == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 4>), grid, dim3(512), 0, st, xa);            \
-    else if (parts == 2) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 2>), grid, dim3(512), 0, st, xa);       \
-    else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1>), grid, dim3(512), 0, st, xa);                       \
+    if (xa.RG <= 8 && !bwd_unstacked) {                                                                      \
+      if (parts == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 4, true>), grid, dim3(512), 0, st, xa);     \
+      else if (parts == 2) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 2, true>), grid, dim3(512), 0, st, xa);\
+      else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, true>), grid, dim3(512), 0, st, xa);                \
+    } else if (parts == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 4, false>), grid, dim3(512), 0, st, xa); \
+    else if (parts == 2) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 2, false>), grid, dim3(512), 0, st, xa); \
+    else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, false>), grid, dim3(512), 0, st, xa);                 \
   } while (0)
       switch (ug) {
         case 4: ONSSEN_BWD_UG(4); break;

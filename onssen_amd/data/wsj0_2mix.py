@@ -2,10 +2,13 @@
 
 ``wsj0_2mix_dataloader(model_name, feature_options, partition, device)`` of the reference (onssen/data/wsj0_2mix.py:26-37)
 globs ``<data_path>/wav8k/min/<partition>/mix/*.wav`` (``:78-79``), reads mix / s1 / s2 with librosa / torchaudio and computes
-three host STFTs, a random ``frame_length`` crop and the label features per sample (``:103-158``).  Here the files are read on
-the host (``read_wav``: RIFF PCM 8/16/24/32-bit and IEEE float, what ``librosa.load(fn, sr=None)`` returns for them: float32,
-channels averaged) and everything after that runs on the GPU: one STFT launch per utterance for (mix, s1, s2)
-(``onssen_stft_logmag_f32``), the crop, and ONE label-kernel launch per batch (``onssen_labels_f32``).  Same
+three host STFTs, a random ``frame_length`` crop and the label features per sample (``:103-158``) on the training thread
+(``num_workers`` 0, ``:28-32``).  Here (round 5) a producer thread keeps ``loader_prefetch`` batches in flight: the library's
+batch reader (``onssen_wav_read_batch_f32``, csrc/wav_io.inc: RIFF PCM 8/16/24/32-bit and IEEE float -> float32, channels
+averaged -- what ``librosa.load(fn, sr=None)`` returns for them, and bit for bit what ``read_wav`` below returns) fills one
+pinned buffer with the batch's 3 x batch_size signals on ``loader_workers`` host threads; the training thread then issues ONE
+host-to-device transfer, ONE ragged STFT launch for all of them (``onssen_stft_logmag_ragged_f32``), two gathers for the crops
+and ONE label-kernel launch (``onssen_labels_f32``).  Same
 ``feature_options`` keys, same list layouts per ``model_name`` as the synthetic loader next door (and the reference):
 
     "dc"        [feature_mix] , [one_hot, mag_mix]
@@ -72,6 +75,37 @@ def _load(fn, sampling_rate):
     return sig
 
 
+class _Slot:
+    """One (pinned) host buffer of the loader's ring: ``rows`` signals of ``stride`` float32 samples, contiguous (so that the
+    batch goes to the device in ONE plain transfer), + the reader's per-file outputs.  ``release()`` (consumer, after it
+    queued its H2D copy) records an event; ``wait()`` (producer, before refilling) waits for it."""
+
+    def __init__(self, pin, numel=48 * 8000 * 8):
+        self.pin = pin
+        self.event = None
+        self.buf = torch.empty(numel, dtype=torch.float32, pin_memory=pin)
+        self.frames = self.rates = self.status = torch.zeros(0, dtype=torch.int32)
+
+    def shape(self, rows, stride):
+        """The (rows, stride) view of the buffer (reallocated, 25 % larger, when it does not fit)."""
+        if rows * stride > self.buf.numel():
+            self.buf = torch.empty(int(rows * stride * 1.25), dtype=torch.float32, pin_memory=self.pin)
+        if rows > self.frames.numel():
+            self.frames, self.rates, self.status = (torch.zeros(rows, dtype=torch.int32) for _ in range(3))
+        self.wav = self.buf[:rows * stride].view(rows, stride)
+        return self.wav
+
+    def release(self):
+        if self.pin:
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def wait(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+
+
 class Wsj02mixFiles:
     """Iterable over ``(input_list, label_list)`` batches of one partition; ``len()`` = number of batches."""
 
@@ -89,6 +123,7 @@ class Wsj02mixFiles:
         self.file_list = sorted(glob.glob(os.path.join(g("data_path"), "wav8k", "min", partition, "mix", "*.wav")))
         self.shuffle = (partition != "tt") if shuffle is None else shuffle
         self.rng = np.random.default_rng(seed)      # seed=None: fresh entropy, like the reference's unseeded np.random
+        self._headers = {}                          # path -> (frames, rate): see _frames_of
 
     def __len__(self):
         n = len(self.file_list)
@@ -110,28 +145,131 @@ class Wsj02mixFiles:
             sig_ref = torch.from_numpy(np.stack([pad(s1), pad(s2)])[None]).to(self.device)
             yield [logmag], [ri[..., 0].contiguous(), ri[..., 1].contiguous(), sig_ref]
 
-    def _utterance(self, fn):
-        """(3, T', F) log-magnitude and (3, T', F, 2) spectrum of (mix, s1, s2), repeated to more than frame_length frames, cropped."""
-        sigs = [_load(f, self.sampling_rate) for f in self._sources(fn)]
-        n = min(len(s) for s in sigs)
-        wav = torch.from_numpy(np.stack([s[:n] for s in sigs])).to(self.device)
-        logmag, ri = stft_logmag(wav, self.window_size, self.hop_size)
-        T, L = logmag.shape[1], self.frame_length
-        if T <= L:                                   # "pad in a double-copy fashion" (wsj0_2mix.py:118-123)
-            times = L // T + 1
-            logmag, ri = logmag.repeat(1, times, 1), ri.repeat(1, times, 1, 1)
-        start = int(self.rng.integers(0, logmag.shape[1] - L))
-        return logmag[:, start:start + L], ri[:, start:start + L]
+    # ---- training partitions: a producer thread reads whole batches into pinned buffers, the consumer makes ONE transfer,
+    #      ONE ragged STFT launch and two gathers per batch (round 5; the reference does three librosa.load + three host STFTs
+    #      per SAMPLE on the training thread: wsj0_2mix.py:103-158 with num_workers 0, :28-32)
+    def _frames_of(self, path):
+        """(frames, rate) from the file's header, remembered across epochs (the rows of a batch are sized before it is read)."""
+        hit = self._headers.get(path)
+        if hit is None:
+            from ..hip import get_lib
+            fr, rate, _, _ = get_lib().wav_info(path)
+            hit = self._headers[path] = (fr, rate)
+        return hit
+
+    def _read_batch(self, files, slot):
+        """Host side of one batch: the 3 x len(files) signals (mix, s1, s2 per utterance) into the rows of ``slot`` by the
+        library's batch reader (csrc/wav_io.inc, ``loader_workers`` host threads, no Python per sample), per-utterance sample
+        counts, and the crops the seeded generator draws -- in file order, as the per-utterance loop of rounds 1-4 drew them.
+        Returns (slot, n_utt (B,) int32, starts (B,) int64)."""
+        from .. import options
+        from ..hip import get_lib
+        lib = get_lib()
+        paths = [p for fn in files for p in self._sources(fn)]
+        heads = [self._frames_of(p) for p in paths]
+        sr = self.sampling_rate
+        # a file at another rate is resampled on the host (feature_utils.get_stft:17-20 resamples instead of failing): its row
+        # must hold whichever of the two lengths is longer
+        need = max(max(fr, -(-fr * sr // rate)) for fr, rate in heads)
+        stride = -(-need // 64) * 64
+        wav = slot.shape(len(paths), stride)
+        rc = lib.wav_read_batch(paths, wav.data_ptr(), stride, slot.frames.data_ptr(), slot.rates.data_ptr(),
+                                slot.status.data_ptr(), max(1, int(options.get("loader_workers"))))
+        status = slot.status[:len(paths)].numpy()
+        if rc != 0 or status.any():                               # (truncation cannot happen: the rows were sized from the headers)
+            bad = int(np.argmax(status != 0))
+            raise OSError(f"{paths[bad]}: {lib.dll.onssen_error_string(int(status[bad])).decode()} (status {int(status[bad])})")
+        frames = slot.frames[:len(paths)].numpy().copy()
+        for r in np.nonzero(slot.rates[:len(paths)].numpy() != sr)[0]:
+            from math import gcd
+            from scipy.signal import resample_poly
+            rate = int(slot.rates[r])
+            g = gcd(rate, sr)
+            sig = resample_poly(wav[r, :frames[r]].numpy(), sr // g, rate // g).astype(np.float32)[:stride]
+            wav[r, :len(sig)] = torch.from_numpy(sig)
+            frames[r] = len(sig)
+        n_utt = frames.reshape(-1, 3).min(axis=1).astype(np.int32)
+        L, hop = self.frame_length, self.hop_size
+        starts = np.empty(len(files), np.int64)
+        for b, n in enumerate(n_utt):
+            T = 1 + int(n) // hop
+            times = L // T + 1 if T <= L else 1                   # "pad in a double-copy fashion" (wsj0_2mix.py:118-123)
+            starts[b] = int(self.rng.integers(0, T * times - L))
+        return slot, n_utt, starts
+
+    def _device_batch(self, item):
+        """Device side of one batch: (B, 3, L, F) log-magnitude and (B, 3, L, F, 2) spectrum of (mix, s1, s2), cropped."""
+        slot, n_utt, starts = item
+        B, L, hop = len(n_utt), self.frame_length, self.hop_size
+        wav = slot.wav.to(self.device, non_blocking=True)               # ONE contiguous transfer from the pinned buffer
+        slot.release()                                                  # the producer may refill it once that copy has run
+        lengths = torch.from_numpy(np.repeat(n_utt, 3))
+        logmag, ri = stft_logmag(wav, self.window_size, self.hop_size, lengths=lengths)      # ONE ragged launch for the 3B signals
+        T, F = logmag.shape[1], logmag.shape[2]
+        Tb = 1 + n_utt.astype(np.int64) // hop
+        idx = torch.from_numpy((starts[:, None] + np.arange(L)[None, :]) % Tb[:, None]).to(self.device)   # wraps: the repeated utterance
+        rows = torch.arange(B, device=self.device)[:, None, None]
+        trip = torch.arange(3, device=self.device)[None, :, None]
+        return logmag.view(B, 3, T, F)[rows, trip, idx[:, None, :]], ri.view(B, 3, T, F, 2)[rows, trip, idx[:, None, :]]
+
+    def host_batches(self, order=None, ring=None):
+        """Generator over the HOST side of the epoch's batches (``_read_batch`` items), synchronously on the calling thread."""
+        if order is None:
+            order = self.rng.permutation(len(self.file_list)) if self.shuffle else np.arange(len(self.file_list))
+        ring = ring or [_Slot(self.device.type == "cuda")]
+        for k, i0 in enumerate(range(0, len(order), self.batch_size)):
+            slot = ring[k % len(ring)]
+            slot.wait()
+            yield self._read_batch([self.file_list[i] for i in order[i0:i0 + self.batch_size]], slot)
+
+    def _prefetched(self, order):
+        """``host_batches`` run ahead of the consumer by ``loader_prefetch`` batches on a producer thread (``loader_workers``
+        = 0: on the calling thread, nothing in flight)."""
+        import queue
+        import threading
+        from .. import options
+        depth, workers = int(options.get("loader_prefetch")), int(options.get("loader_workers"))
+        if workers <= 0 or depth <= 0:
+            yield from self.host_batches(order)
+            return
+        ring = [_Slot(self.device.type == "cuda") for _ in range(depth + 2)]    # queue + the one being filled + the one being copied
+        q, stop = queue.Queue(maxsize=depth), threading.Event()
+
+        def produce():
+            try:
+                for item in self.host_batches(order, ring):
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:             # reported by the consumer, on the training thread
+                q.put(e)
+        th = threading.Thread(target=produce, name="onssen-wsj0-2mix-loader", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=5.0)
 
     def __iter__(self):
         if self.partition == "tt":
             yield from self._iter_eval()
             return
         order = self.rng.permutation(len(self.file_list)) if self.shuffle else np.arange(len(self.file_list))
-        for i0 in range(0, len(order), self.batch_size):
-            items = [self._utterance(self.file_list[i]) for i in order[i0:i0 + self.batch_size]]
-            logmag = torch.stack([it[0] for it in items])          # (B, 3, L, F)
-            ri = torch.stack([it[1] for it in items])              # (B, 3, L, F, 2)
+        for item in self._prefetched(order):
+            logmag, ri = self._device_batch(item)                   # (B, 3, L, F), (B, 3, L, F, 2)
             feat = logmag[:, 0].contiguous()
             mix, s1, s2 = (ri[:, i].contiguous() for i in range(3))
             out = training_labels(mix, s1, s2, feat, self.db_threshold, with_cos=self.model_name == "chimera++")

@@ -133,3 +133,73 @@ def test_eval_partition_from_files_and_tester(tmp_path):
     t = tester_dc(dict(model_name="dc", model=model, test_loader=dl, device="cuda:0"), hop_size=64)
     sdr = t.eval()
     assert np.isfinite(sdr)
+
+
+def test_native_batch_reader_matches_read_wav_bit_for_bit(tmp_path):
+    """onssen_wav_read_batch_f32 / onssen_wav_info (csrc/wav_io.inc; host code, runs without a GPU) against ``read_wav`` (scipy)
+    on every sample format the loader accepts, a missing file and a row that is too short."""
+    import struct
+    from scipy.io import wavfile
+    from onssen_amd import _abi
+    from onssen_amd.hip import get_lib
+    lib = get_lib()
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(5000) * 0.2).astype(np.float32)
+    p = lambda n: str(tmp_path / n)
+    write_wav(p("pcm16.wav"), x, 8000)
+    write_wav(p("f32.wav"), x[:3001], 16000, "FLOAT")
+    wavfile.write(p("stereo.wav"), 8000, np.stack([x, -0.5 * x], 1))
+    wavfile.write(p("pcm32.wav"), 8000, (x * 2 ** 31).astype(np.int32))
+    wavfile.write(p("u8.wav"), 8000, np.clip(np.rint(x * 128 + 128), 0, 255).astype(np.uint8))
+    wavfile.write(p("f64.wav"), 8000, x.astype(np.float64))
+    wavfile.write(p("three.wav"), 8000, np.stack([(x * 2e4).astype(np.int16), (x * 1e4).astype(np.int16), (x * 3e3).astype(np.int16)], 1))
+    v = (np.clip(x, -1, 1) * (2 ** 23 - 1)).astype(np.int32)
+    raw = np.stack([v & 255, (v >> 8) & 255, (v >> 16) & 255], 1).astype(np.uint8).tobytes()
+    with open(p("pcm24.wav"), "wb") as f:       # with an odd-sized LIST chunk in front of the data, like files in the wild
+        f.write(b"RIFF" + struct.pack("<I", 36 + 8 + 6 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 1, 8000, 24000, 3, 24)
+                + b"LIST" + struct.pack("<I", 5) + b"abcde\x00" + b"data" + struct.pack("<I", len(raw)) + raw)
+    names = ["pcm16.wav", "f32.wav", "stereo.wav", "pcm32.wav", "u8.wav", "f64.wav", "three.wav", "pcm24.wav", "missing.wav"]
+    paths = [p(n) for n in names]
+    n, stride = len(paths), 5056
+    out = torch.full((n, stride), float("nan"))
+    fr, rt, st = (torch.zeros(n, dtype=torch.int32) for _ in range(3))
+    rc = lib.wav_read_batch(paths, out.data_ptr(), stride, fr.data_ptr(), rt.data_ptr(), st.data_ptr(), 3)
+    assert rc == -19 and st.tolist() == [0] * 8 + [-16] and fr[8] == 0
+    for i, path in enumerate(paths[:-1]):
+        ref, rate = read_wav(path)
+        assert rt[i] == rate and fr[i] == len(ref), names[i]
+        assert np.array_equal(out[i, :len(ref)].numpy(), ref), names[i]
+        assert lib.wav_info(path)[:2] == (len(ref), rate)
+    assert lib.wav_info(paths[2])[2:] == (2, -32) and lib.wav_info(paths[7])[2:] == (1, 24)
+    rc = lib.wav_read_batch(paths[:1], out.data_ptr(), 100, fr.data_ptr(), rt.data_ptr(), st.data_ptr(), 1)       # the row is too short
+    assert rc == 0 and st[0] == _abi.WAV_TRUNCATED and fr[0] == 100
+    (tmp_path / "junk.wav").write_bytes(b"not a wave file at all")
+    with pytest.raises(_abi.OnssenError, match="RIFF"):
+        lib.wav_info(p("junk.wav"))
+
+
+def test_host_side_of_the_training_batches(tmp_path):
+    """The producer's half of a training batch without a GPU: signals (one file at 16 kHz: resampled like _load does), per-
+    utterance sample counts and the seeded crops in file order -- the sequence the per-utterance loop of rounds 1-4 drew."""
+    from onssen_amd.data.wsj0_2mix import _load
+    lengths = [64 * 70 + 13, 64 * 25, 64 * 55 + 7]
+    make_corpus(str(tmp_path), "tr", lengths)
+    mix16 = synth_mixture(77, 9000, 16000)                        # utt01's mixture at another rate (s1 / s2 stay at 8 kHz)
+    write_wav(os.path.join(str(tmp_path), "wav8k", "min", "tr", "mix", "utt01.wav"), mix16, 16000)
+    fo = dict(FO, data_path=str(tmp_path))
+    dl = Wsj02mixFiles("dc", fo, "tr", device="cpu", shuffle=False, seed=11)
+    items = [(slot.wav.clone(), n_utt.copy(), starts.copy()) for slot, n_utt, starts in dl.host_batches()]
+    assert [len(it[1]) for it in items] == [2, 1]
+    rng = np.random.default_rng(11)
+    k = 0
+    for wav, n_utt, starts in items:
+        for b in range(len(n_utt)):
+            fn = dl.file_list[k]; k += 1
+            sigs = [_load(f, 8000) for f in dl._sources(fn)]
+            n = min(len(s) for s in sigs)
+            assert n_utt[b] == n
+            for j in range(3):
+                np.testing.assert_array_equal(wav[3 * b + j, :n].numpy(), sigs[j][:n])
+            T = 1 + n // 64
+            Tr = T * (40 // T + 1) if T <= 40 else T
+            assert starts[b] == int(rng.integers(0, Tr - 40))

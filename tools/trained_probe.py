@@ -117,6 +117,41 @@ def evaluate(model, dev, n_utt=16, seed0=900_000, log=print):
     return mean, rows
 
 
+def routes(model, dev, B=32, n=25536, log=print):
+    """The same trained network through every inference route at the HEADLINE's shape (B chunks of 400 frames): whole batch
+    with the fused first layer (default above 16 rows), unfused, launch-per-step recurrence, exact fp32, one chunk per
+    forward, and the compacted clustering route (no embedding round trip) -- SI-SDR of each and the largest embedding
+    difference against the batch-1 forwards."""
+    from onssen_amd import options
+    from onssen_amd.evaluate import batch_SDR_torch
+    from onssen_amd.features import mask_istft, stft_logmag
+    from onssen_amd.separation import dc_masks, dc_masks_from_features
+    from onssen_amd.synthetic import synth_mixture
+    model.eval()
+    trips = [synth_mixture(910_000 + u, n, 8000, return_sources=True) for u in range(B)]
+    wav = torch.from_numpy(np.stack([t[0] for t in trips])).to(dev)
+    ref = torch.from_numpy(np.stack([np.stack(t[1:]) for t in trips])).to(dev)
+    out = {}
+    with torch.no_grad():
+        logmag, ri = stft_logmag(wav, 256, 64)
+        one = torch.cat([model([logmag[b:b + 1].contiguous()])[0] for b in range(B)])
+        def sdr_of(masks):
+            return float(batch_SDR_torch(mask_istft(ri, masks, 64, n), ref).mean())
+        out["one_chunk_per_forward"] = {"si_sdr": sdr_of(torch.cat([dc_masks(one[b:b + 1].contiguous(), logmag[b:b + 1].contiguous()) for b in range(B)]))}
+        for name, opts in (("batch_default", {}), ("batch_unfused", {"fuse_first_layer": "0"}), ("batch_steps", {"recurrence": "steps"}),
+                           ("batch_f32", {"precision": "f32"})):
+            old = options.configure(**opts)
+            emb, = model([logmag])
+            out[name] = {"si_sdr": sdr_of(dc_masks(emb, logmag)), "max_abs_diff_vs_one_chunk_forwards": float((emb - one).abs().max())}
+            options.configure(**{k: old[k] for k in opts})
+        mk = dc_masks_from_features(model, logmag)
+        out["batch_compact_route"] = {"si_sdr": sdr_of(mk) if mk is not None else None}
+        out["mixture"] = {"si_sdr": float(batch_SDR_torch(torch.stack([wav, wav], 1), ref).mean())}
+    for k, v in out.items():
+        log(f"  route {k:24s} {v}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
@@ -125,6 +160,7 @@ def main():
     ap.add_argument("--eval", type=int, default=16)
     ap.add_argument("--checkpoints", default="0,500", help="also evaluate after these step counts (comma separated)")
     ap.add_argument("--save", default="", help="write the trained state_dict here (torch.save)")
+    ap.add_argument("--routes", action="store_true", help="after training: the same network through every inference route at B = 32 x 400 frames")
     args = ap.parse_args()
     from onssen_amd import nn as onn
     from onssen_amd.nn._core import _XcdStatus
@@ -147,6 +183,9 @@ def main():
               f"min {100 * mean['min_agree_device_sklearn']:.3f} % of the active bins, max |SI-SDR gap| {mean['max_abs_sdr_gap_device_sklearn']:.3f} dB | "
               f"Lloyd passes mean {mean['lloyd_passes']:.1f}")
         out["checkpoints"].append({"steps": done, "mean": mean, "rows": rows})
+    if args.routes:
+        print("--- inference routes on the trained network (32 x 400-frame chunks, held out)")
+        out["routes"] = routes(model, dev)
     _XcdStatus.flush()
     if args.save:
         torch.save({"model": model.state_dict()}, args.save)
