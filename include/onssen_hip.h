@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader).  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -137,6 +137,14 @@ int onssen_lstm_geometry(int H, int ug, int* Hp, int* NP, int* KQ, int64_t* whh_
  */
 int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int in_dim,
                          int bidir_in, int H, int ug, float* wih_p, float* whh_p, float* bias_p, void* stream);
+
+/* (round 5) One direction's packed W_ih, its bias and the x3 image of the packed matrix in ONE pass: what onssen_lstm_pack_f32's
+ * wih_p / bias_p and onssen_x3_image_f32(wih_p, ...) give, bit for bit, without the fp32 whh image nobody reads on the persistent
+ * training path.  The training forward re-packs every step (the optimizer moves the weights between two forwards), so
+ * the pack is part of the training step (onssen/utils/train.py:75-86).  wih_img: this direction's NP rows of the
+ * [2*NP][ceil(K/32)][2][32] image (K = in_dim, or 2*Hp with bidir_in), 16-byte aligned. */
+int onssen_lstm_pack_wih_image_f32(const float* w_ih, const float* b_ih, const float* b_hh, int in_dim, int bidir_in, int H, int ug,
+                                   float* wih_p, float* bias_p, uint16_t* wih_img, void* stream);
 
 /* Split-bf16 image of one direction's W_hh (see ONSSEN_BLSTM_BF16X3): hi = bf16(w), lo = bf16(w - hi), in
  * v_mfma_f32_16x16x32_bf16 B-fragment order [NU][KQ2][ug/4][hi|lo][64][8], KQ2 = ceil(Hp/32). */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "onssen_lstm_pack_whh_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_wih_bf16x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "onssen_lstm_pack_wih_image_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_linear_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
@@ -224,6 +225,10 @@ class Lib:
     def lstm_pack(self, w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p, bias_p, stream):
         self.check(self.dll.onssen_lstm_pack_f32(w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p,
                                                  bias_p, stream), "onssen_lstm_pack_f32")
+
+    def lstm_pack_wih_image(self, w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream):
+        self.check(self.dll.onssen_lstm_pack_wih_image_f32(w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream),
+                   "onssen_lstm_pack_wih_image_f32")
 
     def head_pack(self, w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream):
         self.check(self.dll.onssen_head_pack_f32(w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream),

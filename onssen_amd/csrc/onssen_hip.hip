@@ -297,6 +297,22 @@ int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih
   return ONSSEN_OK;
 }
 
+int onssen_lstm_pack_wih_image_f32(const float* w_ih, const float* b_ih, const float* b_hh, int in_dim, int bidir_in, int H, int ug,
+                                   float* wih_p, float* bias_p, uint16_t* wih_img, void* stream) {
+  int Hp, NP;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK) return ONSSEN_E_ARG;
+  if (!w_ih || !b_ih || !b_hh || !wih_p || !bias_p || !wih_img || in_dim <= 0) return ONSSEN_E_ARG;
+  if (bidir_in && in_dim != 2 * H) return ONSSEN_E_ARG;
+  if (!aligned16(wih_img)) return ONSSEN_E_ALIGN;
+  const int Kp = bidir_in ? 2 * Hp : ceil_div(in_dim, 4) * 4, K = bidir_in ? 2 * Hp : in_dim, KB = ceil_div(K, 32);
+  ONSSEN_CLEAR_ERROR();
+  const long n = (long)NP * KB * 4;
+  hipLaunchKernelGGL(pack_wih_image_kernel, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w_ih, b_ih, b_hh, in_dim, bidir_in, H, Hp, ug, Kp, K, KB, wih_p, bias_p, wih_img);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 int onssen_head_pack_f32(const float* w, const float* b, int N, int H, int Hp, const float* bn_gamma,
                          const float* bn_beta, const float* bn_mean, const float* bn_var, float bn_eps, float* w_p,
                          float* b_p, void* stream) {

@@ -342,4 +342,6 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
             raise err if err is not None else _abi.OnssenError("onssen_amd.train_step: another rank failed in the re-run of this step")
     torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     optimizer.step()
+    from .nn._core import invalidate_packed_weights
+    invalidate_packed_weights()          # (a fused optimizer moves the parameters without bumping their versions)
     return float(loss_avg.item())

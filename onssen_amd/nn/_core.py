@@ -370,11 +370,19 @@ def invalidate_packed_weights():
     """Drop every packed weight image of the process (they are rebuilt from the live parameters at the next forward).
 
     The packed images are keyed on (data_ptr, tensor._version, device) of their source parameters.  In-place updates
-    through autograd-visible ops (optimizer steps, ``p.copy_()``, ``load_state_dict``) bump ``_version`` and are seen;
-    updates through ``p.data`` (``p.data.add_()``, EMA / weight-averaging code, hand-written checkpoint loaders) change
-    neither the version nor the pointer -- call this (or ``module.repack()``) after such an update.  ``load_state_dict``
-    and ``module.to()/.float()/...`` call it themselves; ``ONSSEN_CHECK_WEIGHTS=1`` adds a device-side checksum of the
-    parameters to the key (one synchronisation per forward: a debugging aid that finds forgotten calls)."""
+    through autograd-visible ops (``p.copy_()``, ``load_state_dict``, the for-loop / foreach optimizers) bump ``_version``
+    and are seen; updates through ``p.data`` (``p.data.add_()``, EMA / weight-averaging code, hand-written checkpoint
+    loaders) change neither the version nor the pointer -- call this (or ``module.repack()``) after such an update.
+    **FUSED optimizers do not bump it either** (round 5, measured on torch 2.10 + ROCm: ``torch.optim.Adam(fused=True)``
+    leaves ``_version`` at 1 after 300 steps; ``tools/micro/train_then_eval_diag.py``) -- and ``build_optimizer`` returns one.
+    Rounds 3-4 therefore trained with the BLSTM images of step 0 in every forward (only the heads, whose training GEMMs
+    split their weights per call, learned), and an eval-mode forward after training used whichever images an earlier
+    eval-mode forward had left.  Since round 5 nothing relies on the version alone where the weights are expected to
+    move: the training forward rebuilds its images every step (``PackedBLSTM.get(force=True)``), every optimizer from
+    ``build_optimizer`` and ``dist.train_step`` call this after ``step()``, and switching a model between ``train()`` and
+    ``eval()`` calls it.  ``load_state_dict`` and ``module.to()/.float()/...`` call it themselves;
+    ``ONSSEN_CHECK_WEIGHTS=1`` adds a device-side checksum of the parameters to the key (one synchronisation per forward: a
+    debugging aid that finds forgotten calls)."""
     _WEIGHT_EPOCH[0] += 1
 
 
@@ -397,6 +405,11 @@ class PackedWeightsMixin:
         invalidate_packed_weights()
         return out
 
+    def train(self, mode=True):                     # .train() / .eval(): the weights may have moved under any optimizer since
+        if bool(mode) != self.training:
+            invalidate_packed_weights()
+        return super().train(mode)
+
     def repack(self):
         """Rebuild the packed weight images from the live parameters at the next forward."""
         invalidate_packed_weights()
@@ -413,11 +426,14 @@ class PackedBLSTM:
         self.p = params
         self.cache = {}     # ug -> packed images (a batch-size class can prefer another unit-group size)
 
-    def get(self, ug):
+    def get(self, ug, force=False, lean=False):
+        """``force``: rebuild whatever the version key says (the training forward: its parameters change every step, and a
+        fused optimizer changes them WITHOUT bumping ``_version`` -- see invalidate_packed_weights).  ``lean``: only the
+        images the persistent training path reads (no split planes of W_ih, no first-layer fragment image)."""
         img = self.cache.get(ug)
         if img is None:
             img = self.cache[ug] = _PackedImages(self.p, ug)
-        return img.get()
+        return img.get(force, lean)
 
 
 class _PackedImages:
@@ -426,11 +442,11 @@ class _PackedImages:
         self.key = None
         self._whhT = None
 
-    def get(self):
+    def get(self, force=False, lean=False):
         p, lib = self.p, get_lib()
         flat = p.flat_weights()
-        key = _version_key(flat)
-        if key == self.key:
+        key = _version_key(flat) + (bool(lean),)
+        if key == self.key and not force:
             return self
         dev = flat[0].device
         H, L = p.hidden_size, p.num_layers
@@ -444,27 +460,34 @@ class _PackedImages:
             in_l = p.input_size if l == 0 else 2 * H
             Kp = (in_l + 3) // 4 * 4 if l == 0 else 2 * self.Hp
             a = torch.empty(2, self.NP, Kp, device=dev, dtype=torch.float32)
-            b = torch.empty(2, we, device=dev, dtype=torch.float32)
+            b = None if lean else torch.empty(2, we, device=dev, dtype=torch.float32)
             c = torch.empty(2, self.NP, device=dev, dtype=torch.float32)
+            K_l = in_l if l == 0 else 2 * self.Hp
+            ai = torch.empty(2 * self.NP, (K_l + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
             for d in range(2):
                 w_ih, w_hh, b_ih, b_hh = [t.detach().contiguous() for t in flat[(2 * l + d) * 4:(2 * l + d) * 4 + 4]]
-                lib.lstm_pack(w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), in_l,
-                              0 if l == 0 else 1, H, self.ug, a[d].data_ptr(), b[d].data_ptr(), c[d].data_ptr(), st)
+                if lean:     # the per-step pack of the training forward: packed W_ih + bias + its x3 image in one pass, no fp32 W_hh image
+                    lib.lstm_pack_wih_image(w_ih.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), in_l, 0 if l == 0 else 1, H, self.ug,
+                                            a[d].data_ptr(), c[d].data_ptr(), ai[d * self.NP:].data_ptr(), st)
+                else:
+                    lib.lstm_pack(w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), in_l,
+                                  0 if l == 0 else 1, H, self.ug, a[d].data_ptr(), b[d].data_ptr(), c[d].data_ptr(), st)
             b3 = torch.empty(2, we3, device=dev, dtype=torch.int16)
             for d in range(2):
                 w_hh = flat[(2 * l + d) * 4 + 1].detach().contiguous()
                 lib.lstm_pack_whh_bf16x3(w_hh.data_ptr(), H, self.ug, b3[d].data_ptr(), st)
             ld = (in_l if l == 0 else 2 * self.Hp)
             ld = (ld + 31) // 32 * 32
-            a3 = torch.empty(2, 2 * self.NP, ld, device=dev, dtype=torch.int16)     # hi plane, lo plane
-            lib.linear_pack_bf16x3(a.data_ptr(), 2 * self.NP, in_l if l == 0 else 2 * self.Hp, Kp, ld, a3.data_ptr(), st)
+            a3 = None
+            if not lean:     # (the launch-per-step split-bf16 GEMM's operand: the persistent path reads the x3 image below)
+                a3 = torch.empty(2, 2 * self.NP, ld, device=dev, dtype=torch.int16)     # hi plane, lo plane
+                lib.linear_pack_bf16x3(a.data_ptr(), 2 * self.NP, in_l if l == 0 else 2 * self.Hp, Kp, ld, a3.data_ptr(), st)
             # x3 image of the same matrix (ONSSEN_BLSTM_XCD form: pre-split operands, onssen_linear_x3p)
-            K_l = in_l if l == 0 else 2 * self.Hp
-            ai = torch.empty(2 * self.NP, (K_l + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
-            lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
+            if not lean:
+                lib.x3_image(a.data_ptr(), Kp, 0, 1, 2 * self.NP, K_l, ai.data_ptr(), st)
             self.wih.append(a), self.whh.append(b), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(a3)
             self.wih_img.append(ai)
-            if l == 0 and in_l <= 129 and self.ug <= 20:   # fragment image for the fused first-layer input projection (FUSE_IN0: <= 4 MFMA k-chunks)
+            if l == 0 and in_l <= 129 and self.ug <= 20 and not lean:   # fragment image for the fused first-layer input projection (FUSE_IN0: <= 4 MFMA k-chunks)
                 kc = (in_l + 31) // 32
                 f0 = torch.empty(2, (self.Hp // self.ug) * kc * (self.ug // 4) * 1024, device=dev, dtype=torch.int16)
                 for d in range(2):

@@ -214,7 +214,9 @@ class BLSTMTrainFunction(torch.autograd.Function):
         x3 = H <= 640 or persistent
         fwd_flags = (_abi.BLSTM_XCD | _abi.BLSTM_BF16X3) if persistent else _abi.BLSTM_BF16X3 if x3 else 0
         _XcdStatus.poll()
-        pk = packed.get(ug)
+        # the images are rebuilt EVERY training forward when a parameter may move (an optimizer changes them between two
+        # forwards; a fused one does it without bumping their versions: see invalidate_packed_weights)
+        pk = packed.get(ug, force=any(t.requires_grad for t in flat), lean=bool(persistent))
         Hp, NP = pk.Hp, pk.NP
         st = torch.cuda.current_stream().cuda_stream
         dev = x.device
@@ -264,6 +266,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
                 saved.append((xp, y, gates, cs, None, imgs))
         ctx.saved_layers = saved
         ctx.packed, ctx.ug, ctx.dims, ctx.p_drop, ctx.persistent = packed, ug, (B, T, In, H, L, Hp, NP), p_drop, bool(persistent)
+        ctx.pk = pk
         ctx.flat = flat
         return y[..., :H].reshape(T, B, 2 * H).transpose(0, 1).contiguous()
 
@@ -276,7 +279,7 @@ class BLSTMTrainFunction(torch.autograd.Function):
                                "overwritten in place by the backward recurrence (retain_graph / double backward are not supported)")
         dy_bt = dy_bt.float()
         B, T, In, H, L, Hp, NP = ctx.dims
-        ug, pk = ctx.ug, ctx.packed.get(ctx.ug)
+        ug, pk = ctx.ug, ctx.pk          # the images this graph's forward ran on (nothing moves the weights between the two)
         st = torch.cuda.current_stream().cuda_stream
         dev = dy_bt.device
         flat = ctx.flat

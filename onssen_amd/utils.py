@@ -32,15 +32,21 @@ class AttrDict(dict):
 
 
 def build_optimizer(params, optimizer_options):
-    """onssen/utils/basic.py:5-11: ``{"name": "adam" | "sgd" | "rmsprop", "lr": ...}``."""
+    """onssen/utils/basic.py:5-11: ``{"name": "adam" | "sgd" | "rmsprop", "lr": ...}``.  Every optimizer returned drops the
+    package's packed weight images after ``step()`` (a fused step moves the parameters without bumping their versions:
+    ``nn._core.invalidate_packed_weights``)."""
     name, lr = optimizer_options["name"], optimizer_options["lr"]
     if name == "adam":
         # same update rule; on a GPU the whole step is ONE multi-tensor kernel instead of ~10 (ONSSEN_FUSED_ADAM=0: torch's default)
         params = list(params)
         fused = bool(params) and all(p.is_cuda for p in params) and options.get("fused_adam") == "1"
-        return torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
-    if name == "sgd":
-        return torch.optim.SGD(params, lr=lr, momentum=0.9)
-    if name == "rmsprop":
-        return torch.optim.RMSprop(params, lr=lr)
-    raise ValueError(f"unknown optimizer {name!r}")
+        opt = torch.optim.Adam(params, lr=lr, fused=True) if fused else torch.optim.Adam(params, lr=lr)
+    elif name == "sgd":
+        opt = torch.optim.SGD(params, lr=lr, momentum=0.9)
+    elif name == "rmsprop":
+        opt = torch.optim.RMSprop(params, lr=lr)
+    else:
+        raise ValueError(f"unknown optimizer {name!r}")
+    from .nn._core import invalidate_packed_weights
+    opt.register_step_post_hook(lambda optimizer, args, kwargs: invalidate_packed_weights())
+    return opt

@@ -142,3 +142,23 @@ def test_every_onssen_switch_read_by_the_package_is_in_the_table():
                     if m.group(1) not in ("ONSSEN_HIP_LIB",):             # where the library lives: read before anything else exists
                         stray.append((f, m.group(1)))
     assert not stray, stray
+
+
+def test_packed_images_are_dropped_when_weights_may_have_moved():
+    """A fused optimizer moves parameters without bumping ``_version`` (measured on the GPU box; the bug of rounds 3-4): the packed
+    weight images must not rely on it.  ``build_optimizer``'s step hook and a train()/eval() switch bump the global epoch that is
+    part of every image's key."""
+    from onssen_amd.nn import _core
+    model = onn.deep_clustering(129, 8, 1, 4)
+    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    e0 = _core._WEIGHT_EPOCH[0]
+    opt.step()
+    assert _core._WEIGHT_EPOCH[0] == e0 + 1
+    model.eval()
+    assert _core._WEIGHT_EPOCH[0] == e0 + 2
+    model.eval()                                   # no change of mode: nothing dropped
+    assert _core._WEIGHT_EPOCH[0] == e0 + 2
+    model.train()
+    assert _core._WEIGHT_EPOCH[0] == e0 + 3

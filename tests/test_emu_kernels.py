@@ -1250,3 +1250,24 @@ def test_bn_rows_train_forward_and_gradient(lib, M, C):
     lib.bn_rows_train(P(x2), M, C, P(gamma), P(beta), 0.0, P(y), P(mean), P(invstd), P(ws), ws.nbytes, None)
     np.testing.assert_allclose(mean, x2.astype(np.float64).mean(0), rtol=1e-6)
     np.testing.assert_allclose(1 / invstd.astype(np.float64) ** 2, x2.astype(np.float64).var(0), rtol=2e-4)
+
+
+@pytest.mark.parametrize("H,ug,in_dim,bidir", [(10, 4, 9, 0), (24, 8, 129, 0), (24, 8, 48, 1), (40, 20, 80, 1), (30, 4, 60, 1)])
+def test_wih_pack_with_image_in_one_pass(lib, H, ug, in_dim, bidir):
+    """onssen_lstm_pack_wih_image_f32 (round 5: the training forward's per-step pack) == onssen_lstm_pack_f32's packed W_ih and bias
+    + onssen_x3_image_f32 of the packed matrix, bit for bit."""
+    rng = np.random.default_rng(H + in_dim)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    Kp = 2 * Hp if bidir else (in_dim + 3) // 4 * 4
+    K = 2 * Hp if bidir else in_dim
+    KB = (K + 31) // 32
+    w_ih, w_hh = rand(rng, 4 * H, in_dim), rand(rng, 4 * H, H)
+    b_ih, b_hh = rand(rng, 4 * H), rand(rng, 4 * H)
+    a0, b0, c0 = np.full((NP, Kp), np.nan, np.float32), np.zeros(we, np.float32), np.full(NP, np.nan, np.float32)
+    lib.lstm_pack(P(w_ih), P(w_hh), P(b_ih), P(b_hh), in_dim, bidir, H, ug, P(a0), P(b0), P(c0), None)
+    img0 = np.zeros((NP, KB, 2, 32), np.uint16)
+    lib.x3_image(P(a0), Kp, 0, 1, NP, K, P(img0), None)
+    a1, c1 = np.full((NP, Kp), np.nan, np.float32), np.full(NP, np.nan, np.float32)
+    img1 = np.full((NP, KB, 2, 32), 0xffff, np.uint16)
+    lib.lstm_pack_wih_image(P(w_ih), P(b_ih), P(b_hh), in_dim, bidir, H, ug, P(a1), P(c1), P(img1), None)
+    assert np.array_equal(a0, a1) and np.array_equal(c0, c1) and np.array_equal(img0, img1)

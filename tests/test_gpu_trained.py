@@ -32,14 +32,64 @@ def test_trained_deep_clustering_separates_and_device_2means_matches_sklearn(mon
     print(f"1000 steps in {secs:.1f} s; loss {curve[0][1]:.1f} -> {curve[-1][1]:.1f}; SI-SDR mixture {mean['sdr_mixture']:.2f}, untrained "
           f"{before['sdr_device']:.2f}, device {mean['sdr_device']:.2f}, sklearn {mean['sdr_sklearn']:.2f}, ideal {mean['sdr_ideal_binary']:.2f} dB; "
           f"agreement mean {mean['agree_device_sklearn']:.4f} min {mean['min_agree_device_sklearn']:.4f}")
-    assert curve[-1][1] < 0.8 * curve[0][1], curve                       # it learns (3 700 -> ~2 450 in the probe: the norm-form loss flattens early)
+    assert curve[-1][1] < 0.6 * curve[0][1], curve                       # it learns (3 420 -> 1 450 in the probe)
     assert mean["sdr_device"] > mean["sdr_mixture"] + 6.0, mean           # it separates (the mixture scores ~0 dB, untrained < 2 dB)
     assert mean["sdr_device"] > before["sdr_device"] + 5.0, (before, mean)
     # the device back end against upstream's sklearn on the same trained embeddings
-    # (probe, 16 utterances: 99.98-100 % at 1 000 and 2 000 steps, max gap 0.014 dB; at 500 steps ONE utterance sat in another
-    #  optimum than sklearn's best of 10 initialisations -- 66 % --: one such outlier is tolerated here, not more)
+    # (probe, 16 utterances: >= 99.98 % on every utterance at 250 / 500 / 1 000 / 2 000 steps, max gap 0.004 dB; one outlier --
+    #  another optimum than sklearn's best of 10 initialisations, seen once on a half-trained network -- is tolerated, not more)
     same = [r for r in rows if r["agree_device_sklearn"] >= 0.99]
     assert len(same) >= len(rows) - 1, [r["agree_device_sklearn"] for r in rows]
     assert max(abs(r["sdr_device"] - r["sdr_sklearn"]) for r in same) <= 0.05, same
     assert abs(mean["sdr_device"] - mean["sdr_sklearn"]) <= 0.6, mean
     assert all(np.isfinite(r["sdr_device"]) for r in rows)
+
+
+@pytest.mark.parametrize("eval_first", [False, True])
+def test_eval_after_training_runs_on_the_trained_weights(eval_first):
+    """Regression (round 5).  ``build_optimizer`` returns ``torch.optim.Adam(fused=True)`` on a GPU, and a fused step moves the
+    parameters WITHOUT bumping ``tensor._version`` -- the key the packed weight images were cached on.  Rounds 3-4 therefore ran
+    every training forward on the BLSTM images of step 0, and an eval-mode forward after training used whichever images an earlier
+    eval-mode forward had left (``tools/micro/train_then_eval_diag.py``: 1.24 max|d| against the oracle on the live state_dict).
+    Now: after a few optimizer steps the eval-mode embedding must be the ATen-CPU oracle's on the LIVE state_dict, whether or
+    not an eval-mode forward ran before training, and the training forward must see each update (the loss of a fixed batch
+    moves from step to step exactly as a from-scratch forward on the updated weights says)."""
+    import trained_probe as P
+    from onssen_amd import nn as onn
+    from onssen_amd.data import SyntheticVoicePairs
+    from onssen_amd.dist import train_step
+    from onssen_amd.features import stft_logmag
+    from onssen_amd.loss import loss_dc
+    from onssen_amd.synthetic import synth_mixture
+    from onssen_amd.utils import build_optimizer
+    from oracle import torch_cpu as TC
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = onn.deep_clustering(129, 600, 2, 20, dropout=0.0).to(dev)
+    wav = torch.from_numpy(synth_mixture(900_001, 64 * 120)[None]).to(dev)
+    with torch.no_grad():
+        logmag, _ = stft_logmag(wav, 256, 64)
+        if eval_first:
+            model.eval()
+            model([logmag])
+    model.train()
+    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
+    assert opt.defaults.get("fused"), "the regression needs the fused optimizer build_optimizer picks on a GPU"
+    data = SyntheticVoicePairs(dict(batch_size=4, frame_length=100, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40), device=dev, voices=8)
+    w0 = model.rnn.weight_hh_l0.detach().clone()
+    batch = next(data)
+    losses = [train_step(model, opt, loss_dc, *batch) for _ in range(12)]          # the SAME batch: the loss must fall
+    assert float((model.rnn.weight_hh_l0 - w0).abs().max()) > 1e-3
+    assert losses[-1] < 0.9 * losses[0], losses
+    # a from-scratch training-mode forward on the updated weights (fresh module, state_dict copied) gives the loss the next step reports
+    twin = onn.deep_clustering(129, 600, 2, 20, dropout=0.0).to(dev).train()
+    twin.load_state_dict(model.state_dict())
+    l_twin = float(torch.mean(loss_dc(twin(batch[0]), batch[1])))
+    l_next = train_step(model, opt, loss_dc, *batch)
+    assert abs(l_next - l_twin) <= 2e-4 * abs(l_twin), (l_next, l_twin)
+    model.eval()
+    with torch.no_grad():
+        emb, = model([logmag])
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = TC.deep_clustering_forward(sd, logmag.cpu().numpy()).numpy()
+    assert np.abs(emb.cpu().numpy() - ref).max() < 5e-5
