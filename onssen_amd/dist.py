@@ -245,9 +245,12 @@ def _abort_group(group=None):
 def _forward_backward(model, optimizer, loss_fn, input, label, reducer):
     from .nn import _train
     loss = None
-    if getattr(model, "fused_loss_dc", None) is not None and getattr(loss_fn, "__name__", "") == "loss_dc" \
-            and getattr(loss_fn, "__module__", "") == "onssen_amd.loss":
-        # this step holds the labels while the forward runs: head + loss as one autograd node (nn/deep_clustering.fused_loss_dc)
+    from . import loss as _loss_mod, options
+    if (getattr(model, "fused_loss_dc", None) is not None and loss_fn is _loss_mod.loss_dc and options.get("loss") == "1"
+            and not model._forward_hooks and not model._forward_pre_hooks):
+        # this step holds the labels while the forward runs: head + loss as one autograd node (nn/deep_clustering.fused_loss_dc).
+        # It does not go through nn.Module.__call__: a model with forward (pre-)hooks, another loss function, or
+        # loss = "torch" (ONSSEN_LOSS_HIP=0) takes the plain model(input) -> loss_fn(output, label) route below
         loss = model.fused_loss_dc(input, label)
     if loss is None:
         loss = loss_fn(model(input), label)
