@@ -106,6 +106,9 @@ def dc_masks_from_features(model, logmag, db_threshold=40.0, iters=20, frames=No
     ws = _cluster_ws(logmag.device, (logmag.device, B, T, F, D, "compact"), nb, comp_off, frames is not None)
     st = torch.cuda.current_stream().cuda_stream
     fr = frames.data_ptr() if frames is not None else None
+    # (round 5 measured "no": the map depends on the features only, so its three small launches were put on a side stream under
+    #  the first layer's recurrence -- 1.888 / 1.879 ms against 1.875 / 1.882 ms per step in the captured graph, and the map's
+    #  kernels, squeezed onto the 16 CUs the recurrence leaves, took 135 us instead of 10: profiles/NOTES.md)
     lib.dc_index(logmag.data_ptr(), B, T, F, D, float(db_threshold), ws.data_ptr(), nb, st, frames=fr)
     y = run_blstm(model._packed, model._ws, logmag, need_y=False, frames=frames)
     img = getattr(y, "x3_image", None)
