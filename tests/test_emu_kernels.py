@@ -237,9 +237,19 @@ def test_linear_split_bf16(lib, mode, group, K):
     np.testing.assert_allclose(out, ref, atol=2e-3 if group == 2 else 3e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("mode,group,K", [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40),
-                                          (_abi.EPI_L2NORM, 40, 33)])
-@pytest.mark.parametrize("tile", ["0", "256", "320", "256/128", "320/128"])     # kernel / width[/height] of the x3q tile
+def _half_grid(rows, cols):
+    """The checkerboard half of rows x cols (every row value and every column value still occurs, every pair of the full grid
+    differs from a kept one in at most one factor); ONSSEN_EMU_FULL=1 runs the whole grid.  The host-side emulation runs every
+    work-item as an OS thread: the full grids of the two widest kernels cost a minute and a half of the CPU suite, and the GPU
+    suite runs the same kernels at full size."""
+    import os
+    full = os.environ.get("ONSSEN_EMU_FULL") == "1"
+    return [r + c for i, r in enumerate(rows) for j, c in enumerate(cols) if full or (i + j) % 2 == 0]
+
+
+@pytest.mark.parametrize("tile,mode,group,K", _half_grid(
+    [("0",), ("256",), ("320",), ("256/128",), ("320/128",)],     # kernel / width[/height] of the x3q tile
+    [(_abi.EPI_BIAS, 0, 37), (_abi.EPI_L2NORM, 20, 64), (_abi.EPI_SIGMOID, 0, 40), (_abi.EPI_L2NORM, 40, 33)]))
 def test_linear_x3_images(lib, mode, group, K, tile, monkeypatch):
     """onssen_x3_image_f32 + onssen_linear_x3p (pre-split operands; 256x160 register-staged tile, 256x256 / 256x320
     LDS-DMA tiles; register epilogue): ragged M/N/K, strided A rows and C rows, all epilogues."""
@@ -474,8 +484,9 @@ def _poison_handoff(ws, B, T, Hp, NP, L):
 
 
 # fuse 2: FUSE_IN0 + FUSE_TAIL, F = 33; bf16 1: ONSSEN_BLSTM_BF16 (opt-in plain bf16 products)
-@pytest.mark.parametrize("scramble,fuse,bf16", [("0", 0, 0), ("1", 0, 0), ("0", 1, 0), ("0", 2, 0), ("0", 0, 1), ("0", 1, 1)])
-@pytest.mark.parametrize("H,ug,B,T", [(8, 4, 3, 4), (24, 8, 17, 3), (32, 4, 2, 6)])
+@pytest.mark.parametrize("H,ug,B,T,scramble,fuse,bf16", _half_grid(
+    [(8, 4, 3, 4), (24, 8, 17, 3), (32, 4, 2, 6)],
+    [("0", 0, 0), ("1", 0, 0), ("0", 1, 0), ("0", 2, 0), ("0", 0, 1), ("0", 1, 1)]))
 def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fuse, bf16):
     """ONSSEN_BLSTM_XCD: one persistent launch per layer, h exchanged inside the launch.  The mock runtime runs
     every workgroup concurrently (forked) over shared memory; scramble=1 makes the members of a group report
