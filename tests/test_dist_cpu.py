@@ -224,3 +224,46 @@ def test_two_process_bench_selftest_record():
     assert r["roofline"]["frac"] > 0 and r["roofline"]["legs_le_step"] is True
     assert "2-means" in r["config"]["workload"] and r["config"]["parallelism"].startswith("utterance-sharded x2")
     assert r["vs_baseline"] is None and r["data"] == "synthetic"
+
+
+def _failing_worker(rank, world, port, out):
+    """Rank 1's loss raises in the middle of a data-parallel step.  It must re-raise (after aborting its communicator); rank 0,
+    already inside the step's collectives, must get an ERROR within the process group's timeout -- not wait forever, and not
+    pair one of its bucket all-reduces with whatever rank 1 would have issued next."""
+    import datetime
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    torch.set_num_threads(1)
+    m = _model().train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    inp, lab = _batch(100 + rank, 2)
+
+    def loss_fn(output, label):
+        if rank == 1:
+            raise ValueError("boom on rank 1")
+        return loss_dc(output, label)
+    import time
+    t0 = time.time()
+    try:
+        odist.train_step(m, opt, loss_fn, inp, lab, world)
+        out.put((rank, "returned", time.time() - t0))
+    except ValueError as e:
+        out.put((rank, "ValueError: " + str(e), time.time() - t0))
+    except Exception as e:                      # gloo: the peer's pending all-reduce fails (connection closed / timed out)
+        out.put((rank, type(e).__name__, time.time() - t0))
+    os._exit(0)                                 # the group is gone on rank 1: no orderly teardown
+
+
+@pytest.mark.timeout(180)
+def test_a_rank_that_raises_mid_step_does_not_leave_its_peer_waiting_forever():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict((r, (what, dt)) for r, what, dt in (q.get(timeout=120) for _ in range(2)))
+    for p in ps:
+        p.join(timeout=30)
+    assert res[1][0] == "ValueError: boom on rank 1" and res[1][1] < 10.0, res
+    assert res[0][0] not in ("returned",) and res[0][1] < 60.0, res       # an error, within the group's timeout
