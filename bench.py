@@ -225,17 +225,16 @@ def lloyd_iterations(B, T, F, D):
     from onssen_amd.hip import get_lib
     lib = get_lib()
     keys = [k for k in separation._CLUSTER_WS if tuple(k[1:5]) == (B, T, F, D)]
+    if not keys:
+        return None
     keys.sort(key=lambda k: k not in separation._CLUSTER_PINNED)          # the captured step's buffer first
-    for key in keys[:1]:
-        ws = separation._CLUSTER_WS[key]
-        if True:
-            so = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
-            iw = ws[so - B * 72 * 4:so].view(torch.int32).view(B, 72).cpu().numpy()
-            it = (iw[:, 66] & 0xffff).astype(int)
-            return {"per_utterance": it.tolist(), "min": int(it.min()), "max": int(it.max()), "mean": float(it.mean()),
-                    "stopped_before_the_cap": int(((iw[:, 66] >> 16) & 1).sum()), "cap": 20,
-                    "active_bin_fraction": float(iw[:, 64].sum()) / float(B * T * F)}
-    return None
+    ws = separation._CLUSTER_WS[keys[0]]
+    so = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
+    iw = ws[so - B * 72 * 4:so].view(torch.int32).view(B, 72).cpu().numpy()
+    it = (iw[:, 66] & 0xffff).astype(int)
+    return {"per_utterance": it.tolist(), "min": int(it.min()), "max": int(it.max()), "mean": float(it.mean()),
+            "stopped_before_the_cap": int(((iw[:, 66] >> 16) & 1).sum()), "cap": 20,
+            "active_bin_fraction": float(iw[:, 64].sum()) / float(B * T * F)}
 
 
 def batch_sweep(dev):
@@ -263,7 +262,7 @@ def batch_sweep(dev):
                 audio = B * (wl["T"] * wl["HOP"] / wl["SR"])
                 rows.append({"chunks": B, "ms_per_step": ms, "x_real_time": audio / ms * 1e3, "frames_per_s": B * wl["T"] / ms * 1e3,
                              "recurrence_us_per_time_step": roof["us_per_time_step"], "recurrence_frac_of_peak": roof["frac"],
-                             "recurrence_launches_per_layer": roof["launches_per_step"] // wl["L"] if kind != "phase_net" else roof["launches_per_step"] // wl["L"],
+                             "recurrence_launches_per_layer": roof["launches_per_step"] // wl["L"],
                              "recurrence_TFLOPs": roof["achieved"]})
                 del wl, run
             except Exception as e:
