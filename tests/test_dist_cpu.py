@@ -251,6 +251,8 @@ def _failing_worker(rank, world, port, out):
         out.put((rank, "ValueError: " + str(e), time.time() - t0))
     except Exception as e:                      # gloo: the peer's pending all-reduce fails (connection closed / timed out)
         out.put((rank, type(e).__name__, time.time() - t0))
+    out.close()
+    out.join_thread()                           # (the queue's feeder thread must have flushed before the hard exit)
     os._exit(0)                                 # the group is gone on rank 1: no orderly teardown
 
 
