@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -367,6 +367,17 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
  * library's own generator) the random stream is not torch's; the caller draws `seed` from torch's generator, so runs
  * repeat under torch.manual_seed.  0 <= p < 1; out may alias x; n elements, 16-byte aligned when n % 4 == 0. */
 int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float* out, void* stream);
+/* (round 5) Gradient-norm clipping + Adam over n parameter tensors in two passes (onssen/utils/train.py:83-84:
+ * `clip_grad_norm_(model.parameters(), 5)` then `optimizer.step()`; Adam without weight decay / amsgrad, torch.optim.Adam's
+ * formulas):  coef = min(1, max_norm / (||g|| + 1e-6)), g' = coef g, m += (g' - m)(1 - beta1), v = beta2 v + (1 - beta2) g'^2,
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).  The scaled gradient is not written back unless
+ * write_grads != 0.  max_norm <= 0 or +inf: no clipping (one pass, ws may be NULL).  *_host: HOST arrays of n DEVICE pointers /
+ * element counts; step >= 1 is the step being taken; lr / betas / eps are doubles (rounded once, after 1 - beta is formed).  ws: onssen_clip_adam_workspace_bytes() bytes, 16-byte aligned; after the
+ * call ws[0] (float) holds ||g|| before clipping (clip_grad_norm_'s return value). */
+size_t onssen_clip_adam_workspace_bytes(const int64_t* numel_host, int n);
+int onssen_clip_adam_f32(int n, float* const* p_host, float* const* g_host, float* const* m_host, float* const* v_host,
+                         const int64_t* numel_host, float max_norm, double lr, double beta1, double beta2, double eps, int step,
+                         int write_grads, void* ws, size_t ws_bytes, void* stream);
 /* F.normalize(x, p=2, dim=-1, eps) over `rows` rows of D floats and its backward -- the embedding's unit norm per TF bin in a
  * TRAINING forward (onssen/nn/deep_clustering.py:40-41; inference normalises in the GEMM epilogue):
  *   y = x / max(||x||, eps);   dx = (g - y (y . g)) / ||x||  where ||x|| > eps,  g / eps  elsewhere.   D % 4 == 0, D <= 64. */

@@ -38,6 +38,8 @@ SIGNATURES = {
     "onssen_lstm_pack_wih_bf16x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_lstm_pack_wih_image_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "onssen_clip_adam_workspace_bytes": (_sz, [_vp, _i]),
+    "onssen_clip_adam_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, C.c_double, C.c_double, C.c_double, C.c_double, _i, _i, _vp, _sz, _vp]),
     "onssen_head_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "onssen_linear_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _i64, _vp]),
     "onssen_linear_pack_bf16x3": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
@@ -229,6 +231,18 @@ class Lib:
     def lstm_pack_wih_image(self, w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream):
         self.check(self.dll.onssen_lstm_pack_wih_image_f32(w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream),
                    "onssen_lstm_pack_wih_image_f32")
+
+    def clip_adam(self, p, g, m, v, numel, max_norm, lr, beta1, beta2, eps, step, ws, ws_bytes, stream, write_grads=False):
+        """p / g / m / v: lists of device pointers; numel: list of element counts (include/onssen_hip.h: onssen_clip_adam_f32)."""
+        n = len(p)
+        arr = lambda xs: (C.c_void_p * n)(*xs)
+        ne = (C.c_int64 * n)(*numel)
+        self.check(self.dll.onssen_clip_adam_f32(n, arr(p), arr(g), arr(m), arr(v), ne, max_norm, lr, beta1, beta2, eps, step,
+                                                 1 if write_grads else 0, ws, ws_bytes, stream), "onssen_clip_adam_f32")
+
+    def clip_adam_workspace_bytes(self, numel):
+        ne = (C.c_int64 * len(numel))(*numel)
+        return int(self.dll.onssen_clip_adam_workspace_bytes(ne, len(numel)))
 
     def head_pack(self, w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream):
         self.check(self.dll.onssen_head_pack_f32(w, b, N, H, Hp, g, beta, mean, var, bn_eps, w_p, b_p, stream),

@@ -103,6 +103,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 #include "fft.inc"
 #include "loss_sdr.inc"
 #include "wav_io.inc"      // host code: the batch RIFF reader of the file loader
+#include "optim.inc"
 
 // Bounded waits of the persistent kernels: ~0.2 s of polling on the GPU by default.  A run-time setting of the library
 // (onssen_xcd_spin_limit), initialised from ONSSEN_XCD_SPIN_LIMIT: the host-side emulation -- where a 'workgroup' is a
@@ -1356,6 +1357,66 @@ int onssen_dropout_f32(const float* x, int64_t n, float p, uint64_t seed, float*
   ONSSEN_CLEAR_ERROR();
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(nb > 16384 ? 16384 : nb)), dim3(256), 0, (hipStream_t)stream, x, (long)n, thr,
                      1.0f / (1.0f - p), (unsigned long long)seed, out, vec);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+static long adam_blocks(const int64_t* numel, int n) {
+  long b = 0;
+  for (int i = 0; i < n; ++i) b += (numel[i] + opt::CHUNK - 1) / opt::CHUNK;
+  return b;
+}
+
+size_t onssen_clip_adam_workspace_bytes(const int64_t* numel_host, int n) {
+  if (!numel_host || n <= 0) return 0;
+  for (int i = 0; i < n; ++i)
+    if (numel_host[i] <= 0) return 0;
+  return align256((size_t)(1 + adam_blocks(numel_host, n)) * sizeof(float));
+}
+
+int onssen_clip_adam_f32(int n, float* const* p_host, float* const* g_host, float* const* m_host, float* const* v_host,
+                         const int64_t* numel_host, float max_norm, double lr, double beta1, double beta2, double eps, int step,
+                         int write_grads, void* ws, size_t ws_bytes, void* stream) {
+  if (n <= 0 || !p_host || !g_host || !m_host || !v_host || !numel_host || step < 1 || !(lr >= 0.) || !(beta1 >= 0. && beta1 < 1.) ||
+      !(beta2 >= 0. && beta2 < 1.) || !(eps >= 0.))
+    return ONSSEN_E_ARG;
+  for (int i = 0; i < n; ++i)
+    if (!p_host[i] || !g_host[i] || !m_host[i] || !v_host[i] || numel_host[i] <= 0) return ONSSEN_E_ARG;
+  const bool clip = max_norm > 0.f && max_norm < INFINITY;
+  const long nblk = adam_blocks(numel_host, n);
+  if (nblk > 0x7fffffffL) return ONSSEN_E_ARG;
+  if (clip && (!ws || ws_bytes < onssen_clip_adam_workspace_bytes(numel_host, n))) return ONSSEN_E_WORKSPACE;
+  if (clip && (reinterpret_cast<uintptr_t>(ws) & 15u)) return ONSSEN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  float* wsf = (float*)ws;
+  // hyper-parameters arrive as doubles (Python floats) and are rounded ONCE, after 1 - beta has been formed: 1 - float(0.999) is
+  // off by 1.3e-5 relative, which is what torch avoids by the same route
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  ONSSEN_CLEAR_ERROR();
+  for (int pass = clip ? 0 : 1; pass < 2; ++pass) {
+    long done_blocks = 0;
+    for (int i0 = 0; i0 < n; i0 += opt::MAXT) {
+      AdamArgs a;
+      a.n = n - i0 < opt::MAXT ? n - i0 : opt::MAXT;
+      int b = 0;
+      for (int i = 0; i < a.n; ++i) {
+        a.p[i] = p_host[i0 + i]; a.g[i] = g_host[i0 + i]; a.m[i] = m_host[i0 + i]; a.v[i] = v_host[i0 + i];
+        a.numel[i] = (long)numel_host[i0 + i];
+        a.first_block[i] = b;
+        b += (int)((numel_host[i0 + i] + opt::CHUNK - 1) / opt::CHUNK);
+      }
+      a.first_block[a.n] = b;
+      a.lr_bc1 = (float)(lr / bc1); a.omb1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.omb2 = (float)(1.0 - beta2);
+      a.eps = (float)eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+      a.max_norm = max_norm; a.write_grads = write_grads;
+      a.partials = clip ? wsf + 1 + done_blocks : nullptr;
+      a.norm = clip ? wsf : nullptr;
+      if (pass == 0) hipLaunchKernelGGL(grad_sqnorm_partial_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)b), dim3(256), 0, st, a);
+      done_blocks += b;
+    }
+    if (pass == 0) hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, st, (const float*)(wsf + 1), (int)nblk, wsf);
+  }
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

@@ -343,8 +343,11 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
         err = examine()               # a second abort (only possible on a rank that did not abort the first time) is fatal,
         if agree(err, fatal_if_aborted=True) == 2:     # ... and every rank learns of it before anybody raises
             raise err if err is not None else _abi.OnssenError("onssen_amd.train_step: another rank failed in the re-run of this step")
-    torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
-    optimizer.step()
+    if hasattr(optimizer, "step_clipped"):        # utils.ClipAdam: the clipping rides in the optimizer's own two passes
+        optimizer.step_clipped(clip_norm)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+        optimizer.step()
     from .nn._core import invalidate_packed_weights
     invalidate_packed_weights()          # (a fused optimizer moves the parameters without bumping their versions)
     return float(loss_avg.item())

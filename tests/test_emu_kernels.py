@@ -1282,3 +1282,50 @@ def test_wih_pack_with_image_in_one_pass(lib, H, ug, in_dim, bidir):
     img1 = np.full((NP, KB, 2, 32), 0xffff, np.uint16)
     lib.lstm_pack_wih_image(P(w_ih), P(b_ih), P(b_hh), in_dim, bidir, H, ug, P(a1), P(c1), P(img1), None)
     assert np.array_equal(a0, a1) and np.array_equal(c0, c1) and np.array_equal(img0, img1)
+
+
+@pytest.mark.parametrize("max_norm", [5.0, 1e9, 0.0])
+def test_clip_adam_against_the_formulas(lib, max_norm):
+    """onssen_clip_adam_f32 (round 5): torch.nn.utils.clip_grad_norm_ + torch.optim.Adam's update restated in NumPy fp64, three steps
+    over tensors of awkward sizes (one larger than a chunk, one unaligned view): clipping active (5.0), inactive (1e9) and off (0)."""
+    rng = np.random.default_rng(3)
+    sizes = [7, 4800, 32768 + 13, 129 * 20]
+    raw = [aligned_f32(n + 1) for n in sizes]
+    p = [r[:n] for r, n in zip(raw, sizes)]
+    p[1] = raw[1][1:4801]                                   # 4-byte aligned only: the scalar path
+    for a in p:
+        a[...] = rand(rng, a.size)
+    g = [rand(rng, n) * (3.0 if i == 2 else 0.5) for i, n in enumerate(sizes)]
+    m = [np.zeros(n, np.float32) for n in sizes]
+    v = [np.zeros(n, np.float32) for n in sizes]
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    P64, M64, V64 = [a.astype(np.float64) for a in p], [a.astype(np.float64) for a in m], [a.astype(np.float64) for a in v]
+    nb = lib.clip_adam_workspace_bytes(sizes)
+    ws = aligned_f32(nb // 4 + 4)
+    for step in (1, 2, 3):
+        for a in g:
+            a[...] = rand(rng, a.size) * 2.0
+        G64 = [a.astype(np.float64) for a in g]
+        norm = np.sqrt(sum((a * a).sum() for a in G64))
+        coef = min(1.0, max_norm / (norm + 1e-6)) if 0 < max_norm < np.inf else 1.0
+        for i in range(len(sizes)):
+            gg = G64[i] * coef
+            M64[i] += (gg - M64[i]) * (1 - b1)
+            V64[i] = V64[i] * b2 + (1 - b2) * gg * gg
+            P64[i] -= lr / (1 - b1 ** step) * M64[i] / (np.sqrt(V64[i]) / np.sqrt(1 - b2 ** step) + eps)
+        keep = [a.copy() for a in g]
+        lib.clip_adam([P(a) for a in p], [P(a) for a in g], [P(a) for a in m], [P(a) for a in v], sizes, max_norm, lr, b1, b2, eps,
+                      step, P(ws), nb, None)
+        assert all(np.array_equal(a, k) for a, k in zip(g, keep))          # gradients untouched unless asked for
+        if 0 < max_norm < np.inf:
+            np.testing.assert_allclose(ws[0], norm, rtol=2e-6)
+        for i in range(len(sizes)):
+            np.testing.assert_allclose(p[i], P64[i], rtol=2e-6, atol=2e-7)
+            np.testing.assert_allclose(m[i], M64[i], rtol=2e-6, atol=2e-7)      # (g - m cancels: fp32 round-off of O(|g|) terms)
+            np.testing.assert_allclose(v[i], V64[i], rtol=2e-6, atol=1e-12)
+    if 0 < max_norm < 1e6:                                  # write_grads: the clipped gradients land in g
+        lib.clip_adam([P(a) for a in p], [P(a) for a in g], [P(a) for a in m], [P(a) for a in v], sizes, max_norm, lr, b1, b2, eps,
+                      4, P(ws), nb, None, write_grads=True)
+        norm = np.sqrt(sum((a.astype(np.float64) ** 2).sum() for a in keep))
+        for a, k in zip(g, keep):
+            np.testing.assert_allclose(a, k * min(1.0, max_norm / (norm + 1e-6)), rtol=2e-6)

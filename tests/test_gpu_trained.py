@@ -45,8 +45,9 @@ def test_trained_deep_clustering_separates_and_device_2means_matches_sklearn(mon
     assert all(np.isfinite(r["sdr_device"]) for r in rows)
 
 
+@pytest.mark.parametrize("which", ["clip_adam", "torch_fused"])
 @pytest.mark.parametrize("eval_first", [False, True])
-def test_eval_after_training_runs_on_the_trained_weights(eval_first):
+def test_eval_after_training_runs_on_the_trained_weights(eval_first, which):
     """Regression (round 5).  ``build_optimizer`` returns ``torch.optim.Adam(fused=True)`` on a GPU, and a fused step moves the
     parameters WITHOUT bumping ``tensor._version`` -- the key the packed weight images were cached on.  Rounds 3-4 therefore ran
     every training forward on the BLSTM images of step 0, and an eval-mode forward after training used whichever images an earlier
@@ -73,8 +74,14 @@ def test_eval_after_training_runs_on_the_trained_weights(eval_first):
             model.eval()
             model([logmag])
     model.train()
-    opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
-    assert opt.defaults.get("fused"), "the regression needs the fused optimizer build_optimizer picks on a GPU"
+    # both optimizers that move parameters WITHOUT bumping their versions: the package's own (what build_optimizer returns on a GPU
+    # since round 5: raw-pointer kernel) and torch's fused Adam (what it returned in rounds 3-4: the original bug)
+    from onssen_amd.utils import ClipAdam
+    if which == "clip_adam":
+        opt = build_optimizer(model.parameters(), {"name": "adam", "lr": 1e-3})
+        assert isinstance(opt, ClipAdam)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
     data = SyntheticVoicePairs(dict(batch_size=4, frame_length=100, sampling_rate=8000, window_size=256, hop_size=64, db_threshold=40), device=dev, voices=8)
     w0 = model.rnn.weight_hh_l0.detach().clone()
     batch = next(data)
@@ -93,3 +100,38 @@ def test_eval_after_training_runs_on_the_trained_weights(eval_first):
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     ref = TC.deep_clustering_forward(sd, logmag.cpu().numpy()).numpy()
     assert np.abs(emb.cpu().numpy() - ref).max() < 5e-5
+
+
+def test_clip_adam_is_clip_grad_norm_plus_torch_adam():
+    """utils.ClipAdam.step_clipped(5) against ``clip_grad_norm_(params, 5); torch.optim.Adam.step()`` (onssen/utils/train.py:83-84) on
+    the parameter shapes of the as-shipped recipe (DC 3xBLSTM-600: 23.9 M parameters in 28 tensors), five steps with gradients
+    of very different scales (clipping active on some steps, not on others); also the plain ``step()`` and a state_dict round trip
+    into torch.optim.Adam."""
+    from onssen_amd import nn as onn
+    from onssen_amd.utils import ClipAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ma = onn.deep_clustering(129, 600, 3, 20).to(dev)
+    mb = onn.deep_clustering(129, 600, 3, 20).to(dev)
+    mb.load_state_dict(ma.state_dict())
+    oa = ClipAdam(ma.parameters(), lr=1e-3)
+    ob = torch.optim.Adam(mb.parameters(), lr=1e-3)
+    g = torch.Generator(device=dev).manual_seed(1)
+    for step, scale in enumerate((1e-3, 3e-3, 1e-5, 2e-2, 1e-3)):          # 23.9 M elements: norms ~ 4.9, 14.7, 0.05, 98, 4.9
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            pa.grad = torch.randn(pa.shape, device=dev, generator=g) * scale
+            pb.grad = pa.grad.clone()
+        if step == 2:
+            oa.step()                                                      # the plain update on the same kernel
+            ob.step()
+        else:
+            na = oa.step_clipped(5.0)
+            nb = torch.nn.utils.clip_grad_norm_(mb.parameters(), 5.0)
+            ob.step()
+            assert abs(float(na) - float(nb)) <= 2e-6 * float(nb)
+        for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+            torch.testing.assert_close(pa, pb, rtol=2e-6, atol=2e-8, msg=lambda m: f"step {step} {n}: {m}")
+    sd = oa.state_dict()
+    oc = torch.optim.Adam(ma.parameters(), lr=1e-3)
+    oc.load_state_dict(sd)                                                 # same state layout as torch.optim.Adam
+    assert float(oc.state[next(iter(ma.parameters()))]["step"]) == 5.0
