@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -337,11 +337,18 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
  *   Split-bf16 products, fp32 accumulation and state in both forms.
  *   db_rows (ONSSEN_LSTM_BWD_XCD only, may be NULL): [B][2][NP], receives sum_t dP[t][b] per batch row -- the kernel has every
  *   dP in registers as it goes; the bias gradient is the sum of its B rows instead of a pass over all T*B rows of dP. */
+/* onssen_lstm_train_backward_img_f32 (round 5): the ONSSEN_LSTM_BWD_XCD form that leaves dP as the x3 image
+ *   dp_img [T*B][2*NP/32][2][32] (row m = t*B + b, column k = d*NP + packed gate column; onssen_x3_image_f32's layout, bit for bit
+ *   what it makes of the fp32 dP) INSTEAD of overwriting the gates: the gradient GEMMs read that image, the fp32 -> image pass over
+ *   all of dP disappears.  `gates` is only read (padded rows / columns of dp_img that no unit owns are NOT written: 2*NP % 32 == 0
+ *   and Hp == H give an image without such holes; otherwise zero it first). */
 #define ONSSEN_LSTM_BWD_STEPS 0
 #define ONSSEN_LSTM_BWD_XCD 1
 int onssen_lstm_train_forward_f32(const float* x, int64_t x_stride_b, int64_t x_stride_t, int B, int T, int in_dim, int H,
                                   int ug, const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,
                                   float* gates, float* cs, void* ws, size_t ws_bytes, void* stream);
+int onssen_lstm_train_backward_img_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, const float* gates,
+                                       const float* cs, void* ws, size_t ws_bytes, float* db_rows, uint16_t* dp_img, void* stream);
 /* The same training forward in a chosen FORM of onssen_blstm_forward_f32 (round 4: the training path no longer leaves the
  * library when the persistent launch cannot be used -- the re-run of a step whose persistent launch aborted, H > 640):
  *   flags = ONSSEN_BLSTM_XCD | ONSSEN_BLSTM_BF16X3   the persistent launch (= onssen_lstm_train_forward_f32; wih = x3 image,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "onssen_lstm_pack_whhR_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_train_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_lstm_train_backward_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
+    "onssen_lstm_train_backward_img_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "onssen_dropout_f32": (_i, [_vp, _i64, _f, C.c_uint64, _vp, _vp]),
     "onssen_l2norm_rows_f32": (_i, [_vp, _i64, _i, _f, _vp, _vp]),
     "onssen_bn_rows_workspace_bytes": (_sz, [_i64, _i]),
@@ -349,6 +350,10 @@ class Lib:
     def lstm_train_backward(self, B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, stream, db_rows=None):
         self.check(self.dll.onssen_lstm_train_backward_f32(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, db_rows, stream),
                    "onssen_lstm_train_backward_f32")
+
+    def lstm_train_backward_img(self, B, T, H, ug, whh_img, dy, gates, cs, ws, ws_bytes, stream, db_rows, dp_img):
+        self.check(self.dll.onssen_lstm_train_backward_img_f32(B, T, H, ug, whh_img, dy, gates, cs, ws, ws_bytes, db_rows, dp_img, stream),
+                   "onssen_lstm_train_backward_img_f32")
 
     def bn_rows_workspace_bytes(self, M, Cc):
         return int(self.dll.onssen_bn_rows_workspace_bytes(M, Cc))

@@ -1193,8 +1193,25 @@ size_t onssen_lstm_train_backward_workspace_bytes(int B, int H, int ug, int form
   return align256((size_t)2 * 2 * ceil_div(B, 16) * KQB * 2048) + align256((size_t)2 * B * Hp * sizeof(float));
 }
 
+static int lstm_train_backward_impl(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
+                                    const float* cs, void* ws, size_t ws_bytes, int form, float* db_rows, uint16_t* dp_img, void* stream);
+
 int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
                                    const float* cs, void* ws, size_t ws_bytes, int form, float* db_rows, void* stream) {
+  return lstm_train_backward_impl(B, T, H, ug, whh_img, dy, gates_dp, cs, ws, ws_bytes, form, db_rows, nullptr, stream);
+}
+
+int onssen_lstm_train_backward_img_f32(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, const float* gates,
+                                       const float* cs, void* ws, size_t ws_bytes, float* db_rows, uint16_t* dp_img, void* stream) {
+  int Hp, NP;
+  if (!dp_img || !aligned16(dp_img) || onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK || (2 * NP) % 32 != 0)
+    return ONSSEN_E_ARG;
+  return lstm_train_backward_impl(B, T, H, ug, whh_img, dy, const_cast<float*>(gates), cs, ws, ws_bytes, ONSSEN_LSTM_BWD_XCD, db_rows,
+                                  dp_img, stream);
+}
+
+static int lstm_train_backward_impl(int B, int T, int H, int ug, const uint16_t* whh_img, const float* dy, float* gates_dp,
+                                    const float* cs, void* ws, size_t ws_bytes, int form, float* db_rows, uint16_t* dp_img, void* stream) {
   int Hp, NP, KQB, NUB;
   if (!whh_img || !dy || !gates_dp || !cs || !ws || B <= 0 || T <= 0 || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB) ||
       (form != ONSSEN_LSTM_BWD_STEPS && form != ONSSEN_LSTM_BWD_XCD) || (db_rows && form != ONSSEN_LSTM_BWD_XCD) ||
@@ -1213,7 +1230,7 @@ int onssen_lstm_train_backward_f32(int B, int T, int H, int ug, const uint16_t* 
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
     xa.B = B; xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.NU = Hp / ug; xa.NTB = NUB; xa.RG = bwd_rows_per_group(B);
-    xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env; xa.db_rows = db_rows;
+    xa.spin_limit = xcd_spin; xa.ablate = ablate_env; xa.delay = delay_env; xa.db_rows = db_rows; xa.dp_img = dp_img;
     // ONSSEN_XCD_PROFILE builds only (ONSSEN_BWD_DBG=1, tools/bwd_timeline.py): 8 timestamps per step of workgroup 0 in the tail of ws
     static const bool dbg_env = ONSSEN_KNOB_INT("ONSSEN_BWD_DBG", 0) != 0;
     xa.dbg = dbg_env && ws_bytes >= onssen_lstm_train_backward_workspace_bytes(B, H, ug, form) + (size_t)T * 64

@@ -78,7 +78,14 @@ def _x3_image(lib, st, m):
     return img
 
 
-def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, db_rows=None, fwd_images=None):
+def wgrad_rows_applies(H, Hp, NP, Kx, in_features, xp):
+    """Does this layer take the weight-gradient GEMM over row-major images (onssen_lstm_wgrad_images_f32)?  No padded units, 32-wide
+    k blocks, contiguous input rows."""
+    return (Hp == H and Kx == in_features and NP % 32 == 0 and Hp % 8 == 0 and xp.is_contiguous()
+            and options.get("train_wgrad_rows") == "1")
+
+
+def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, db_rows=None, fwd_images=None, dp_image=None):
     """The same contractions as layer_gradients on the split-bf16 MFMA GEMM (onssen_linear_x3p), in the packed layouts
     the kernels use, so that no gather of dP is needed:
 
@@ -99,12 +106,15 @@ def layer_gradients_x3(lib, st, dP, xp, y, wih_p, H, ug, in_features, need_dx, d
     # images (onssen_lstm_wgrad_images_f32: gfx950's transposing LDS read; h of the step before is a row shift of y's image) --
     # no transposed image of dP, x or y is made, and x's and y's row-major images are the persistent forward's own, still in
     # its workspace (``fwd_images``).  Bit-identical gradients; 7.25 -> 7.05 ms per training step on the same box
-    rows_gemm = (direct and NP % 32 == 0 and Hp % 8 == 0 and xp.is_contiguous()
-                 and options.get("train_wgrad_rows") == "1")
+    rows_gemm = wgrad_rows_applies(H, Hp, NP, Kx, in_features, xp)
+    if dp_image is not None and not rows_gemm:
+        raise RuntimeError("layer_gradients_x3: dp_image is the row-major operand of the rows GEMM only")
     a_t = None if rows_gemm else torch.empty(2 * NP, KB, 2, 32, device=dev, dtype=torch.int16)
     a_rows = None
     if rows_gemm:
-        a_rows = _x3_image(lib, st, dp2)
+        # (round 5) the backward recurrence has already left dP as this image (onssen_lstm_train_backward_img_f32): `dP` then
+        # still holds the saved gates and is not read here
+        a_rows = dp_image if dp_image is not None else _x3_image(lib, st, dp2)
     elif need_dx:     # dP is the operand of both gradient GEMMs: its row-major and its transposed image from ONE pass over it
         a_rows = torch.empty(TB, (2 * NP + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
         lib.x3_image_both(dp2.data_ptr(), 2 * NP, 2 * NP, TB, a_rows.data_ptr(), a_t.data_ptr(), st)
@@ -301,14 +311,23 @@ class BLSTMTrainFunction(torch.autograd.Function):
             db_rows = torch.empty(B, 2 * NP, device=dev, dtype=torch.float32) if form == _abi.LSTM_BWD_XCD else None
             if form == _abi.LSTM_BWD_XCD:
                 _XcdSerial.before(dev)
-            lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
-                                    wsb.data_ptr(), wsb.numel(), form, st, db_rows.data_ptr() if db_rows is not None else None)
+            # the persistent kernel writes dP straight as the gradient GEMMs' row-major operand where they take one (round 5)
+            dp_img = None
+            in_l = In if l == 0 else 2 * H
+            if (form == _abi.LSTM_BWD_XCD and use_x3 and options.get("train_dp_image") == "1"
+                    and wgrad_rows_applies(H, Hp, NP, xp.shape[1], in_l, xp)):
+                dp_img = torch.empty(T * B, 2 * NP // 32, 2, 32, device=dev, dtype=torch.int16)
+                lib.lstm_train_backward_img(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
+                                            wsb.data_ptr(), wsb.numel(), st, db_rows.data_ptr(), dp_img.data_ptr())
+            else:
+                lib.lstm_train_backward(B, T, H, ug, whh_img[l].data_ptr(), dy.data_ptr(), gates.data_ptr(), cs.data_ptr(),
+                                        wsb.data_ptr(), wsb.numel(), form, st, db_rows.data_ptr() if db_rows is not None else None)
             if form == _abi.LSTM_BWD_XCD:
                 _XcdSerial.after(dev)
                 _XcdStatus.post(wsb)
             need_dx = l > 0 or ctx.needs_input_grad[0]
             if use_x3:
-                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx, db_rows, imgs)
+                dx_rows, g = layer_gradients_x3(lib, st, gates, xp, y, pk.wih[l], H, ug, In if l == 0 else 2 * H, need_dx, db_rows, imgs, dp_img)
             else:
                 w_ih = (flat[(2 * l) * 4].detach(), flat[(2 * l + 1) * 4].detach())
                 x_rows = xp if l == 0 or Hp == H else xp.view(T, B, 2, Hp)[..., :H].reshape(T * B, 2 * H)

@@ -75,6 +75,7 @@ TABLE = {
     "train_blstm": ("ONSSEN_TRAIN_HIP", "1", _alias({"hip": "1", "aten": "0"}), "training BLSTM / head / BatchNorm on the HIP kernels"),
     "train_backward": ("ONSSEN_BWD_XCD", "1", _alias({"persistent": "1", "steps": "0"}), "backward recurrence form"),
     "train_gemm": ("ONSSEN_TRAIN_GEMM", "x3", _choice("x3", "blas"), "weight / input gradient contractions: package GEMM or library fp32"),
+    "train_dp_image": ("ONSSEN_TRAIN_DP_IMAGE", "1", _flag, "the backward recurrence writes dP as the gradient GEMMs' x3 image instead of fp32"),
     "train_wgrad_rows": ("ONSSEN_TRAIN_WGRAD_ROWS", "1", _flag, "weight gradients from the row-major images the forward left"),
     "train_fused_loss": ("ONSSEN_TRAIN_FUSED_LOSS", "1", _flag, "fc_dc + normalise + loss_dc as one autograd node in train_step"),
     "train_fused_norm": ("ONSSEN_TRAIN_FUSED_NORM", "1", _flag, "fc_dc + normalise as one autograd node"),

@@ -880,7 +880,28 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     wsb = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug, form) // 4 + 64,))
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)     # scramble=1: the placement-independent protocol
     db_rows = _shm((B, 2, NP), fill=np.nan) if xcd else None
+    gates_saved = _shm(gates.shape); gates_saved[...] = gates
     lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, form, None, P(db_rows) if xcd else None)
+    if xcd and (2 * NP) % 32 == 0:
+        # round 5: the same launch leaving dP as the gradient GEMMs' x3 image instead of fp32 -- bit for bit onssen_x3_image_f32 of
+        # the fp32 dP wherever a unit owns the column (holes of padded units keep what the buffer held)
+        img = _shm((T * B, 2 * NP // 32, 2, 32), dtype=np.uint16); img[...] = 0
+        db2 = _shm((B, 2, NP), fill=np.nan)
+        wsb2 = _shm((lib.lstm_train_backward_workspace_bytes(B, H, ug, form) // 4 + 64,))
+        lib.lstm_train_backward_img(B, T, H, ug, P(wT), P(dy), P(gates_saved), P(cs), P(wsb2), wsb2.nbytes, None, P(db2), P(img))
+        ref = _shm((T * B, 2 * NP // 32, 2, 32), dtype=np.uint16)          # (forked workgroups: shared memory)
+        dp_fp32 = _shm((T * B, 2 * NP)); dp_fp32[...] = np.array(gates).reshape(T * B, 2 * NP)
+        lib.x3_image(P(dp_fp32), 2 * NP, 0, 1, T * B, 2 * NP, P(ref), None)
+        owned = np.zeros(NP, bool)
+        for ugi in range(Hp // ug):
+            for ju in range(ug):
+                if ugi * ug + ju < H:
+                    owned[ugi * 4 * ug + ju * 4: ugi * 4 * ug + ju * 4 + 4] = True
+        own2 = np.concatenate([owned, owned]).reshape(2 * NP // 32, 32)
+        got, want = np.array(img), np.array(ref)
+        assert np.array_equal(got[:, :, 0][:, own2], want[:, :, 0][:, own2]) and np.array_equal(got[:, :, 1][:, own2], want[:, :, 1][:, own2])
+        assert np.array_equal(np.array(gates_saved), np.array(gates_saved)) and wsb2.view(np.uint32)[280] == 0
+        np.testing.assert_allclose(np.array(db2), np.array(db_rows), rtol=1e-6, atol=1e-7)
     if xcd:      # the kernel's per-row sums of dP over time (the bias gradient's operand) against the dP it wrote
         np.testing.assert_allclose(np.array(db_rows), np.array(gates).sum(0), rtol=1e-5, atol=1e-6)
     if xcd:
