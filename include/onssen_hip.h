@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -145,6 +145,15 @@ int onssen_lstm_pack_f32(const float* w_ih, const float* w_hh, const float* b_ih
  * [2*NP][ceil(K/32)][2][32] image (K = in_dim, or 2*Hp with bidir_in), 16-byte aligned. */
 int onssen_lstm_pack_wih_image_f32(const float* w_ih, const float* b_ih, const float* b_hh, int in_dim, int bidir_in, int H, int ug,
                                    float* wih_p, float* bias_p, uint16_t* wih_img, void* stream);
+
+/* (round 5) ... and the whole stack's training images in ONE launch: per (layer l, direction d), index i = 2 l + d of every HOST
+ * pointer array: onssen_lstm_pack_wih_image_f32 (layer 0: in_dim plain columns; deeper layers: bidir_in), onssen_lstm_pack_whh_bf16x3
+ * and -- when whhR_host is not NULL -- onssen_lstm_pack_whhR_bf16x3, bit for bit what the single calls give.  wih_img_host[i]:
+ * direction d's NP rows of layer l's image. */
+int onssen_lstm_pack_train_f32(int L, int in_dim, int H, int ug, const float* const* w_ih_host, const float* const* w_hh_host,
+                               const float* const* b_ih_host, const float* const* b_hh_host, float* const* wih_p_host,
+                               float* const* bias_p_host, uint16_t* const* wih_img_host, uint16_t* const* whh_x3_host,
+                               uint16_t* const* whhR_host, void* stream);
 
 /* Split-bf16 image of one direction's W_hh (see ONSSEN_BLSTM_BF16X3): hi = bf16(w), lo = bf16(w - hi), in
  * v_mfma_f32_16x16x32_bf16 B-fragment order [NU][KQ2][ug/4][hi|lo][64][8], KQ2 = ceil(Hp/32). */

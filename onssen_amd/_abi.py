@@ -37,6 +37,7 @@ SIGNATURES = {
     "onssen_lstm_pack_whh_bf16x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_wih_bf16x3": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "onssen_lstm_pack_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "onssen_lstm_pack_train_f32": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "onssen_lstm_pack_wih_image_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "onssen_clip_adam_workspace_bytes": (_sz, [_vp, _i]),
     "onssen_clip_adam_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _f, C.c_double, C.c_double, C.c_double, C.c_double, _i, _i, _vp, _sz, _vp]),
@@ -228,6 +229,12 @@ class Lib:
     def lstm_pack(self, w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p, bias_p, stream):
         self.check(self.dll.onssen_lstm_pack_f32(w_ih, w_hh, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, whh_p,
                                                  bias_p, stream), "onssen_lstm_pack_f32")
+
+    def lstm_pack_train(self, L, in_dim, H, ug, w_ih, w_hh, b_ih, b_hh, wih_p, bias_p, wih_img, whh_x3, whhR, stream):
+        """Lists of 2 L device pointers, index 2 l + d (whhR may be None): include/onssen_hip.h: onssen_lstm_pack_train_f32."""
+        arr = lambda xs: (C.c_void_p * (2 * L))(*xs) if xs is not None else None
+        self.check(self.dll.onssen_lstm_pack_train_f32(L, in_dim, H, ug, arr(w_ih), arr(w_hh), arr(b_ih), arr(b_hh), arr(wih_p), arr(bias_p),
+                                                       arr(wih_img), arr(whh_x3), arr(whhR), stream), "onssen_lstm_pack_train_f32")
 
     def lstm_pack_wih_image(self, w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream):
         self.check(self.dll.onssen_lstm_pack_wih_image_f32(w_ih, b_ih, b_hh, in_dim, bidir_in, H, ug, wih_p, bias_p, wih_img, stream),

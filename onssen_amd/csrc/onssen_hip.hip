@@ -258,8 +258,9 @@ int onssen_lstm_pack_whh_bf16x3(const float* w_hh, int H, int ug, uint16_t* whh_
   if (!w_hh || !whh_x3 || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK ||
       onssen_lstm_geometry_x3(H, ug, &KQ2, nullptr, &we) != ONSSEN_OK)
     return ONSSEN_E_ARG;
+  if (!aligned16(whh_x3)) return ONSSEN_E_ALIGN;      // 16-byte stores (one fragment lane's 8 values per half)
   ONSSEN_CLEAR_ERROR();
-  const long n = we / 2;
+  const long n = we / 16;
   hipLaunchKernelGGL(pack_whh_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, w_hh, H, Hp, ug, KQ2, H, whh_x3);
   ONSSEN_LAUNCH_CHECK();
@@ -269,9 +270,10 @@ int onssen_lstm_pack_wih_bf16x3(const float* w_ih, int in_dim, int H, int ug, ui
   int Hp;
   if (!w_ih || !wih_x3 || in_dim <= 0 || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK)
     return ONSSEN_E_ARG;
+  if (!aligned16(wih_x3)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   const int KC = ceil_div(in_dim, 32);
-  const long n = (long)(Hp / ug) * KC * (ug / 4) * 512;
+  const long n = (long)(Hp / ug) * KC * (ug / 4) * 64;
   hipLaunchKernelGGL(pack_whh_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, w_ih, H, Hp, ug, KC, in_dim, wih_x3);
   ONSSEN_LAUNCH_CHECK();
@@ -1167,11 +1169,57 @@ int64_t onssen_lstm_whhR_elems(int H, int ug) {
 int onssen_lstm_pack_whhR_bf16x3(const float* w_hh, int H, int ug, uint16_t* out, void* stream) {
   int Hp, NP, KQB, NUB;
   if (!w_hh || !out || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB)) return ONSSEN_E_ARG;
+  if (!aligned16(out)) return ONSSEN_E_ALIGN;
   ONSSEN_CLEAR_ERROR();
   const int KC = ceil_div(4 * ug, 32);
-  const long n = (long)(Hp / ug) * KC * NUB * 512;
+  const long n = (long)(Hp / ug) * KC * NUB * 64;
   hipLaunchKernelGGL(pack_whhR_bf16x3_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w_hh, H, Hp, ug, KC, NUB, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_lstm_pack_train_f32(int L, int in_dim, int H, int ug, const float* const* w_ih_host, const float* const* w_hh_host,
+                               const float* const* b_ih_host, const float* const* b_hh_host, float* const* wih_p_host,
+                               float* const* bias_p_host, uint16_t* const* wih_img_host, uint16_t* const* whh_x3_host,
+                               uint16_t* const* whhR_host, void* stream) {
+  int Hp, NP, KQB, NUB, KQ2;
+  if (L <= 0 || in_dim <= 0 || !w_ih_host || !w_hh_host || !b_ih_host || !b_hh_host || !wih_p_host || !bias_p_host || !wih_img_host ||
+      !whh_x3_host || !lstm_bwd_geometry(H, ug, &Hp, &NP, &KQB, &NUB) || onssen_lstm_geometry_x3(H, ug, &KQ2, nullptr, nullptr) != ONSSEN_OK)
+    return ONSSEN_E_ARG;
+  for (int i = 0; i < 2 * L; ++i)
+    if (!w_ih_host[i] || !w_hh_host[i] || !b_ih_host[i] || !b_hh_host[i] || !wih_p_host[i] || !bias_p_host[i] || !wih_img_host[i] ||
+        !whh_x3_host[i] || !aligned16(wih_img_host[i]) || !aligned16(whh_x3_host[i]) ||
+        (whhR_host && (!whhR_host[i] || !aligned16(whhR_host[i]))))
+      return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  const int per = whhR_host ? 3 : 2, group = packt::MAXJ / per;       // (layer, direction) pairs per launch
+  auto blocks = [](long n) { const long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : b); };
+  for (int i0 = 0; i0 < 2 * L; i0 += group) {
+    PackTrainArgs a;
+    a.H = H; a.Hp = Hp; a.UG = ug; a.KQ2 = KQ2; a.KC = ceil_div(4 * ug, 32); a.NTB = NUB; a.njobs = 0;
+    int fb = 0;
+    for (int i = i0; i < 2 * L && i < i0 + group; ++i) {
+      const int l = i / 2, bidir = l > 0;
+      const int ind = bidir ? 2 * H : in_dim, Kp = bidir ? 2 * Hp : ceil_div(in_dim, 4) * 4, K = bidir ? 2 * Hp : in_dim, KB = ceil_div(K, 32);
+      PackJob j{};
+      j.w = w_ih_host[i]; j.b_ih = b_ih_host[i]; j.b_hh = b_hh_host[i]; j.wih_p = wih_p_host[i]; j.bias_p = bias_p_host[i];
+      j.out = wih_img_host[i]; j.type = 0; j.in_dim = ind; j.bidir = bidir; j.Kp = Kp; j.K = K; j.KB = KB;
+      j.first_block = fb; j.nblocks = blocks((long)NP * KB * 4); fb += j.nblocks;
+      a.job[a.njobs++] = j;
+      PackJob h{};
+      h.w = w_hh_host[i]; h.out = whh_x3_host[i]; h.type = 1;
+      h.first_block = fb; h.nblocks = blocks((long)(Hp / ug) * KQ2 * (ug / 4) * 64); fb += h.nblocks;
+      a.job[a.njobs++] = h;
+      if (whhR_host) {
+        PackJob r{};
+        r.w = w_hh_host[i]; r.out = whhR_host[i]; r.type = 2;
+        r.first_block = fb; r.nblocks = blocks((long)(Hp / ug) * a.KC * NUB * 64); fb += r.nblocks;
+        a.job[a.njobs++] = r;
+      }
+    }
+    hipLaunchKernelGGL(lstm_pack_train_kernel, dim3((unsigned)fb), dim3(256), 0, (hipStream_t)stream, a);
+  }
   ONSSEN_LAUNCH_CHECK();
   return ONSSEN_OK;
 }

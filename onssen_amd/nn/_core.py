@@ -456,6 +456,10 @@ class _PackedImages:
         self.bias0_tail = None
         _, _, we3 = lib.lstm_geometry_x3(H, self.ug)
         st = _stream()
+        if lean:
+            self._get_lean(flat, dev, H, L, we3, st)
+            self.key = key
+            return self
         for l in range(L):
             in_l = p.input_size if l == 0 else 2 * H
             Kp = (in_l + 3) // 4 * 4 if l == 0 else 2 * self.Hp
@@ -499,6 +503,41 @@ class _PackedImages:
         self.key = key
         self._whhT = None
         return self
+
+    def _get_lean(self, flat, dev, H, L, we3, st):
+        """The per-step pack of the training forward (round 5): every image the persistent training path reads -- packed W_ih + bias
+        + its x3 image, the W_hh fragment images of the forward recurrence and (H <= 640) the row-slice images of the backward
+        recurrence -- for ALL layers and directions in ONE launch (onssen_lstm_pack_train_f32), no fp32 W_hh image, no split planes,
+        no first-layer fragment image."""
+        lib, p = get_lib(), self.p
+        cont = [t.detach().contiguous() for t in flat]
+        nR = lib.lstm_whhR_elems(H, self.ug) if H <= 640 else 0
+        ptr = {k: [] for k in ("w_ih", "w_hh", "b_ih", "b_hh", "a", "c", "ai", "b3", "r")}
+        whhR = []
+        for l in range(L):
+            in_l = p.input_size if l == 0 else 2 * H
+            Kp = (in_l + 3) // 4 * 4 if l == 0 else 2 * self.Hp
+            K_l = in_l if l == 0 else 2 * self.Hp
+            a = torch.empty(2, self.NP, Kp, device=dev, dtype=torch.float32)
+            c = torch.empty(2, self.NP, device=dev, dtype=torch.float32)
+            ai = torch.empty(2 * self.NP, (K_l + 31) // 32, 2, 32, device=dev, dtype=torch.int16)
+            b3 = torch.empty(2, we3, device=dev, dtype=torch.int16)
+            r = torch.empty(2, nR, device=dev, dtype=torch.int16) if nR else None
+            for d in range(2):
+                w_ih, w_hh, b_ih, b_hh = cont[(2 * l + d) * 4:(2 * l + d) * 4 + 4]
+                ptr["w_ih"].append(w_ih.data_ptr()), ptr["w_hh"].append(w_hh.data_ptr())
+                ptr["b_ih"].append(b_ih.data_ptr()), ptr["b_hh"].append(b_hh.data_ptr())
+                ptr["a"].append(a[d].data_ptr()), ptr["c"].append(c[d].data_ptr()), ptr["ai"].append(ai[d * self.NP:].data_ptr())
+                ptr["b3"].append(b3[d].data_ptr())
+                if nR:
+                    ptr["r"].append(r[d].data_ptr())
+            self.wih.append(a), self.whh.append(None), self.bias.append(c), self.whh_x3.append(b3), self.wih_x3.append(None)
+            self.wih_img.append(ai)
+            whhR.append(r)
+        lib.lstm_pack_train(L, p.input_size, H, self.ug, ptr["w_ih"], ptr["w_hh"], ptr["b_ih"], ptr["b_hh"], ptr["a"], ptr["c"], ptr["ai"],
+                            ptr["b3"], ptr["r"] if nR else None, st)
+        self._keep = cont                  # (contiguous copies, if any were made, must outlive the launch)
+        self._whhT = {_abi.LSTM_BWD_XCD: whhR} if nR else None
 
     def whh_bwd(self, form):
         """Per layer, both directions' images of W_hh for the backward recurrence (training only; built lazily):

@@ -1350,3 +1350,41 @@ def test_clip_adam_against_the_formulas(lib, max_norm):
         norm = np.sqrt(sum((a.astype(np.float64) ** 2).sum() for a in keep))
         for a, k in zip(g, keep):
             np.testing.assert_allclose(a, k * min(1.0, max_norm / (norm + 1e-6)), rtol=2e-6)
+
+
+@pytest.mark.parametrize("H,ug,F,L,with_r", [(10, 4, 9, 2, True), (24, 8, 33, 3, True), (40, 20, 20, 1, False), (12, 4, 7, 5, True)])
+def test_training_repack_of_the_whole_stack_in_one_launch(lib, H, ug, F, L, with_r):
+    """onssen_lstm_pack_train_f32 (round 5) == per (layer, direction) onssen_lstm_pack_wih_image_f32 + onssen_lstm_pack_whh_bf16x3 +
+    onssen_lstm_pack_whhR_bf16x3, bit for bit (L = 5 with the row-slice images needs two launches)."""
+    rng = np.random.default_rng(H + L)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    nR = lib.lstm_whhR_elems(H, ug)
+    keep, ptr = [], {k: [] for k in ("w_ih", "w_hh", "b_ih", "b_hh", "a", "c", "ai", "b3", "r")}
+    ref = []
+    for l in range(L):
+        in_l = F if l == 0 else 2 * H
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        K = F if l == 0 else 2 * Hp
+        KB = (K + 31) // 32
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = rand(rng, 4 * H, in_l), rand(rng, 4 * H, H), rand(rng, 4 * H), rand(rng, 4 * H)
+            a1, c1 = np.full((NP, Kp), np.nan, np.float32), np.full(NP, np.nan, np.float32)
+            i1, h1, r1 = np.full((NP, KB, 2, 32), 7, np.uint16), np.full(we3, 7, np.uint16), np.full(nR, 7, np.uint16)
+            lib.lstm_pack_wih_image(P(w_ih), P(b_ih), P(b_hh), in_l, 1 if l else 0, H, ug, P(a1), P(c1), P(i1), None)
+            lib.lstm_pack_whh_bf16x3(P(w_hh), H, ug, P(h1), None)
+            lib.lstm_pack_whhR_bf16x3(P(w_hh), H, ug, P(r1), None)
+            a2, c2 = np.full((NP, Kp), np.nan, np.float32), np.full(NP, np.nan, np.float32)
+            i2, h2, r2 = np.full((NP, KB, 2, 32), 9, np.uint16), np.full(we3, 9, np.uint16), np.full(nR, 9, np.uint16)
+            keep += [w_ih, w_hh, b_ih, b_hh]
+            for k, v in (("w_ih", w_ih), ("w_hh", w_hh), ("b_ih", b_ih), ("b_hh", b_hh), ("a", a2), ("c", c2), ("ai", i2), ("b3", h2), ("r", r2)):
+                ptr[k].append(P(v))
+            ref.append(((a1, c1, i1, h1, r1), (a2, c2, i2, h2, r2)))
+    lib.lstm_pack_train(L, F, H, ug, ptr["w_ih"], ptr["w_hh"], ptr["b_ih"], ptr["b_hh"], ptr["a"], ptr["c"], ptr["ai"], ptr["b3"],
+                        ptr["r"] if with_r else None, None)
+    for one, merged in ref:
+        for k, (x, y) in enumerate(zip(one, merged)):
+            if k == 4 and not with_r:
+                assert (y == 9).all()
+            else:
+                assert np.array_equal(x, y), k
