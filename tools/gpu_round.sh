@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end validation on the GPU box: parity suite, smoke, every bench configuration, rocprofv3 passes.
 # Usage: bash tools/gpu_round.sh <tag>   (tag names the profile directory gpurun_out/prof_<tag>, e.g. r02a)
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -2 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -1
