@@ -40,3 +40,28 @@ def test_recorded_two_rank_self_test_line():
     assert len(dp["per_rank_ms_per_step"]) == 2 and dp["all_reduce_bytes_per_step"] == 23_908_980 * 4
     assert dp["replicas_identical_after_dp_steps"] is True and dp["buckets_issued_inside_backward"] >= 1
     assert dp["ms_per_step"] > 0 and dp["ms_per_step_without_exchange"] > 0
+
+
+def test_recorded_bench_line_carries_the_contract():
+    """profiles/r05_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
+    key the bench contract names, the roofline and CPU-baseline blocks, and the round-5 additions."""
+    r = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 5 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None and r["data"] == "synthetic" and "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 32 * 3.2 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]          # audio seconds per wall second
+    roof = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["legs_le_step"] is True                                                   # the legs timed one by one sum to <= the step
+    cpu = r["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cpu, k
+    assert cpu["kind"] == "port" and cpu["value"] > 0
+    assert r["lloyd_iterations"]["cap"] == 20 and "second_input_set" in r
+    ex = r["extra_configs"]
+    assert ex["trained_weights_dc_l2_b32"]["si_sdr_db"]["separated_mean"] > 8.0           # the headline step on a trained network separates
+    assert [row["chunks"] for row in ex["batch_sweep"]["dc_l2"]["rows"]] == [8, 16, 32, 64, 128, 256]
+    assert ex["cfg4_training_step_dc_l3_b16"]["ms_per_step"] < 7.5
