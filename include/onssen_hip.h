@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 11   /* 11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 12   /* 12: onssen_log_magnitude_f32, onssen_cos_difference_f32, onssen_one_hot_f32 (the reference's stand-alone feature helpers).  11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -436,6 +436,20 @@ int onssen_phase_input_f32(const float* x_mag, const float* mask, int64_t m_sb, 
 int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* stft_s2, const float* feature_mix, int B,
                       int T, int F, float db_threshold, float* utt_max, float* one_hot, float* mag_mix, float* mag_s1,
                       float* mag_s2, float* cos_s1, float* cos_s2, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The reference's stand-alone feature helpers on ONE utterance's arrays (onssen_amd/data/feature_utils.py binds them under
+ * the reference's names).  `stft*` are complex arrays as interleaved (re, im) float32 pairs, `n` complex elements.
+ *   onssen_log_magnitude_f32   out[e] = log10f(|stft[e]| + epsilon)           get_log_magnitude, onssen/data/feature_utils.py:49-51
+ *   onssen_cos_difference_f32  out[e] = cos(angle(stft_1[e]) - angle(stft_2[e]))   get_cos_difference, feature_utils.py:77-80
+ *   onssen_one_hot_f32         one_hot (B, per_utt, 2) float32 from B utterances of per_utt bins each: e_argmax(mag_s1, mag_s2)
+ *                              (speaker 0 on ties), all-zero where feature < max_over_the_utterance(feature) - db_threshold/20;
+ *                              utt_max (B) scratch                             get_one_hot, feature_utils.py:83-95
+ */
+int onssen_log_magnitude_f32(const float* stft_ri, int64_t n, float epsilon, float* out, void* stream);
+int onssen_cos_difference_f32(const float* stft_1, const float* stft_2, int64_t n, float* out, void* stream);
+int onssen_one_hot_f32(const float* feature_mix, const float* mag_s1, const float* mag_s2, int B, int64_t per_utt,
+                       float db_threshold, float* utt_max, float* one_hot, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * N2  deep-clustering back end: per utterance, 2-means over the D-dimensional embeddings of the bins with

@@ -10,7 +10,7 @@ import os
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 11
+ABI_VERSION = 12
 WAV_TRUNCATED = 1
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
@@ -87,6 +87,9 @@ SIGNATURES = {
     "onssen_wav_info": (_i, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "onssen_wav_read_batch_f32": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i64, _vp, _vp, _vp, _i]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "onssen_log_magnitude_f32": (_i, [_vp, _i64, _f, _vp, _vp]),
+    "onssen_cos_difference_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "onssen_one_hot_f32": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
     "onssen_dc_cluster_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "onssen_dc_cluster_status_offset": (_sz, [_i, _i]),
     "onssen_loss_mask_workspace_bytes": (_sz, [_i]),
@@ -409,6 +412,15 @@ class Lib:
     def labels(self, mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, stream):
         self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
                                               cos_s1, cos_s2, stream), "onssen_labels_f32")
+
+    def log_magnitude(self, stft_ri, n, eps, out, stream):
+        self.check(self.dll.onssen_log_magnitude_f32(stft_ri, n, eps, out, stream), "onssen_log_magnitude_f32")
+
+    def cos_difference(self, s1, s2, n, out, stream):
+        self.check(self.dll.onssen_cos_difference_f32(s1, s2, n, out, stream), "onssen_cos_difference_f32")
+
+    def one_hot(self, feat, m1, m2, B, per_utt, db, utt_max, out, stream):
+        self.check(self.dll.onssen_one_hot_f32(feat, m1, m2, B, per_utt, db, utt_max, out, stream), "onssen_one_hot_f32")
 
     def dc_compact_layout(self, B, T, F, D):
         """(workspace bytes, byte offset of the compacted array, byte offset of the target map)."""

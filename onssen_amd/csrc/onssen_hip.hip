@@ -1515,6 +1515,37 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
   return ONSSEN_OK;
 }
 
+static unsigned ew_blocks(long total) { const long nb = (total + 255) / 256; return (unsigned)(nb > 8192 ? 8192 : nb); }
+
+int onssen_log_magnitude_f32(const float* stft_ri, int64_t n, float epsilon, float* out, void* stream) {
+  if (!stft_ri || !out || n <= 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(log_magnitude_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, stft_ri, (long)n, epsilon, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_cos_difference_f32(const float* stft_1, const float* stft_2, int64_t n, float* out, void* stream) {
+  if (!stft_1 || !stft_2 || !out || n <= 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(cos_difference_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, stft_1, stft_2, (long)n, out);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
+int onssen_one_hot_f32(const float* feature_mix, const float* mag_s1, const float* mag_s2, int B, int64_t per_utt,
+                       float db_threshold, float* utt_max, float* one_hot, void* stream) {
+  if (!feature_mix || !mag_s1 || !mag_s2 || !utt_max || !one_hot || B <= 0 || per_utt <= 0) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)per_utt * B;
+  hipLaunchKernelGGL(utt_max_kernel, dim3((unsigned)B), dim3(256), 0, st, feature_mix, (long)per_utt, utt_max);
+  hipLaunchKernelGGL(one_hot_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, feature_mix, mag_s1, mag_s2, utt_max, (long)per_utt,
+                     total, db_threshold, one_hot);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 // workspace: [B][stride] float header (feature max, centroids, partial sums, done flag) | [B][km::IW] ints + status word |
 // compacted active rows [B][T*F][D] (persistent form)
 static size_t dc_cluster_header_floats(int B, int D) { return (size_t)B * (1 + 2 * D + km::NBLK * 2 * (D + 1) + 1); }

@@ -4,11 +4,16 @@ synthetic corpus (``synthetic_wsj0_2mix.SyntheticWsj02mix``; there is no WSJ0 in
 for: ``data_path`` absent / ``None`` / ``""`` / ``"synthetic"``, or ``ONSSEN_SYNTHETIC_DATA=1`` in the environment (recipe configs
 carry the author's corpus path).  A ``data_path`` that is given but holds no files for the partition raises ``FileNotFoundError``
 like the reference's empty dataset would fail -- numbers must never come from synthetic mixtures by accident.  Either way the
-features and labels are computed on the GPU and the yield contract is the reference's."""
+features and labels are computed on the GPU and the yield contract is the reference's.
+
+``feature_utils`` carries the reference's helper names (``get_stft``, ``get_log_magnitude``, ``get_phase``, ``get_cos_difference``,
+``get_one_hot``: onssen/data/feature_utils.py:5-21,49-95), NumPy in / NumPy out over the same device kernels."""
 import glob
 import os
 
 from .. import options
+from . import feature_utils
+from .feature_utils import get_cos_difference, get_log_magnitude, get_one_hot, get_phase, get_stft
 from .synthetic_wsj0_2mix import SyntheticVoicePairs, SyntheticWsj02mix
 from .wsj0_2mix import Wsj02mixFiles, read_wav, write_wav
 
@@ -27,4 +32,5 @@ def wsj0_2mix_dataloader(model_name, feature_options, partition, device=None):
                             f"{partition!r}); pass data_path='' / 'synthetic' or set ONSSEN_SYNTHETIC_DATA=1 for the synthetic corpus")
 
 
-__all__ = ["wsj0_2mix_dataloader", "SyntheticVoicePairs", "SyntheticWsj02mix", "Wsj02mixFiles", "read_wav", "write_wav"]
+__all__ = ["wsj0_2mix_dataloader", "feature_utils", "get_stft", "get_log_magnitude", "get_phase", "get_cos_difference", "get_one_hot",
+           "SyntheticVoicePairs", "SyntheticWsj02mix", "Wsj02mixFiles", "read_wav", "write_wav"]

@@ -40,8 +40,12 @@ class ClipAdam(torch.optim.Optimizer):
     state_dicts move between the two.  After ``step_clipped`` ``p.grad`` still holds the UNclipped gradients unless
     ``write_clipped_grads=True``."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, write_clipped_grads=False):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, write_clipped_grads=False, weight_decay=0, amsgrad=False,
+                 maximize=False):
+        if weight_decay != 0 or amsgrad or maximize:
+            raise ValueError("ClipAdam implements plain Adam only: weight_decay / amsgrad / maximize are not supported "
+                             "(use torch.optim.Adam: fused_adam = 0)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False))
         self.write_clipped_grads = write_clipped_grads
         self._ws = None
         for group in self.param_groups:
@@ -61,14 +65,41 @@ class ClipAdam(torch.optim.Optimizer):
         scalar, like ``clip_grad_norm_``)."""
         return self._update(float(max_norm))
 
+    def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", []):     # a torch.optim.Adam state with options this kernel does not implement
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("ClipAdam.load_state_dict: weight_decay / amsgrad / maximize are not supported")
+        super().load_state_dict(state_dict)
+
     def _update(self, max_norm):
+        try:
+            return self._update_impl(max_norm)
+        finally:
+            # the kernel moves the parameters through raw pointers: tensor._version does not change, and step_clipped() does not
+            # pass through Optimizer.step's hook wrapper -- drop the packed weight images here, whoever built this optimizer
+            from .nn._core import invalidate_packed_weights
+            invalidate_packed_weights()
+            self._opt_called = True              # LR schedulers check that an optimizer step came before scheduler.step()
+
+    def _update_impl(self, max_norm):
         from .hip import get_lib
         lib = get_lib()
         groups = []
         for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
+            if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
+                raise ValueError("ClipAdam: weight_decay / amsgrad / maximize are not supported")
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
                 continue
+            # one kernel call takes ONE bias-correction step: parameters are bucketed by their own step count (torch.optim.Adam
+            # keeps it per parameter; a head that only gets a gradient now and then has a smaller one than the rest)
+            by_step = {}
+            for p in live:
+                st = self.state[p]
+                by_step.setdefault(int(st["step"]) if st else 0, []).append(p)
+            for _, ps in sorted(by_step.items()):
+                groups.append((group, ps))
+        for group, ps in groups:
             for p in ps:
                 st = self.state[p]
                 if not st:
@@ -77,7 +108,6 @@ class ClipAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
                     p.grad = p.grad.float().contiguous()
-            groups.append((group, ps))
         if not groups:
             return None
         # one call per parameter group (its own lr / betas / step); the clip coefficient is the GLOBAL norm's: with several

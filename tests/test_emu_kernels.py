@@ -1388,3 +1388,39 @@ def test_training_repack_of_the_whole_stack_in_one_launch(lib, H, ug, F, L, with
                 assert (y == 9).all()
             else:
                 assert np.array_equal(x, y), k
+
+
+def test_feature_helper_kernels_match_the_reference_fixture(lib, golden_dir):
+    """onssen_log_magnitude_f32 / onssen_cos_difference_f32 / onssen_one_hot_f32 (the kernels behind
+    onssen_amd.data.feature_utils) against the REFERENCE's get_log_magnitude / get_cos_difference / get_one_hot outputs
+    (tests/golden/g3_features.npz, tools/gen_golden_features.py; onssen/data/feature_utils.py:49-51,77-95)."""
+    z = np.load(f"{golden_dir}/g3_features.npz")
+    for tag in ("a", "b"):
+        X, S1, S2 = (np.ascontiguousarray(z[f"{tag}_{k}"]) for k in ("X", "S1", "S2"))
+        n = X.size
+        for eps, key in ((1e-7, "log_magnitude"), (1e-3, "log_magnitude_eps3")):
+            out = np.full(X.shape, np.nan, np.float32)
+            lib.log_magnitude(P(X.view(np.float32)), n, eps, P(out), None)
+            np.testing.assert_allclose(10.0 ** out.astype(np.float64), 10.0 ** z[f"{tag}_{key}"].astype(np.float64), rtol=2e-6, atol=1e-9)
+        big = (np.abs(X) > 1e-3) & (np.abs(S1) > 1e-3) & (np.abs(S2) > 1e-3)
+        for S, key in ((S1, "cos_s1"), (S2, "cos_s2")):
+            out = np.full(X.shape, np.nan, np.float32)
+            lib.cos_difference(P(X.view(np.float32)), P(S.view(np.float32)), n, P(out), None)
+            np.testing.assert_allclose(out[big], z[f"{tag}_{key}"][big], atol=1e-5)
+            assert np.all(np.abs(out) <= 1.0 + 1e-6)
+        feat, m1, m2 = z[f"{tag}_log_magnitude"], np.abs(S1), np.abs(S2)
+        for db in (40, 20):
+            out, umax = np.full(X.shape + (2,), np.nan, np.float32), np.zeros(1, np.float32)
+            lib.one_hot(P(feat), P(m1), P(m2), 1, n, float(db), P(umax), P(out), None)
+            assert umax[0] == feat.max()
+            np.testing.assert_array_equal(out.astype(np.float64), z[f"{tag}_one_hot_{db}"])   # magnitudes in: no tie tolerance needed
+    # two utterances in one call: each thresholded against its own maximum
+    fa, fb = z["a_log_magnitude"], z["a_log_magnitude"] - 1.0
+    feat2 = np.ascontiguousarray(np.stack([fa, fb]))
+    m1, m2 = np.abs(z["a_S1"]), np.abs(z["a_S2"])
+    out, umax = np.full((2,) + fa.shape + (2,), np.nan, np.float32), np.zeros(2, np.float32)
+    m1x2, m2x2 = np.ascontiguousarray(np.stack([m1, m1])), np.ascontiguousarray(np.stack([m2, m2]))
+    lib.one_hot(P(feat2), P(m1x2), P(m2x2), 2, fa.size, 40.0, P(umax), P(out), None)
+    np.testing.assert_array_equal(out[0], out[1])
+    np.testing.assert_array_equal(out[0].astype(np.float64), z["a_one_hot_40"])
+    assert lib.dll.onssen_log_magnitude_f32(None, 4, 1e-7, None, None) == -1 and lib.dll.onssen_one_hot_f32(P(fa), P(m1), P(m2), 0, 4, 40.0, P(umax), P(out), None) == -1
