@@ -772,6 +772,24 @@ def main():
             dp = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:400]}
         dog.cancel()
         result["dp_training_step_dc_l3_b16"] = dp
+    if world > 1:
+        # ---- per-rank health of the persistent kernels and the collective layer's settings IN FORCE (every rank reports; rank 0 prints):
+        #      the first hardware N = 8 run must be able to tell "a rank fell back / aborted" from "RCCL got more channels than the two
+        #      spare CUs per XCD hold" from the line alone
+        from onssen_amd.nn._core import _XcdPolicy
+        mine = torch.tensor([int(_XcdStatus.safe_protocol_seen), _XcdPolicy.aborts, _XcdPolicy.recovered, _XcdPolicy.persistent_launches,
+                             _XcdPolicy.fallback_launches, int(os.environ.get("NCCL_MAX_NCHANNELS", "-1")), torch.cuda.current_device()],
+                            device="cpu" if one_dev else dev, dtype=torch.int64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        keys = ("xcd_placement_independent_protocol_used", "persistent_launch_aborts", "calls_rerun_after_abort", "persistent_stack_launches",
+                "launch_per_step_stack_launches", "NCCL_MAX_NCHANNELS", "device_index")
+        result["per_rank_health"] = [dict(zip(keys, (int(v) for v in e.tolist()))) for e in every]
+        result["collective_layer"] = {"backend": "gloo (ONSSEN_BENCH_ONE_DEVICE harness self-test)" if one_dev else "nccl = RCCL over xGMI",
+                                      "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                                      "why": "one RCCL workgroup per channel; <= 16 channels = <= 2 workgroups per XCD = the CUs a 30-member "
+                                             "recurrence group leaves free (onssen_amd/dist.py: configure_rccl)"}
     if rank == 0:
         result["roofline"] = roof
         if dc_e2e is not None:
@@ -1062,101 +1080,136 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D, recurrence_only=False)
     return rec
 
 
+def _host_cpu():
+    """(model name, physical cores, hardware threads) of this host from /proc/cpuinfo (physical = distinct (package, core id) pairs)."""
+    model, cores, threads, phys, cid = "unknown", set(), 0, None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                cores.add((phys, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    n_phys = len(cores) or max(1, threads // 2)
+    return model, min(n_phys, usable), usable
+
+
 def cpu_baseline(sd, kind, wav_np, masks_np):
-    """The oracle restatement (NumPy STFT/iSTFT + ATen-on-CPU network) timed on this host's cores on a bounded sample of
-    the same workload.  ``value`` = the whole hot path on 8 of the batch's chunks per pass (best of a few thread counts:
-    ATen's LSTM does not scale to every core of a big host).  ``network_only`` = SURVEY 8(d)'s CPU reference timing of the
-    network forward alone: eval mode, no_grad, fp32, all cores torch uses by default, 3 warm-ups, median of 10 (B = 1) /
-    of up to 5 within 8 s (B = 32), T = 400."""
+    """The oracle restatement (NumPy STFT/iSTFT + ATen-on-CPU network + sklearn KMeans) timed on this host's cores beside the GPU
+    line, by BASELINE.md section 3's protocol (round 6): fp32, eval mode, no_grad, 3 warm-ups, median of 10 at B = 1 and at B = 32
+    (T = 400), thread counts up to ALL PHYSICAL cores tried and the best one used (ATen's LSTM gets slower when every core of a big
+    host is used; the counts tried and the count used are reported), the STFT / iSTFT legs threaded over the utterances.
+    ``value`` = the whole hot path at B = 32 with the reference's own back end: ``KMeans(n_clusters=2, random_state=0)`` of the
+    reference's era (``n_init=10``, the default until sklearn 1.4); the same with sklearn >= 1.4's ``n_init='auto'`` (one k-means++
+    run: a tenth of the clustering work) is reported beside it.  Passes are capped by time (at least 3) so that the default bench
+    stays within minutes; the counts actually run are in the record."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import np_oracle as O
     from oracle import torch_cpu as TC
     n_thr = torch.get_num_threads()
-    Bs = min(len(wav_np), 8)                     # bounded sample: 8 chunks of the batch
-    wav_s, masks_s = wav_np[:Bs], masks_np[:Bs]
-    cpu_model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
+    cpu_model, n_phys, n_usable = _host_cpu()
+    audio_s = T_FRAMES * HOP / SR
+    fwd = {"chimera": TC.chimera_forward, "phase_net": TC.phase_net_forward}.get(kind, TC.deep_clustering_forward)
+    thr_set = sorted({t for t in (4, 8, 16, 32, 64, n_phys) if t <= n_phys} | {min(n_phys, 8)})
+    pool = ThreadPoolExecutor(max_workers=min(n_phys, 32))
 
-    def once():
-        X = [O.stft(w, NFFT, HOP) for w in wav_s]
+    def batch_of(nb):
+        w = wav_np[:min(len(wav_np), nb)]
+        if len(w) < nb:
+            w = np.concatenate([w] * (nb // len(w) + 1))[:nb]
+        return w
+
+    def whole_path(wav_s, n_init):
+        """One pass of the whole path on ``wav_s`` utterances; returns per-leg seconds."""
+        nb = len(wav_s)
+        t0 = time.perf_counter()
+        X = list(pool.map(lambda w: O.stft(w, NFFT, HOP), wav_s))
         lm = np.stack([O.log_magnitude(x) for x in X])
+        t1 = time.perf_counter()
         if kind == "chimera":
             _, a, b = TC.chimera_forward(sd, lm)
             mk = np.stack([a.numpy(), b.numpy()], 1)
+            t2 = t3 = time.perf_counter()
         elif kind == "phase_net":
             ph = np.stack([np.stack([x.real, x.imag], -1) for x in X]).astype(np.float32)
             _, a, b, _, _ = TC.phase_net_forward(sd, lm, ph)
             mk = np.stack([a.numpy(), b.numpy()], 1)
+            t2 = t3 = time.perf_counter()
         else:                                    # the reference's own back end: sklearn KMeans on the active bins (evaluate.py:36-41)
             from sklearn.cluster import KMeans
             emb = TC.deep_clustering_forward(sd, lm).numpy()
-            mk = np.zeros((Bs, 2) + lm.shape[1:], np.float64)
-            for i in range(Bs):
+            t2 = time.perf_counter()
+            mk = np.zeros((nb, 2) + lm.shape[1:], np.float64)
+            for i in range(nb):                  # one utterance at a time, like the reference's evaluation loop (batch 1)
                 act = O.dc_active_bins(lm[i])
-                lab = KMeans(n_clusters=2, random_state=0, n_init=10).fit_predict(emb[i][act])
+                lab = KMeans(n_clusters=2, random_state=0, n_init=n_init).fit_predict(emb[i][act])
                 mk[i] = O.dc_binary_masks(lm[i], lab)
-        for i in range(Bs):
-            O.mask_istft(X[i], mk[i], HOP, N_SAMPLES)
+            t3 = time.perf_counter()
+        list(pool.map(lambda i: O.mask_istft(X[i], mk[i], HOP, N_SAMPLES), range(nb)))
+        t4 = time.perf_counter()
+        return {"stft": t1 - t0, "network": t2 - t1, "cluster": t3 - t2, "istft": t4 - t3, "total": t4 - t0}
 
-    best = None
-    for thr in sorted({min(n_thr, 8), min(n_thr, 16), min(n_thr, 32), n_thr}):
-        torch.set_num_threads(thr)
-        once()
-        ts, t_start = [], time.perf_counter()
-        while len(ts) < 5 and time.perf_counter() - t_start < 4.0:
+    def median_of(fn, warm, reps, cap_s):
+        for _ in range(warm):
+            fn()
+        rows, t_start = [], time.perf_counter()
+        while len(rows) < reps and (len(rows) < 3 or time.perf_counter() - t_start < cap_s):
             t0 = time.perf_counter()
-            once()
-            ts.append(time.perf_counter() - t0)
-        med_t = float(np.median(ts))
-        if best is None or med_t < best[0]:
-            best = (med_t, thr, len(ts))
-    torch.set_num_threads(n_thr)
-    med, best_thr, n_pass = best
+            r = fn()
+            rows.append((time.perf_counter() - t0, r))
+        rows.sort(key=lambda x: x[0])
+        return rows[len(rows) // 2][0], rows[len(rows) // 2][1], len(rows)
 
-    if kind == "phase_net":          # (no network-only leg: SURVEY 8(d) quotes it for the mask-estimation networks)
-        torch.set_num_threads(n_thr)
-        return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
-                "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "cpu_model": cpu_model, "host_threads": n_thr, "kind": "port",
-                "sample": f"{Bs} of the batch's {T_FRAMES}-frame chunks per pass, median of {n_pass} passes "
-                          f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads)"}
-    fwd = TC.chimera_forward if kind == "chimera" else TC.deep_clustering_forward
-    lm_all = np.stack([O.log_magnitude(O.stft(w, NFFT, HOP)) for w in wav_np[:min(len(wav_np), 32)]])
-    if len(lm_all) < 32:
-        lm_all = np.concatenate([lm_all] * (32 // len(lm_all) + 1))[:32]
-    # SURVEY 8(d)'s network-only reference timing, at the BEST thread count like `value` (ATen's LSTM gets slower when
-    # every core of a big host is used: the all-threads figure of rounds 1-2 was a strawman)
-    net = {}
-    for nb, reps, cap, thr_set in ((1, 7, 2.0, {min(n_thr, 4), min(n_thr, 8), min(n_thr, 16), min(n_thr, 32)}),
-                                   (32, 3, 6.0, {min(n_thr, 16), min(n_thr, 32), min(n_thr, 64)})):
-        x = lm_all[:nb]
-        best_n = None
-        for thr in sorted(thr_set):
+    # ---- network only (SURVEY 8(d)): best thread count up to all physical cores, then median of 10 at that count
+    net, best_thr = {}, {}
+    if kind != "phase_net":
+        for nb, cap in ((1, 3.0), (32, 8.0)):
+            lm_b = np.stack([O.log_magnitude(O.stft(w, NFFT, HOP)) for w in batch_of(nb)])
+            scan = {}
+            for thr in thr_set:
+                torch.set_num_threads(thr)
+                scan[thr] = median_of(lambda: fwd(sd, lm_b), 1, 3, 0.0)[0]
+            thr = min(scan, key=scan.get)
             torch.set_num_threads(thr)
-            for _ in range(2 if nb == 1 else 1):
-                fwd(sd, x)
-            ts, t_start = [], time.perf_counter()
-            while len(ts) < reps and (not ts or time.perf_counter() - t_start < cap):
-                t0 = time.perf_counter()
-                fwd(sd, x)
-                ts.append(time.perf_counter() - t0)
-            m = float(np.median(ts))
-            if best_n is None or m < best_n[0]:
-                best_n = (m, thr, len(ts))
-        m, thr, n_p = best_n
-        net[f"B{nb}"] = {"ms": 1e3 * m, "x_real_time": nb * (T_FRAMES * HOP / SR) / m, "passes": n_p, "threads": thr,
-                         "threads_tried": sorted(thr_set)}
+            m, _, n_p = median_of(lambda: fwd(sd, lm_b), 3, 10, cap)
+            best_thr[nb] = thr
+            net[f"B{nb}"] = {"ms": 1e3 * m, "x_real_time": nb * audio_s / m, "passes": n_p, "threads": thr,
+                             "threads_tried": {str(k): round(1e3 * v, 2) for k, v in scan.items()}}
+    # ---- the whole path: B = 1 and B = 32 at the network's best thread count; the era-faithful KMeans(n_init=10) and n_init='auto'
+    whole = {}
+    n_inits = (10, "auto") if kind == "deep_clustering" else (10,)
+    for nb, cap in ((1, 3.0), (min(32, max(len(wav_np), 1)), 24.0)):
+        torch.set_num_threads(best_thr.get(nb if nb == 1 else 32, min(n_phys, 16)))
+        ws = batch_of(nb)
+        for n_init in n_inits:
+            m, legs, n_p = median_of(lambda: whole_path(ws, n_init), 1 if nb > 1 else 3, 10, cap if n_init == 10 else cap / 2)
+            whole[f"B{nb}" + ("" if n_init == 10 else "_kmeans_auto")] = {
+                "ms": 1e3 * m, "x_real_time": nb * audio_s / m, "frames_per_s": nb * T_FRAMES / m, "passes": n_p,
+                "threads": torch.get_num_threads(), "legs_ms": {k: round(1e3 * v, 2) for k, v in legs.items()}}
     torch.set_num_threads(n_thr)
-    return {"value": Bs * (T_FRAMES * HOP / SR) / med, "unit": "audio-seconds separated per wall-second (x real time)",
-            "frames_per_s": Bs * T_FRAMES / med, "cores": best_thr, "cpu_model": cpu_model, "host_threads": n_thr, "kind": "port",
-            "sample": f"{Bs} of the batch's 400-frame chunks per pass, median of {n_pass} passes "
-                      f"(NumPy fp64 STFT/iSTFT single-threaded + ATen/oneDNN fp32 network on {best_thr} threads"
-                      + ("; sklearn KMeans(2) on the active bins' embeddings like egs/wsj0-2mix/deep_clustering/evaluate.py:36-41)" if kind == "deep_clustering" else ")"),
-            "network_only": net}
+    pool.shutdown()
+    nb_big = min(32, max(len(wav_np), 1))
+    head = whole[f"B{nb_big}"]
+    return {"value": head["x_real_time"], "unit": "audio-seconds separated per wall-second (x real time)",
+            "frames_per_s": head["frames_per_s"], "cores": head["threads"], "cores_physical": n_phys, "threads_used": head["threads"],
+            "host_threads": n_usable, "cpu_model": cpu_model, "kind": "port", "kmeans_n_init": 10 if kind == "deep_clustering" else None,
+            "protocol": "BASELINE.md section 3: fp32, eval, no_grad, warm-ups then median of up to 10 passes (time-capped, >= 3), B = 1 and "
+                        "B = 32 x 400 frames, thread counts up to all physical cores scanned on the network and the best one used",
+            "sample": f"all {nb_big} chunks of the batch per pass, median of {head['passes']} passes: NumPy fp64 STFT / iSTFT threaded over the "
+                      f"utterances + ATen/oneDNN fp32 network on {head['threads']} of {n_phys} physical cores"
+                      + ("; sklearn KMeans(2, random_state=0, n_init=10) per utterance on the active bins' embeddings like "
+                         "egs/wsj0-2mix/deep_clustering/evaluate.py:36-41" if kind == "deep_clustering" else ""),
+            "whole_path": whole, "network_only": net}
 
 
 if __name__ == "__main__":

@@ -225,6 +225,7 @@ static inline void emu_atomic_store(T* p, V val) {
 #define __hip_atomic_store(p, v, order, scope) emu_atomic_store((p), (v))
 static inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 // a hardware wave runs its lanes in lockstep; here the lanes are threads, so the scheduling barrier is a real one
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 // a wave executes s_waitcnt once for all of its lanes: here the lanes are threads, so "every earlier store of

@@ -42,6 +42,37 @@ def test_recorded_two_rank_self_test_line():
     assert dp["ms_per_step"] > 0 and dp["ms_per_step_without_exchange"] > 0
 
 
+def test_recorded_eight_rank_self_test_line():
+    """profiles/r06_bench_selflaunch_8rank.json: ``ONSSEN_BENCH_ONE_DEVICE=1 python bench.py --gpus 8 --steps 3
+    --warmup 1`` on the 1-GPU box (tools/gpu_r06e.sh) -- the command line the driver's first N = 8 SCALE run uses, with every rank on
+    cuda:0 over gloo and launch-per-step kernels.  What it proves is the HARNESS at world 8: the self-launcher, the rendezvous, the
+    barrier + max-over-ranks timing, the whole-job value, the data-parallel leg with its 7 buckets, and the per-rank health block the
+    line carries at N > 1 (round 6).  Its timings say nothing about 8 GPUs."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_selflaunch_8rank.json")
+    lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 only
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert len(r["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in r["per_rank_ms_per_step"])
+    assert abs(r["ms_per_step"] - max(r["per_rank_ms_per_step"])) <= 1e-6 * r["ms_per_step"]      # MAX over ranks
+    audio_per_step = 8 * r["config"]["chunks_per_gpu"] * r["config"]["frames_per_chunk"] * 64 / 8000.0
+    assert abs(r["value"] - audio_per_step / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]        # whole job: all eight ranks' chunks
+    assert r["config"]["parallelism"].startswith("utterance-sharded x8") and r["vs_baseline"] is None
+    health = r["per_rank_health"]
+    assert len(health) == 8
+    for h in health:
+        assert set(h) == {"xcd_placement_independent_protocol_used", "persistent_launch_aborts", "calls_rerun_after_abort",
+                          "persistent_stack_launches", "launch_per_step_stack_launches", "NCCL_MAX_NCHANNELS", "device_index"}
+        assert h["persistent_launch_aborts"] == 0 and h["calls_rerun_after_abort"] == 0
+    assert "gloo" in r["collective_layer"]["backend"] and r["collective_layer"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    dp = r["dp_training_step_dc_l3_b16"]
+    assert "error" not in dp, dp
+    assert len(dp["per_rank_ms_per_step"]) == 8 and dp["all_reduce_bytes_per_step"] == 23_908_980 * 4
+    assert len(dp["bucket_bytes"]) == 7 and sum(dp["bucket_bytes"]) == dp["all_reduce_bytes_per_step"]
+    assert dp["replicas_identical_after_dp_steps"] is True and dp["buckets_issued_inside_backward"] >= 1
+    assert len(dp["last_loss_per_rank"]) == 8 and len(set(dp["last_loss_per_rank"])) == 8       # every rank trained on its own batches
+
+
 def test_recorded_bench_line_carries_the_contract():
     """profiles/r05_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
     key the bench contract names, the roofline and CPU-baseline blocks, and the round-5 additions."""

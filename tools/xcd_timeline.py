@@ -23,7 +23,8 @@ def layer(dbgflag):
 AB = int(os.environ.get('AB', 0))
 for _ in range(3): layer(32 | AB)
 torch.cuda.synchronize()
-d = ws[nb - 65536:].cpu().numpy().view(np.int64)[:64 * 24].reshape(64, 24)[2:62].astype(np.float64)
+STN = int(os.environ.get('STN', 64))      # stamped steps of the build (-DONSSEN_XCD_PROFILE_STN, default 64)
+d = ws[nb - 65536:].cpu().numpy().view(np.int64)[:STN * 24].reshape(STN, 24)[2:STN - 2].astype(np.float64)
 per = (d[1:, 0] - d[:-1, 0]).mean()
 m = lambda a, b: (d[:, a] - d[:, b]).mean()
 st = ws[:2048].cpu().numpy().view(np.uint32)
