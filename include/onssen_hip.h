@@ -438,6 +438,18 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
                       float* mag_s2, float* cos_s1, float* cos_s2, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Weight guard: do packed weight images still belong to the live parameters?  `ptrs` / `numel` are DEVICE arrays of n parameter
+ * tensors (float32, any 4-byte type) and their element counts.  mode 0: ref[t] = a 32-bit fold of a strided sample (<= `samples`
+ * elements, first and last included) of tensor t -- call when the images are built; mode 1: the same fold compared with ref[t],
+ * `*flag |= 1` on a difference (sticky; the caller reads and clears it asynchronously).  One launch of n small workgroups,
+ * stream-ordered, capturable.  Nothing in the reference corresponds to it: there a module's weights ARE its parameters
+ * (onssen/utils/test.py:21-35 loads a checkpoint and runs); here it keeps a cached re-layout honest against updates that bypass
+ * autograd's version counter (fused optimizers, p.data arithmetic).
+ */
+int onssen_param_guard_u32(const void* const* ptrs, const int64_t* numel, int n, int samples, int mode, uint32_t* ref, uint32_t* flag,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The reference's stand-alone feature helpers on ONE utterance's arrays (onssen_amd/data/feature_utils.py binds them under
  * the reference's names).  `stft*` are complex arrays as interleaved (re, im) float32 pairs, `n` complex elements.
  *   onssen_log_magnitude_f32   out[e] = log10f(|stft[e]| + epsilon)           get_log_magnitude, onssen/data/feature_utils.py:49-51

@@ -87,6 +87,7 @@ SIGNATURES = {
     "onssen_wav_info": (_i, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "onssen_wav_read_batch_f32": (_i, [C.POINTER(C.c_char_p), _i, _vp, _i64, _vp, _vp, _vp, _i]),
     "onssen_labels_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "onssen_param_guard_u32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "onssen_log_magnitude_f32": (_i, [_vp, _i64, _f, _vp, _vp]),
     "onssen_cos_difference_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "onssen_one_hot_f32": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp]),
@@ -412,6 +413,9 @@ class Lib:
     def labels(self, mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2, cos_s1, cos_s2, stream):
         self.check(self.dll.onssen_labels_f32(mix, s1, s2, feat, B, T, F, db, utt_max, one_hot, mag_mix, mag_s1, mag_s2,
                                               cos_s1, cos_s2, stream), "onssen_labels_f32")
+
+    def param_guard(self, ptrs, numel, n, samples, mode, ref, flag, stream):
+        self.check(self.dll.onssen_param_guard_u32(ptrs, numel, n, samples, mode, ref, flag, stream), "onssen_param_guard_u32")
 
     def log_magnitude(self, stft_ri, n, eps, out, stream):
         self.check(self.dll.onssen_log_magnitude_f32(stft_ri, n, eps, out, stream), "onssen_log_magnitude_f32")

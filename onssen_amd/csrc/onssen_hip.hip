@@ -1515,6 +1515,16 @@ int onssen_labels_f32(const float* stft_mix, const float* stft_s1, const float* 
   return ONSSEN_OK;
 }
 
+int onssen_param_guard_u32(const void* const* ptrs, const int64_t* numel, int n, int samples, int mode, uint32_t* ref, uint32_t* flag,
+                           void* stream) {
+  if (!ptrs || !numel || !ref || !flag || n <= 0 || samples <= 0 || (mode != 0 && mode != 1)) return ONSSEN_E_ARG;
+  ONSSEN_CLEAR_ERROR();
+  hipLaunchKernelGGL(param_guard_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float* const*>(ptrs),
+                     reinterpret_cast<const long long*>(numel), samples, mode, ref, flag);
+  ONSSEN_LAUNCH_CHECK();
+  return ONSSEN_OK;
+}
+
 static unsigned ew_blocks(long total) { const long nb = (total + 255) / 256; return (unsigned)(nb > 8192 ? 8192 : nb); }
 
 int onssen_log_magnitude_f32(const float* stft_ri, int64_t n, float epsilon, float* out, void* stream) {

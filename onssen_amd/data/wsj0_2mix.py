@@ -153,11 +153,17 @@ class Wsj02mixFiles:
         hit = self._headers.get(path)
         if hit is None:
             from ..hip import get_lib
-            fr, rate, _, _ = get_lib().wav_info(path)
+            fr, rate, ch, bits = get_lib().wav_info(path)
+            # a header is input: a streamed file states 0xFFFFFFFF data bytes, a truncated one more frames than it holds -- the row (and the
+            # pinned buffer behind it) must be sized from what the file can actually contain
+            frame_bytes = max(1, ch) * max(1, abs(bits) // 8)
+            fr = min(int(fr), os.path.getsize(path) // frame_bytes)
+            if fr <= 0 or rate <= 0:
+                raise OSError(f"{path}: no audio frames (header: {fr} frames at {rate} Hz)")
             hit = self._headers[path] = (fr, rate)
         return hit
 
-    def _read_batch(self, files, slot):
+    def _read_batch(self, files, slot, rng=None):
         """Host side of one batch: the 3 x len(files) signals (mix, s1, s2 per utterance) into the rows of ``slot`` by the
         library's batch reader (csrc/wav_io.inc, ``loader_workers`` host threads, no Python per sample), per-utterance sample
         counts, and the crops the seeded generator draws -- in file order, as the per-utterance loop of rounds 1-4 drew them.
@@ -194,7 +200,7 @@ class Wsj02mixFiles:
         for b, n in enumerate(n_utt):
             T = 1 + int(n) // hop
             times = L // T + 1 if T <= L else 1                   # "pad in a double-copy fashion" (wsj0_2mix.py:118-123)
-            starts[b] = int(self.rng.integers(0, T * times - L))
+            starts[b] = int((rng or self.rng).integers(0, T * times - L))
         return slot, n_utt, starts
 
     def _device_batch(self, item):
@@ -212,15 +218,16 @@ class Wsj02mixFiles:
         trip = torch.arange(3, device=self.device)[None, :, None]
         return logmag.view(B, 3, T, F)[rows, trip, idx[:, None, :]], ri.view(B, 3, T, F, 2)[rows, trip, idx[:, None, :]]
 
-    def host_batches(self, order=None, ring=None):
-        """Generator over the HOST side of the epoch's batches (``_read_batch`` items), synchronously on the calling thread."""
+    def host_batches(self, order=None, ring=None, rng=None):
+        """Generator over the HOST side of the epoch's batches (``_read_batch`` items), synchronously on the calling thread.
+        ``rng``: the generator the crops are drawn from (default: the loader's own)."""
         if order is None:
             order = self.rng.permutation(len(self.file_list)) if self.shuffle else np.arange(len(self.file_list))
         ring = ring or [_Slot(self.device.type == "cuda")]
         for k, i0 in enumerate(range(0, len(order), self.batch_size)):
             slot = ring[k % len(ring)]
             slot.wait()
-            yield self._read_batch([self.file_list[i] for i in order[i0:i0 + self.batch_size]], slot)
+            yield self._read_batch([self.file_list[i] for i in order[i0:i0 + self.batch_size]], slot, rng)
 
     def _prefetched(self, order):
         """``host_batches`` run ahead of the consumer by ``loader_prefetch`` batches on a producer thread (``loader_workers``
@@ -235,20 +242,26 @@ class Wsj02mixFiles:
         ring = [_Slot(self.device.type == "cuda") for _ in range(depth + 2)]    # queue + the one being filled + the one being copied
         q, stop = queue.Queue(maxsize=depth), threading.Event()
 
+        def put(item):                             # never blocks past `stop`: a consumer that abandons the epoch must not strand the producer
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def produce():
             try:
-                for item in self.host_batches(order, ring):
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            pass
-                    if stop.is_set():
+                for item in self.host_batches(order, ring, rng):
+                    if not put(item):
                         return
-                q.put(None)
+                put(None)
             except BaseException as e:             # reported by the consumer, on the training thread
-                q.put(e)
+                put(e)
+        # the producer draws its crops from a CHILD generator spawned here, on the calling thread: the parent generator is never touched
+        # off-thread (numpy Generators are not thread-safe), and an abandoned epoch cannot perturb the next one's sequence
+        rng = self.rng.spawn(1)[0]
         th = threading.Thread(target=produce, name="onssen-wsj0-2mix-loader", daemon=True)
         th.start()
         try:
@@ -261,7 +274,7 @@ class Wsj02mixFiles:
                 yield item
         finally:
             stop.set()
-            th.join(timeout=5.0)
+            th.join()                              # (bounded: every put gives up within 0.1 s of `stop`, a batch read is finite)
 
     def __iter__(self):
         if self.partition == "tt":

@@ -50,6 +50,16 @@ class XcdNonFinite(XcdAborted):
     semantics: NaN in, NaN out).  Not an abort: no back-off."""
 
 
+class StalePackedWeights(XcdAborted):
+    """An inference forward ran on packed weight images that no longer belong to the live parameters: something moved the weights
+    without bumping ``tensor._version`` and without ``invalidate_packed_weights()`` -- a FUSED torch optimizer built by hand,
+    ``p.data`` arithmetic, a foreign kernel -- while the model stayed in eval mode.  Found by the weight guard (``_WeightGuard``: a
+    device-side sampled checksum, compared asynchronously); by the time this is raised the stale images are already dropped, so the
+    call only has to be repeated: ``separation.separate_*`` and ``evaluate.tester.eval`` do that by themselves (``recovering``), a
+    bare ``model(x)`` raises it at the next forward / ``flush()`` like an aborted launch.  Not an abort: no back-off, and the re-run
+    stays on the persistent kernels."""
+
+
 class _XcdPolicy:
     """What happens after an aborted persistent launch (a co-tenant kernel held more than the 2 spare CUs of an XCD for
     longer than the bounded wait, two persistent launches overlapped, ...): the abort is *per launch*, not a property of
@@ -114,6 +124,10 @@ def recovering(fn):
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
         try:
+            return fn(*args, **kwargs)
+        except StalePackedWeights as e:            # the images are already dropped: the same call again, on the same kernels
+            _XcdPolicy.recovered += 1
+            warnings.warn(f"onssen_amd: {e}  Re-running this call on freshly packed weights.", RuntimeWarning)
             return fn(*args, **kwargs)
         except XcdAborted as e:
             _XcdPolicy.recovered += 1
@@ -195,6 +209,52 @@ class _XcdSerial:
         cls.last[device.index] = (cur.cuda_stream, ev)
 
 
+class _WeightGuard:
+    """Device-side sampled checksum of the source tensors of a set of packed weight images (csrc/optim.inc: param_guard_kernel).
+    ``arm(tensors)`` when the images are built; ``check()`` whenever they are REUSED by an inference forward: one launch of
+    len(tensors) small workgroups that raises a sticky device flag on a mismatch, fetched asynchronously with the persistent
+    kernels' status words (``_XcdStatus.post_guard`` / ``poll``) -- no synchronisation.  Eager forwards only: nothing is added to a
+    hipGraph capture (a graph is bound to the images it captured; re-capture after the weights change).
+    ``weight_guard`` / ONSSEN_WEIGHT_GUARD=0 disables it."""
+    SAMPLES = 2048
+    stale_seen = 0
+    tick = 0               # bumped once per BLSTM stack forward (run_blstm): a guard checks at most once per tick
+                           # (the heads' images are fetched more than once per forward on some paths)
+
+    def __init__(self, what):
+        self.what = what
+        self.n = 0
+        self.last_tick = -1
+        self.posted = False  # one status copy in flight per guard: the device flag is sticky, a later copy still finds it
+
+    def arm(self, tensors):
+        if options.get("weight_guard") != "1" or not tensors or not tensors[0].is_cuda:
+            self.n = 0
+            return
+        dev = tensors[0].device
+        live = [t.detach() for t in tensors if t.numel() > 0 and t.element_size() == 4 and t.is_contiguous()]
+        self.keep = live                                                     # the table holds raw pointers
+        self.n = len(live)
+        if self.n == 0:
+            return
+        self.ptrs = torch.tensor([t.data_ptr() for t in live], dtype=torch.int64).to(dev)
+        self.numel = torch.tensor([t.numel() for t in live], dtype=torch.int64).to(dev)
+        self.ref = torch.zeros(self.n, dtype=torch.int32, device=dev)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        get_lib().param_guard(self.ptrs.data_ptr(), self.numel.data_ptr(), self.n, self.SAMPLES, 0, self.ref.data_ptr(), self.flag.data_ptr(), _stream())
+
+    def check(self):
+        if self.n == 0 or self.last_tick == _WeightGuard.tick or options.get("weight_guard") != "1":
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return       # a captured graph points at THESE images whatever the parameters do later (re-capture after an update): the check
+                         # would cost every replay two dependent launches (measured +0.018 ms on the 1.86 ms headline step) and could not be acted on
+        self.last_tick = _WeightGuard.tick
+        get_lib().param_guard(self.ptrs.data_ptr(), self.numel.data_ptr(), self.n, self.SAMPLES, 1, self.ref.data_ptr(), self.flag.data_ptr(), _stream())
+        if not self.posted:
+            _XcdStatus.post_guard(self)
+
+
 class _XcdStatus:
     """The persistent kernels bound every wait and report through workspace words instead of hanging:
     [280] != 0 -> a wait gave up, the launch aborted, outputs are invalid; [281] == 1 -> some exchange group was
@@ -223,6 +283,18 @@ class _XcdStatus:
         cls.pending.append((ev, host, wsb))
 
     @classmethod
+    def post_guard(cls, guard):
+        """Flag word of a weight guard (``_WeightGuard.check``): non-zero = the parameters no longer match the packed images."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        host = torch.empty(1, dtype=torch.int32).pin_memory()
+        host.copy_(guard.flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        guard.posted = True
+        cls.pending.append((ev, host, guard))
+
+    @classmethod
     def post_cluster(cls, ws, offset):
         """Status word of the persistent Lloyd kernel (separation.dc_masks): non-zero = a bounded wait gave up."""
         if torch.cuda.is_current_stream_capturing():
@@ -246,6 +318,17 @@ class _XcdStatus:
                 ev.synchronize()
             if not ev.query():
                 keep.append((ev, host, wsb))
+                continue
+            if isinstance(wsb, _WeightGuard):           # weight guard: the live parameters differ from the packed images' source
+                wsb.posted = False
+                if int(host[0]) != 0:
+                    wsb.flag.zero_()
+                    invalidate_packed_weights()         # every image of the process is rebuilt at its next use
+                    _WeightGuard.stale_seen += 1
+                    err = err or StalePackedWeights(
+                        f"packed weight images of {wsb.what} were stale: the parameters changed without a version bump (a fused "
+                        "optimizer step, p.data arithmetic, ...) while the model stayed in eval mode, and at least one forward ran on "
+                        "the old images.  They have been dropped; repeat the call (model.repack() after such updates avoids this).")
                 continue
             if isinstance(wsb, tuple):                  # clustering status word
                 if int(host[0]) != 0:
@@ -386,6 +469,17 @@ def invalidate_packed_weights():
     _WEIGHT_EPOCH[0] += 1
 
 
+_GRAPH_KEEPALIVE = []        # packed images a hipGraph capture has seen and that were rebuilt since: a captured graph holds raw pointers
+                             # into them, so they are parked here instead of being returned to the allocator (the graph then replays on the
+                             # OLD weights -- re-capture after the weights change -- but never on memory somebody else owns)
+
+
+def _park_if_captured(owner, names):
+    if getattr(owner, "_in_graph", False):
+        _GRAPH_KEEPALIVE.append([getattr(owner, n, None) for n in names])
+        owner._in_graph = False
+
+
 def _version_key(tensors):
     key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors) + (_WEIGHT_EPOCH[0],)
     if options.get("check_weights") == "1" and not torch.cuda.is_current_stream_capturing():
@@ -441,13 +535,19 @@ class _PackedImages:
         self.p, self.ug = params, ug
         self.key = None
         self._whhT = None
+        self.guard = _WeightGuard(f"the BLSTM stack ({params.num_layers} x {params.hidden_size})")
 
     def get(self, force=False, lean=False):
         p, lib = self.p, get_lib()
         flat = p.flat_weights()
         key = _version_key(flat) + (bool(lean),)
+        capturing = flat[0].is_cuda and torch.cuda.is_current_stream_capturing()
         if key == self.key and not force:
+            self._in_graph = getattr(self, "_in_graph", False) or capturing
+            self.guard.check()                   # (asynchronous: see _WeightGuard)
             return self
+        _park_if_captured(self, ("wih", "whh", "bias", "whh_x3", "wih_x3", "wih_img", "wih_frag0", "bias0_tail", "_whhT"))
+        self._in_graph = capturing
         dev = flat[0].device
         H, L = p.hidden_size, p.num_layers
         self.Hp, self.NP, self.KQ, we = lib.lstm_geometry(H, self.ug)
@@ -459,6 +559,7 @@ class _PackedImages:
         if lean:
             self._get_lean(flat, dev, H, L, we3, st)
             self.key = key
+            self.guard.n = 0                     # (the training forward rebuilds its images every step: nothing to guard)
             return self
         for l in range(L):
             in_l = p.input_size if l == 0 else 2 * H
@@ -502,6 +603,7 @@ class _PackedImages:
                 self.bias0_tail = torch.cat([c.reshape(-1), a[:, :, in_l - 1].reshape(-1)]).contiguous() if in_l % 32 == 1 and in_l > 1 else None
         self.key = key
         self._whhT = None
+        self.guard.arm(flat)
         return self
 
     def _get_lean(self, flat, dev, H, L, we3, st):
@@ -568,13 +670,19 @@ class PackedHead:
     def __init__(self, linear: nn.Linear, bn, H):
         self.lin, self.bn, self.H = linear, bn, H
         self.key = None
+        self.guard = _WeightGuard(f"the {tuple(linear.weight.shape)} head" + (" + BatchNorm" if bn is not None else ""))
 
     def get(self, Hp):
         lin, bn = self.lin, self.bn
         ts = [lin.weight, lin.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
         key = (_version_key(ts), Hp)
+        capturing = lin.weight.is_cuda and torch.cuda.is_current_stream_capturing()
         if key == self.key:
+            self._in_graph = getattr(self, "_in_graph", False) or capturing
+            self.guard.check()
             return self
+        _park_if_captured(self, ("w", "b", "planes", "img"))
+        self._in_graph = capturing
         lib, dev, N = get_lib(), lin.weight.device, lin.weight.shape[0]
         self.w = torch.empty(N, 2 * Hp, device=dev, dtype=torch.float32)
         self.b = torch.empty(N, device=dev, dtype=torch.float32)
@@ -592,6 +700,7 @@ class PackedHead:
         self.img = torch.empty(N, self.ld3 // 32, 2, 32, device=dev, dtype=torch.int16)     # x3 image (onssen_linear_x3p)
         lib.x3_image(self.w.data_ptr(), 2 * Hp, 0, 1, N, 2 * Hp, self.img.data_ptr(), _stream())
         self.N, self.key = N, key
+        self.guard.arm(ts)
         return self
 
 
@@ -664,6 +773,7 @@ def run_blstm(packed: PackedBLSTM, ws: _Workspaces, x, tag="rnn", need_y=True, f
     lib = get_lib()
     p = packed.p
     B, T, In = x.shape
+    _WeightGuard.tick += 1
     if not torch.cuda.is_current_stream_capturing():
         _XcdStatus.poll()
     if frames is not None and precision() == "bf16":

@@ -68,7 +68,10 @@ TABLE = {
     "serialize_persistent": ("ONSSEN_XCD_SERIALIZE", "0", _flag, "one persistent launch in flight per device across streams"),
     "nonfinite": ("ONSSEN_NONFINITE", "raise", _choice("raise", "propagate"), "non-finite activations seen by a persistent launch"),
     "check": ("ONSSEN_CHECK", "0", _flag, "synchronise and examine the persistent launches' status words after every forward"),
-    "check_weights": ("ONSSEN_CHECK_WEIGHTS", "0", _flag, "verify the packed weight images against the parameters before every forward"),
+    "check_weights": ("ONSSEN_CHECK_WEIGHTS", "0", _flag, "verify the packed weight images against the parameters before every forward (one synchronisation each: debugging)"),
+    "weight_guard": ("ONSSEN_WEIGHT_GUARD", "1", _flag, "every inference forward that reuses cached weight images compares a device-side sampled checksum of the "
+                     "live parameters with the one taken when the images were built (one small launch, no synchronisation); a mismatch drops the "
+                     "images and raises StalePackedWeights at the next status poll (separate_* / tester.eval re-run the call by themselves)"),
     "dc_cluster": ("ONSSEN_DC_PERSISTENT", "1", _alias({"persistent": "1", "steps": "0"}),
                    "deep-clustering 2-means: all Lloyd passes in one launch, or one launch per pass"),
     "dc_compact": ("ONSSEN_DC_COMPACT", "1", _flag, "fc_dc stores only the active bins' embeddings into the clustering's array"),

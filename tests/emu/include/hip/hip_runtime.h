@@ -210,6 +210,7 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, e
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST)
 template <class T, class V>
 static inline void emu_atomic_store(T* p, V val) {
   const T v = static_cast<T>(val);

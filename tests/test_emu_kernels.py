@@ -881,6 +881,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
     monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)     # scramble=1: the placement-independent protocol
     db_rows = _shm((B, 2, NP), fill=np.nan) if xcd else None
     gates_saved = _shm(gates.shape); gates_saved[...] = gates
+    gates_before = np.array(gates)             # a private copy: the _img launch below may only READ the saved gates
     lib.lstm_train_backward(B, T, H, ug, P(wT), P(dy), P(gates), P(cs), P(wsb), wsb.nbytes, form, None, P(db_rows) if xcd else None)
     if xcd and (2 * NP) % 32 == 0:
         # round 5: the same launch leaving dP as the gradient GEMMs' x3 image instead of fp32 -- bit for bit onssen_x3_image_f32 of
@@ -900,7 +901,7 @@ def test_lstm_train_forward_and_backward_recurrence(lib, monkeypatch, H, ug, B, 
         own2 = np.concatenate([owned, owned]).reshape(2 * NP // 32, 32)
         got, want = np.array(img), np.array(ref)
         assert np.array_equal(got[:, :, 0][:, own2], want[:, :, 0][:, own2]) and np.array_equal(got[:, :, 1][:, own2], want[:, :, 1][:, own2])
-        assert np.array_equal(np.array(gates_saved), np.array(gates_saved)) and wsb2.view(np.uint32)[280] == 0
+        assert np.array_equal(np.array(gates_saved), gates_before) and wsb2.view(np.uint32)[280] == 0
         np.testing.assert_allclose(np.array(db2), np.array(db_rows), rtol=1e-6, atol=1e-7)
     if xcd:      # the kernel's per-row sums of dP over time (the bias gradient's operand) against the dP it wrote
         np.testing.assert_allclose(np.array(db_rows), np.array(gates).sum(0), rtol=1e-5, atol=1e-6)
@@ -1424,3 +1425,41 @@ def test_feature_helper_kernels_match_the_reference_fixture(lib, golden_dir):
     np.testing.assert_array_equal(out[0], out[1])
     np.testing.assert_array_equal(out[0].astype(np.float64), z["a_one_hot_40"])
     assert lib.dll.onssen_log_magnitude_f32(None, 4, 1e-7, None, None) == -1 and lib.dll.onssen_one_hot_f32(P(fa), P(m1), P(m2), 0, 4, 40.0, P(umax), P(out), None) == -1
+
+
+def test_param_guard_kernel(lib):
+    """onssen_param_guard_u32 (csrc/optim.inc): mode 0 stores the sampled folds, mode 1 raises the sticky flag only when a tensor
+    changed; first / last elements are always sampled; an optimizer-like update of every element is always seen."""
+    import ctypes
+    rng = np.random.default_rng(21)
+    tensors = [rng.standard_normal(n).astype(np.float32) for n in (1, 7, 2048, 2049, 100_003)]
+    ptrs = np.array([t.ctypes.data for t in tensors], np.int64)
+    numel = np.array([t.size for t in tensors], np.int64)
+    ref, flag = np.zeros(len(tensors), np.uint32), np.zeros(1, np.uint32)
+    run = lambda mode: lib.param_guard(P(ptrs), P(numel), len(tensors), 2048, mode, P(ref), P(flag), None)
+    run(0)
+    assert len(set(ref.tolist())) == len(tensors)
+    run(1)
+    assert flag[0] == 0
+    for t, idx in ((4, 0), (4, tensors[4].size - 1), (1, 3), (0, 0)):       # first / last element of a long tensor, any element of a short one
+        keep = tensors[t][idx]
+        tensors[t][idx] = np.nextafter(keep, np.float32(10.0))               # one ulp
+        run(1)
+        assert flag[0] == 1, (t, idx)
+        tensors[t][idx] = keep
+        flag[0] = 0
+        run(1)
+        assert flag[0] == 0
+    tensors[4] *= np.float32(1.0 - 1e-3)                                     # what an optimizer step does: every element moves a little
+    run(1)
+    assert flag[0] == 1
+    run(0)                                                                   # re-arm on the new values; the flag is sticky until the owner clears it
+    assert flag[0] == 1
+    flag[0] = 0
+    run(1)
+    assert flag[0] == 0
+    a, b = tensors[2][0], tensors[2][2047]                                   # two sampled elements swapped: the fold is position dependent
+    tensors[2][0], tensors[2][2047] = b, a
+    run(1)
+    assert flag[0] == 1
+    assert lib.dll.onssen_param_guard_u32(None, None, 1, 16, 0, None, None, None) == -1

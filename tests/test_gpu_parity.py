@@ -29,12 +29,47 @@ def dev():
 def prec(request, monkeypatch):
     """The product's forward paths: split-bf16 with the XCD-local persistent recurrence (default), split-bf16 with one
     launch per time step, exact-fp32 MFMA in the persistent recurrence (round 3) and with one launch per time step.
-    Tolerances: exact fp32 -> |a-b| <= 1e-5 + 1e-4|b|; split-bf16 (~1e-5 relative per dot product) ->
-    |a-b| <= 5e-5 + 1e-4|b|; per-vector rel-L2 <= 1e-4 (the north-star figure) in all."""
+    Tolerances: exact fp32 -> |a-b| <= 1e-5 + 1e-4|b| (measured <= 1.4e-6); split-bf16 (~1e-5 relative per dot
+    product) -> |a-b| <= 3e-5 + 1e-4|b| on the TINY fixtures and the gain >= 1.5 oracle shapes (round 6: tightened from 5e-5 to what
+    the runs support with margin -- the worst case of the whole suite is 2.4e-5 on g1_deep_clustering_H8_L1, whose gain-2.0 weights
+    and 16-wide head leave some 20-vectors with a small norm in front of F.normalize, which amplifies the absolute error; every
+    other comparison is <= 1.4e-5) and the STRICT 1e-5 at BASELINE sizes (test_full_size_golden_subsample: measured <= 4.2e-6);
+    per-vector rel-L2 <= 1e-4 (the north-star figure) in all.  Every comparison prints what it measured (``check``) and the
+    numbers are written to gpurun_out/parity_errors.json (committed per round as profiles/rNN_parity_errors.json)."""
     monkeypatch.setenv("ONSSEN_PRECISION", request.param.split("-")[0])
     monkeypatch.setenv("ONSSEN_XCD", "0" if request.param.endswith("steps") else "1")
     monkeypatch.setenv("ONSSEN_CHECK", "1")
-    return {"name": request.param, "atol": 1e-5 if request.param.startswith("f32") else 5e-5}
+    return {"name": request.param, "atol": 1e-5 if request.param.startswith("f32") else 3e-5}
+
+
+PARITY_LOG = {}      # test id -> measured errors; written to gpurun_out/parity_errors.json when the module ends (profiles/r06_parity_errors.json)
+
+
+def check(tag, got, ref, atol, rtol=1e-4, vectors=True):
+    """assert_allclose that first PRINTS what it measured (max |a-b|, the worst ratio |a-b| / (atol + rtol|b|), max per-vector
+    rel-L2), so that the numbers behind every golden comparison can be read from the GPU test log / the JSON beside it."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    rec = {"max_abs": float(d.max()), "worst_ratio_of_bound": float((d / (atol + rtol * np.abs(ref))).max()), "atol": atol, "rtol": rtol}
+    if vectors and got.ndim >= 2 and got.shape[-1] > 1:
+        rec["max_rel_l2"] = float(rel_l2(got, ref).max())
+    PARITY_LOG[tag] = rec
+    print(f"parity {tag}: max abs {rec['max_abs']:.3e} ({rec['worst_ratio_of_bound']:.2f} of the bound atol {atol:g} + {rtol:g}|b|)"
+          + (f", max rel-L2 {rec['max_rel_l2']:.3e}" if "max_rel_l2" in rec else ""))
+    np.testing.assert_allclose(got, ref, atol=atol, rtol=rtol, err_msg=tag)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_parity_log():
+    yield
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(PARITY_LOG, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 def rel_l2(a, b):
@@ -174,7 +209,7 @@ def test_dc_tiny_golden(dev, golden_dir, prec, name):
         emb, = m([torch.from_numpy(z["x"]).to(dev)])
     emb = emb.cpu().numpy()
     assert emb.shape == z["out_embedding"].shape
-    np.testing.assert_allclose(emb, z["out_embedding"], atol=prec["atol"], rtol=1e-4)
+    check(f"{name}[{prec['name']}] embedding", emb, z["out_embedding"], prec["atol"])
     assert rel_l2(emb, z["out_embedding"]).max() < 1e-4
 
 
@@ -184,9 +219,9 @@ def test_chimera_tiny_golden(dev, golden_dir, prec):
     with torch.no_grad():
         e, a, b = m([torch.from_numpy(z["x"]).to(dev)])
     assert a.shape == z["out_mask_A"].shape and not a.is_contiguous()   # strided views like upstream
-    np.testing.assert_allclose(e.cpu().numpy(), z["out_embedding"], atol=prec["atol"], rtol=1e-4)
-    np.testing.assert_allclose(a.cpu().numpy(), z["out_mask_A"], atol=prec["atol"], rtol=1e-4)
-    np.testing.assert_allclose(b.cpu().numpy(), z["out_mask_B"], atol=prec["atol"], rtol=1e-4)
+    check(f"g1_chimera_H32_L2[{prec['name']}] embedding", e.cpu().numpy(), z["out_embedding"], prec["atol"])
+    check(f"g1_chimera_H32_L2[{prec['name']}] mask_A", a.cpu().numpy(), z["out_mask_A"], prec["atol"], vectors=False)
+    check(f"g1_chimera_H32_L2[{prec['name']}] mask_B", b.cpu().numpy(), z["out_mask_B"], prec["atol"], vectors=False)
 
 
 def test_phase_net_tiny_golden(dev, golden_dir, prec):
@@ -195,9 +230,9 @@ def test_phase_net_tiny_golden(dev, golden_dir, prec):
     with torch.no_grad():
         outs = m([torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["x_phase"]).to(dev)])
     for o, n in zip(outs, ["embedding", "mask_A", "mask_B", "phase_A", "phase_B"]):
-        tol = 1e-4 if n.startswith("phase") else 1e-5   # 2-vector normalisation amplifies round-off
-        tol *= prec["atol"] / 1e-5
-        np.testing.assert_allclose(o.cpu().numpy(), z["out_" + n], atol=tol, rtol=1e-4, err_msg=n)
+        # 2-vector normalisation amplifies round-off: (re, im) of a bin whose raw pair is short (measured: 2.5e-4 split-bf16, 1.7e-5 fp32)
+        tol = (1e-4 if prec["atol"] == 1e-5 else 4e-4) if n.startswith("phase") else prec["atol"]
+        check(f"g1_phase_net_H16_L2[{prec['name']}] {n}", o.cpu().numpy(), z["out_" + n], tol, vectors=n == "embedding")
 
 
 @pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg1_dc_L3", "deep_clustering"),
@@ -214,12 +249,12 @@ def test_full_size_golden_subsample(dev, golden_dir, prec, tag, kind):
     err, rl2 = np.abs(emb[:, ::40, ::16, :] - z["emb_sub"]).max(), rel_l2(emb[:, ::40, ::16, :], z["emb_sub"]).max()
     print(f"[{prec['name']}] {tag}: max abs err {err:.3e}, max per-vector rel-L2 {rl2:.3e}")
     # at BASELINE sizes and PyTorch-scale weights both modes meet the strict elementwise bound
-    np.testing.assert_allclose(emb[:, ::40, ::16, :], z["emb_sub"], atol=1e-5, rtol=1e-4)
+    check(f"g2_{tag}[{prec['name']}] embedding subsample", emb[:, ::40, ::16, :], z["emb_sub"], 1e-5)
     assert rl2 < 1e-4
     np.testing.assert_allclose(emb.astype(np.float64).sum(axis=(2, 3)), z["emb_sum_per_frame"], atol=5e-3)
     if kind == "chimera":
-        np.testing.assert_allclose(outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], atol=1e-5, rtol=1e-4)
-        np.testing.assert_allclose(outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], atol=1e-5, rtol=1e-4)
+        check(f"g2_{tag}[{prec['name']}] mask_A subsample", outs[1].cpu().numpy()[:, ::8, :], z["mask_A_sub"], 1e-5, vectors=False)
+        check(f"g2_{tag}[{prec['name']}] mask_B subsample", outs[2].cpu().numpy()[:, ::8, :], z["mask_B_sub"], 1e-5, vectors=False)
 
 
 @pytest.mark.parametrize("tag,kind", [("cfg1_dc_L2", "deep_clustering"), ("cfg3_chimera_L4", "chimera")])
@@ -306,7 +341,7 @@ def test_dc_matches_oracle_ragged_shapes(dev, prec, B, T, H, L):
     with torch.no_grad():
         emb, = m([torch.from_numpy(x).to(dev)])
     emb = emb.cpu().numpy()
-    np.testing.assert_allclose(emb, ref, atol=prec["atol"], rtol=1e-4)
+    check(f"dc oracle B{B} T{T} H{H} L{L} gain 1.5 [{prec['name']}]", emb, ref, prec["atol"])
     assert rel_l2(emb, ref).max() < 1e-4
     np.testing.assert_allclose(np.linalg.norm(emb, axis=-1), 1.0, atol=1e-5)   # unit embeddings
 
@@ -320,8 +355,8 @@ def test_unit_group_variants_agree(dev, monkeypatch, prec, ug):
     ref = TC.chimera_forward(sd, x)
     with torch.no_grad():
         outs = m([torch.from_numpy(x).to(dev)])
-    for o, r in zip(outs, ref):
-        np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), atol=prec["atol"], rtol=1e-4)
+    for k, (o, r) in enumerate(zip(outs, ref)):
+        check(f"chimera H120 ug{ug} gain 1.5 [{prec['name']}] output {k}", o.cpu().numpy(), r.numpy(), prec["atol"], vectors=k == 0)
 
 
 @pytest.mark.parametrize("xcd", ["1", "0"])

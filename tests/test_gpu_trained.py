@@ -135,3 +135,72 @@ def test_clip_adam_is_clip_grad_norm_plus_torch_adam():
     oc = torch.optim.Adam(ma.parameters(), lr=1e-3)
     oc.load_state_dict(sd)                                                 # same state layout as torch.optim.Adam
     assert float(oc.state[next(iter(ma.parameters()))]["step"]) == 5.0
+
+
+def test_weight_guard_catches_updates_that_bypass_the_version_counter():
+    """a model that STAYS in eval mode (BatchNorm frozen) is fine-tuned with a ``torch.optim.Adam(fused=True)``
+    built by hand -- not ``build_optimizer`` -- which moves the parameters without bumping ``tensor._version``: the cached weight images
+    of the inference path are then stale and nothing in their key says so.  The weight guard (a device-side sampled checksum compared on
+    every reuse, fetched asynchronously) must (a) report it at the next status poll as ``StalePackedWeights`` with the images already
+    dropped, so that the repeated forward runs on the live weights, and (b) let the entry points that own their call
+    (``separate_dc``) repeat it by themselves.  ``p.data`` arithmetic is caught the same way; a forward without any update raises nothing."""
+    import warnings
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    dev = torch.device("cuda:0")
+    from onssen_amd import nn as onn
+    from onssen_amd.nn import _core
+    from onssen_amd.separation import separate_dc
+    from onssen_amd.synthetic import make_state_dict, synth_mixture
+    from oracle import torch_cpu as TC
+    sd = make_state_dict("deep_clustering", 129, 64, 2, 20, 2, seed=11, gain=1.0)
+    m = onn.deep_clustering(129, 64, 2, 20, dropout=0.0)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.uniform(-6, 1.5, (4, 30, 129)).astype(np.float32)).to(dev)
+    live = lambda: TC.deep_clustering_forward({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, x.cpu().numpy()).numpy()
+
+    def fwd():
+        with torch.no_grad():
+            return m([x])[0].cpu().numpy()
+    y0 = fwd()
+    _core._XcdStatus.flush()
+    np.testing.assert_allclose(y0, live(), atol=3e-5, rtol=1e-4)
+    fwd(); fwd()
+    _core._XcdStatus.flush()                                    # reuse without an update: the guard stays quiet
+    seen0 = _core._WeightGuard.stale_seen
+
+    opt = torch.optim.Adam(m.parameters(), lr=3e-2, fused=True)          # by hand: no invalidate hook
+    v0 = m.rnn.weight_hh_l0._version
+    for _ in range(3):
+        opt.zero_grad()
+        m([x])[0].square().mul(torch.linspace(0, 1, 20, device=dev)).sum().backward()      # eval mode + autograd: the training path
+        opt.step()
+    bumped = m.rnn.weight_hh_l0._version != v0
+    y_stale = fwd()                                              # (runs on the old images unless this torch bumps versions after all)
+    if not bumped:
+        with pytest.raises(_core.StalePackedWeights):
+            _core._XcdStatus.flush()
+        assert _core._WeightGuard.stale_seen >= seen0 + 1          # (the stack's guard and the head's guard may both fire)
+        assert np.abs(y_stale - live()).max() > 1e-3             # it really was a forward on stale weights
+    y1 = fwd()
+    _core._XcdStatus.flush()
+    np.testing.assert_allclose(y1, live(), atol=3e-5, rtol=1e-4)
+
+    # p.data arithmetic on a head parameter, then an entry point that owns its call: it repeats the call by itself
+    wav = torch.from_numpy(np.stack([synth_mixture(300 + b, 64 * 29) for b in range(2)])).to(dev)
+    ref0 = separate_dc(m, wav).cpu().numpy()
+    with torch.no_grad():
+        m.fc_dc.weight.data.mul_(-1.0)                            # flips every embedding: the 2-means partition (and the outputs) survive,
+        m.fc_dc.bias.data.mul_(-1.0)                              # so compare the embedding path too
+        m.rnn.weight_ih_l1.data.mul_(0.5)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sig = separate_dc(m, wav).cpu().numpy()
+    assert any("freshly packed weights" in str(i.message) for i in w)
+    m.repack()
+    np.testing.assert_array_equal(sig, separate_dc(m, wav).cpu().numpy())          # = what the live weights give
+    assert ref0.shape == sig.shape       # (binary masks: the separated signals themselves may coincide with the old ones)
+    y2 = fwd()
+    _core._XcdStatus.flush()
+    np.testing.assert_allclose(y2, live(), atol=3e-5, rtol=1e-4)

@@ -82,7 +82,9 @@ def test_training_batches_from_files_match_the_oracle(tmp_path, model_name):
     assert len(batches) == 2 and batches[0][0][0].shape == (2, L, 129) and batches[1][0][0].shape == (1, L, 129)
     nlab = {"dc": 2, "chimera++": 6, "phase": 6}[model_name]
     assert all(len(lab) == nlab for _, lab in batches) and batches[0][1][0].dtype == torch.float64
-    rng = np.random.default_rng(11)
+    # the prefetching producer draws the epoch's crops from a child generator spawned on the calling thread (the parent is never
+    # touched off-thread): epoch 0 of seed 11 = the first child
+    rng = np.random.default_rng(11).spawn(1)[0]
     k = 0
     for inp, lab in batches:
         for b in range(inp[0].shape[0]):
@@ -203,3 +205,41 @@ def test_host_side_of_the_training_batches(tmp_path):
             T = 1 + n // 64
             Tr = T * (40 // T + 1) if T <= 40 else T
             assert starts[b] == int(rng.integers(0, Tr - 40))
+
+
+def test_an_abandoned_epoch_does_not_strand_the_producer_or_perturb_the_next_epoch(tmp_path, monkeypatch):
+    """the producer thread's sentinel / exception puts honour ``stop`` (a consumer that leaves the epoch early with a full
+    queue must not leave a thread blocked in ``put``), the thread is joined, and because it draws from a child generator the next
+    epoch's crop sequence does not depend on how far the abandoned one got.  Host side only (no GPU: ``_prefetched`` items)."""
+    import threading
+    monkeypatch.setenv("ONSSEN_LOADER_PREFETCH", "1")
+    monkeypatch.setenv("ONSSEN_LOADER_WORKERS", "2")
+    lengths = [64 * 50 + k for k in range(6)]
+    make_corpus(str(tmp_path), "tr", lengths)
+    fo = dict(FO, data_path=str(tmp_path), batch_size=1)
+
+    def second_epoch_starts(abandon_after):
+        dl = Wsj02mixFiles("dc", fo, "tr", device="cpu", shuffle=False, seed=5)
+        order = np.arange(len(dl.file_list))
+        it = dl._prefetched(order)
+        for _ in range(abandon_after):
+            next(it)
+        it.close()                                   # the consumer walks away: queue full, producer mid-epoch
+        assert not any(t.name == "onssen-wsj0-2mix-loader" and t.is_alive() for t in threading.enumerate())
+        return [int(starts[0]) for _, _, starts in dl._prefetched(order)]
+    a, b = second_epoch_starts(1), second_epoch_starts(4)
+    assert a == b and len(a) == 6
+
+
+def test_header_frame_counts_are_clamped_to_the_file(tmp_path):
+    """a header that states more data than the file holds (streamed WAVs say 0xFFFFFFFF) must not size a multi-GB row."""
+    import struct
+    make_corpus(str(tmp_path), "tr", [64 * 30])
+    fn = os.path.join(str(tmp_path), "wav8k", "min", "tr", "mix", "utt00.wav")
+    raw = bytearray(open(fn, "rb").read())
+    i = raw.find(b"data")
+    raw[i + 4:i + 8] = struct.pack("<I", 0xFFFFFFFF)
+    open(fn, "wb").write(raw)
+    dl = Wsj02mixFiles("dc", dict(FO, data_path=str(tmp_path)), "tr", device="cpu", shuffle=False, seed=1)
+    fr, rate = dl._frames_of(fn)
+    assert rate == 8000 and 0 < fr <= os.path.getsize(fn) // 2
