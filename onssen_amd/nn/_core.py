@@ -428,8 +428,9 @@ class BLSTMParams(nn.Module):
         persistent forward with saved state (H <= 768) + the persistent backward recurrence (H <= 640) where they apply (no abort
         back-off in force), otherwise the launch-per-step forward with saved state (split-bf16 up to H = 640, exact fp32
         above) + the launch-per-step backward: the re-run of a training step whose persistent launch aborted and wide layers
-        stay inside the library (round 4; rounds 1-3 fell back to the stock ATen / MIOpen LSTM there).  A CPU tensor takes
-        ATen's LSTM (gloo tests, CPU-only debugging): there is no HIP device to run on."""
+        stay inside the library (round 4; rounds 1-3 fell back to the stock ATen / MIOpen LSTM there).  A CPU tensor RAISES (round 6)
+        unless the test scaffolding switch ``cpu_autograd`` / ONSSEN_CPU_AUTOGRAD=1 is set (tests/conftest.py sets it for the gloo
+        tests of the multi-process logic, which have no GPU to run on)."""
         if x.is_cuda:
             from ._train import BLSTMTrainFunction
             persistent = (self.hidden_size <= 768 and options.get("recurrence") == "1" and _XcdPolicy.persistent_allowed())
@@ -439,6 +440,9 @@ class BLSTMParams(nn.Module):
                 object.__setattr__(self, "_train_packed", PackedBLSTM(self))
             p_drop = float(self.dropout) if training and self.num_layers > 1 else 0.0
             return BLSTMTrainFunction.apply(x, self._train_packed, p_drop, persistent, *self.flat_weights())
+        if options.get("cpu_autograd") != "1":
+            raise RuntimeError("onssen_amd: the BLSTM stack needs tensors on a ROCm device; there is no CPU fallback (ONSSEN_CPU_AUTOGRAD=1 "
+                               "is test scaffolding for the multi-process logic over gloo, never a product path)")
         B = x.shape[0]
         z = x.new_zeros(2 * self.num_layers, B, self.hidden_size)
         out, _, _ = torch._VF.lstm(x, (z, z), self.flat_weights(), True, self.num_layers,

@@ -84,6 +84,8 @@ TABLE = {
     "train_fused_norm": ("ONSSEN_TRAIN_FUSED_NORM", "1", _flag, "fc_dc + normalise as one autograd node"),
     "loss": ("ONSSEN_LOSS_HIP", "1", _alias({"hip": "1", "torch": "0"}), "loss kernels on the device or PyTorch ops"),
     "fused_adam": ("ONSSEN_FUSED_ADAM", "1", _flag, "build_optimizer returns utils.ClipAdam (clipping + Adam on onssen_clip_adam_f32) for device parameters"),
+    "cpu_autograd": ("ONSSEN_CPU_AUTOGRAD", "0", _flag, "TEST SCAFFOLDING, off in the product: let a training forward on CPU tensors run on ATen's LSTM so that "
+                     "the multi-process logic (gradient buckets, replica agreement) can be exercised over gloo without a GPU; otherwise a CPU tensor raises"),
     "synthetic_data": ("ONSSEN_SYNTHETIC_DATA", "0", _flag, "wsj0_2mix_dataloader falls back to the synthetic corpus when data_path is empty"),
     "loader_workers": ("ONSSEN_LOADER_WORKERS", "4", _int, "file-reading threads of the wsj0-2mix file loader (0 = read on the calling thread)"),
     "loader_prefetch": ("ONSSEN_LOADER_PREFETCH", "3", _int, "batches the file loader keeps in flight ahead of the training step"),

@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# the gloo / CPU tests of the multi-process and training LOGIC step small models on CPU tensors: test scaffolding the product refuses
+# by default (tests/test_config_surface.py::test_cpu_tensors_raise_without_the_scaffolding_switch checks the refusal)
+os.environ.setdefault("ONSSEN_CPU_AUTOGRAD", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

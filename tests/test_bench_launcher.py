@@ -74,9 +74,9 @@ def test_recorded_eight_rank_self_test_line():
 
 
 def test_recorded_bench_line_carries_the_contract():
-    """profiles/r05_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
-    key the bench contract names, the roofline and CPU-baseline blocks, and the round-5 additions."""
-    r = json.loads(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")).read().strip().splitlines()[-1])
+    """profiles/r06_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
+    key the bench contract names, the roofline and CPU-baseline blocks (round 6: BASELINE.md section 3's protocol), and the round-5 additions."""
+    r = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_final.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in r, k
     assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 5 and r["higher_is_better"] is True and r["scaling"] == "weak"
@@ -91,6 +91,17 @@ def test_recorded_bench_line_carries_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["value"] > 0
+    # physical cores stated, the threads actually used, median of 10 at B = 1 and B = 32,
+    # the network at the best thread count of a scan up to all physical cores, both KMeans n_init settings
+    assert cpu["cores_physical"] >= cpu["threads_used"] == cpu["cores"] >= 1 and cpu["host_threads"] >= cpu["cores_physical"]
+    assert cpu["kmeans_n_init"] == 10 and "n_init=10" in cpu["sample"]
+    assert set(cpu["whole_path"]) == {"B1", "B1_kmeans_auto", "B32", "B32_kmeans_auto"}
+    assert all(v["passes"] >= 3 and v["ms"] > 0 for v in cpu["whole_path"].values()) and cpu["whole_path"]["B32"]["passes"] == 10
+    assert abs(cpu["value"] - cpu["whole_path"]["B32"]["x_real_time"]) < 1e-9
+    assert cpu["whole_path"]["B32_kmeans_auto"]["ms"] < cpu["whole_path"]["B32"]["ms"]
+    net = cpu["network_only"]
+    assert net["B1"]["passes"] == 10 and net["B32"]["passes"] == 10
+    assert str(cpu["cores_physical"]) in net["B32"]["threads_tried"] and str(net["B32"]["threads"]) in net["B32"]["threads_tried"]
     assert r["lloyd_iterations"]["cap"] == 20 and "second_input_set" in r
     ex = r["extra_configs"]
     assert ex["trained_weights_dc_l2_b32"]["si_sdr_db"]["separated_mean"] > 8.0           # the headline step on a trained network separates

@@ -162,3 +162,21 @@ def test_packed_images_are_dropped_when_weights_may_have_moved():
     assert _core._WEIGHT_EPOCH[0] == e0 + 2
     model.train()
     assert _core._WEIGHT_EPOCH[0] == e0 + 3
+
+
+def test_cpu_tensors_raise_without_the_scaffolding_switch(monkeypatch):
+    """No CPU fallback: an inference forward on a CPU tensor raises (always did), and so does a TRAINING forward unless the test
+    scaffolding switch ONSSEN_CPU_AUTOGRAD=1 is set (tests/conftest.py sets it for the gloo tests)."""
+    import pytest
+    import torch
+    from onssen_amd import nn as onn
+    m = onn.deep_clustering(129, 8, 1, 20, dropout=0.0)
+    x = torch.randn(2, 5, 129)
+    monkeypatch.setenv("ONSSEN_CPU_AUTOGRAD", "0")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.train()([x])
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m.eval()([x])
+    monkeypatch.setenv("ONSSEN_CPU_AUTOGRAD", "1")
+    assert m.train()([x])[0].shape == (2, 5, 129, 20)

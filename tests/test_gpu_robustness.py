@@ -104,23 +104,38 @@ def test_nonfinite_activations_are_reported(dev, monkeypatch):
 
 
 def test_data_mutation_needs_repack_and_gets_it(dev, monkeypatch):
-    """`p.data.add_()` changes neither `_version` nor the pointer, so the packed images cannot notice; after
+    """`p.data.add_()` changes neither `_version` nor the pointer, so the packed images' KEY cannot notice; after
     `model.repack()` (or with ONSSEN_CHECK_WEIGHTS=1) the forward follows the live parameters.  load_state_dict and
-    .to() invalidate by themselves."""
-    m = _dc(dev)
-    x = torch.randn(2, 12, 129, device=dev)
-    with torch.no_grad():
-        a = m([x])[0].clone()
-        m.fc_dc.bias.data.add_(0.25)
-        m.rnn.weight_hh_l0.data.mul_(0.5)
-        stale = m([x])[0].clone()
-        m.repack()
-        b = m([x])[0].clone()
-        ref = _dc(dev)
-        ref.load_state_dict(m.state_dict())            # a fresh module with the same live parameters
-        c = ref([x])[0]
-    assert torch.equal(stale, a) and not torch.equal(b, a)
-    np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), atol=1e-6)
+    .to() invalidate by themselves.  Round 6: with the weight guard (default) the one stale forward is REPORTED -- the next status
+    poll raises StalePackedWeights with the images already dropped -- instead of staying silent until somebody calls repack()."""
+    from onssen_amd.nn import _core
+
+    def run(guard):
+        monkeypatch.setenv("ONSSEN_WEIGHT_GUARD", guard)
+        m = _dc(dev)
+        x = torch.randn(2, 12, 129, device=dev)
+        with torch.no_grad():
+            a = m([x])[0].clone()
+            _core._XcdStatus.flush()
+            m.fc_dc.bias.data.add_(0.25)
+            m.rnn.weight_hh_l0.data.mul_(0.5)
+            stale = m([x])[0].clone()
+            if guard == "1":
+                with pytest.raises(_core.StalePackedWeights):
+                    _core._XcdStatus.flush()            # reported; the images are dropped: no repack() needed
+            else:
+                _core._XcdStatus.flush()                # silent, as in rounds 1-5 ...
+                m.repack()                              # ... until somebody says so
+            b = m([x])[0].clone()
+            _core._XcdStatus.flush()
+            ref = _dc(dev)
+            ref.load_state_dict(m.state_dict())            # a fresh module with the same live parameters
+            c = ref([x])[0]
+        assert torch.equal(stale, a) and not torch.equal(b, a)
+        np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), atol=1e-6)
+        return m, x, b
+    run("1")
+    m, x, b = run("0")
     monkeypatch.setenv("ONSSEN_CHECK_WEIGHTS", "1")
     with torch.no_grad():
         m.fc_dc.bias.data.add_(0.25)
