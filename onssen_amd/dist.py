@@ -275,9 +275,9 @@ def train_step(model, optimizer, loss_fn, input, label, world=1, group=None, cli
 
     An aborted persistent recurrence launch (forward or backward; ``nn/_core._XcdPolicy``) never reaches the weights: the
     status words are examined BEFORE the optimizer step; with ``world > 1`` the ranks agree on the outcome through a
-    one-element MAX all-reduce of a status code (0 = fine, 1 = somebody's persistent launch aborted -- or, with
-    ``nonfinite="propagate"`` / ONSSEN_NONFINITE=propagate, saw non-finite activations --, 2 = somebody hit a fatal error:
-    non-finite activations in the default ``nonfinite="raise"`` mode, a second abort) -- an aborted rank's garbage is
+    one-element MAX all-reduce of a status code (0 = fine, 1 = somebody's persistent launch aborted -- or saw non-finite
+    activations (the default ``nonfinite="propagate"``: the re-run propagates them like nn.LSTM, as the reference would) --,
+    2 = somebody hit a fatal error: non-finite activations in the strict ``nonfinite="raise"`` mode, a second abort) -- an aborted rank's garbage is
     already inside everybody's averaged gradients --, and then EVERY rank either runs forward / backward / exchange again
     (the rank that aborted on the launch-per-step HIP recurrences, which also propagate NaNs like nn.LSTM: the training
     path never leaves the library, round 4) or raises.  That agreement covers what the status words report.  An

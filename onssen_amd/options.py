@@ -66,7 +66,10 @@ TABLE = {
     "split_rows": ("ONSSEN_SPLIT_ROWS", "0", _flag, "launch-per-step recurrence: split the batch rows over two workgroups"),
     "ablate": ("ONSSEN_ABLATE", "0", _int, "profiling-only ablation bits of the recurrence kernels"),
     "serialize_persistent": ("ONSSEN_XCD_SERIALIZE", "0", _flag, "one persistent launch in flight per device across streams"),
-    "nonfinite": ("ONSSEN_NONFINITE", "raise", _choice("raise", "propagate"), "non-finite activations seen by a persistent launch"),
+    "nonfinite": ("ONSSEN_NONFINITE", "propagate", _choice("raise", "propagate"),
+                  "non-finite activations seen by a persistent launch (they cannot pass its tagged exchange): propagate (default since round 6) = the "
+                  "call is re-run on the launch-per-step recurrence, which gives nn.LSTM's NaN in / NaN out -- the reference's behaviour --; "
+                  "raise = stop with an error instead"),
     "check": ("ONSSEN_CHECK", "0", _flag, "synchronise and examine the persistent launches' status words after every forward"),
     "check_weights": ("ONSSEN_CHECK_WEIGHTS", "0", _flag, "verify the packed weight images against the parameters before every forward (one synchronisation each: debugging)"),
     "weight_guard": ("ONSSEN_WEIGHT_GUARD", "1", _flag, "every inference forward that reuses cached weight images compares a device-side sampled checksum of the "

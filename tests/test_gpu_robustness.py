@@ -91,16 +91,20 @@ def test_nonfinite_activations_are_reported(dev, monkeypatch):
     with torch.no_grad():
         out = m([x])[0]
     assert torch.isnan(out[1]).any() and torch.isfinite(out[0]).all()
-    # opt-in reference semantics on the persistent path: the entry points that re-run aborted calls
-    # re-run a call that met a NaN on the launch-per-step recurrence -> NaN in, NaN out, like nn.LSTM
+    # reference semantics on the persistent path (the DEFAULT since round 6): the entry points
+    # that re-run aborted calls re-run a call that met a NaN on the launch-per-step recurrence -> NaN in, NaN out, like nn.LSTM
     from onssen_amd.separation import separate_dc
     monkeypatch.setenv("ONSSEN_XCD", "1")
     monkeypatch.delenv("ONSSEN_CHECK")
-    monkeypatch.setenv("ONSSEN_NONFINITE", "propagate")
+    monkeypatch.delenv("ONSSEN_NONFINITE", raising=False)
     wav = torch.from_numpy(np.stack([synth_mixture(3 + b, 4000) for b in range(2)])).to(dev)
     wav[1, 1000] = float("nan")
     sig = separate_dc(m, wav)
     assert torch.isnan(sig[1]).any() and torch.isfinite(sig[0]).all() and _core._XcdPolicy.persistent_allowed()
+    # the strict mode stops instead
+    monkeypatch.setenv("ONSSEN_NONFINITE", "raise")
+    with pytest.raises(_abi.OnssenError, match="non-finite"):
+        separate_dc(m, wav)
 
 
 def test_data_mutation_needs_repack_and_gets_it(dev, monkeypatch):
