@@ -1274,6 +1274,7 @@ static int lstm_train_backward_impl(int B, int T, int H, int ug, const uint16_t*
     static const int ablate_env = ONSSEN_KNOB_INT("ONSSEN_BWD_ABLATE", 0);
     static const int delay_env = ONSSEN_KNOB_INT("ONSSEN_BWD_DELAY", 0);
     static const bool bwd_unstacked = ONSSEN_KNOB_INT("ONSSEN_BWD_UNSTACKED", 0) != 0;      // debug builds: the three-term form of rounds 2-4, for A/B
+    static const bool bwd_wide = ONSSEN_KNOB_INT("ONSSEN_BWD_WIDE", ONSSEN_BWD_WIDE) != 0;      // the wide poll of round 6 (lstm_bwd.inc: RGW)
     XcdBwdArgs xa;
     xa.gd = gates_dp; xa.cs = cs; xa.dy = dy; xa.wR = whh_img; xa.sync = (unsigned*)ws;
     xa.xch = (float*)((char*)ws + ONSSEN_BLSTM_WS_HEADER_BYTES);
@@ -1292,7 +1293,11 @@ static int lstm_train_backward_impl(int B, int T, int H, int ug, const uint16_t*
       xa.nbg = ceil_div(rows, xa.RG);
 #define ONSSEN_BWD_UG(UG_)                                                                                   \
   do {                                                                                                       \
-    if (xa.RG <= 8 && !bwd_unstacked) {                                                                      \
+    if (bwd_wide && !bwd_unstacked) {   /* round 6: the wide poll (16-byte loads, 16 lanes per unit) */       \
+      if (xa.RG == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, true, 4>), grid, dim3(512), 0, st, xa);  \
+      else if (xa.RG == 8) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, true, 8>), grid, dim3(512), 0, st, xa); \
+      else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, false, 16>), grid, dim3(512), 0, st, xa);          \
+    } else if (xa.RG <= 8 && !bwd_unstacked) {                                                               \
       if (parts == 4) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 4, true>), grid, dim3(512), 0, st, xa);     \
       else if (parts == 2) hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 2, true>), grid, dim3(512), 0, st, xa);\
       else hipLaunchKernelGGL((lstm_xcd_bwd_kernel<UG_, 1, true>), grid, dim3(512), 0, st, xa);                \

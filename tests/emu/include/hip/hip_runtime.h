@@ -332,13 +332,15 @@ static inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, __amdgpu_b
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
   // quad_perm (ctrl 0..255: two selector bits per lane of a quad) and row_shl:n (0x101..0x10f: lane l receives lane l+n of
   // its row of 16; beyond the row: 0 with bound_ctrl, else `old`), full row / bank masks.  Every lane of the wave must call it.
-  if (ctrl < 0 || (ctrl > 255 && (ctrl < 0x101 || ctrl > 0x10f))) { fprintf(stderr, "emu: DPP control not emulated\n"); abort(); }
+  if (ctrl < 0 || (ctrl > 255 && (ctrl < 0x101 || ctrl > 0x10f) && (ctrl < 0x121 || ctrl > 0x12f))) { fprintf(stderr, "emu: DPP control not emulated\n"); abort(); }
   auto& w = emu::ctx->wbuf[emu::wave];
   memcpy(&w.a[emu::lane], &src, 4);
   emu::wave_sync();
   int r = old;
   if (ctrl <= 255) {
     memcpy(&r, &w.a[(emu::lane & ~3) + ((ctrl >> (2 * (emu::lane & 3))) & 3)], 4);
+  } else if (ctrl >= 0x121) {       // row_ror:n -- lane l receives lane (l - n) mod 16 of its row
+    memcpy(&r, &w.a[(emu::lane & ~15) + (((emu::lane & 15) - (ctrl - 0x120)) & 15)], 4);
   } else {
     const int srcl = (emu::lane & 15) + (ctrl - 0x100);
     if (srcl < 16) memcpy(&r, &w.a[(emu::lane & ~15) + srcl], 4);
