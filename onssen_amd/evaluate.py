@@ -92,7 +92,7 @@ class tester:
         examined once per window.  An aborted launch re-runs that window on the launch-per-step recurrence (inference
         is functional: same inputs, same outputs)."""
         import warnings
-        from .nn._core import XcdAborted, XcdNonFinite, _XcdPolicy, _XcdStatus
+        from .nn._core import StalePackedWeights, XcdAborted, XcdNonFinite, _XcdPolicy, _XcdStatus
         total, count = 0.0, 0
         self.model = self.model.eval()
 
@@ -107,14 +107,17 @@ class tester:
             return batch_SDR_torch(sig_est, sig_ref, lengths=lengths)
 
         def rerun(pend, e):
+            import contextlib
             _XcdPolicy.recovered += 1
+            stale = isinstance(e, StalePackedWeights)        # the weight guard: the images are already dropped, the same kernels again
             if not isinstance(e, XcdNonFinite):
-                warnings.warn(f"onssen_amd: {e}  Re-running {len(pend)} forward(s) on the launch-per-step recurrence.", RuntimeWarning)
+                warnings.warn(f"onssen_amd: {e}  Re-running {len(pend)} forward(s) "
+                              + ("on freshly packed weights." if stale else "on the launch-per-step recurrence."), RuntimeWarning)
             try:
                 _XcdStatus.flush(policy=False)   # the window's other launches ran into the same abort word: drain their reports
             except XcdAborted:
                 pass
-            with _XcdPolicy.forced_steps():
+            with (contextlib.nullcontext() if stale else _XcdPolicy.forced_steps()):
                 sdrs = [one(input, label, ragged) for input, label, ragged, _ in pend]
                 _XcdStatus.flush()
             return sdrs
