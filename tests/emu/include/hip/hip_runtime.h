@@ -366,6 +366,16 @@ static inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned 
 }
 // the lanes of an emulated wave are threads with their own copy of every wave-uniform value
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+// v_readlane_b32: every lane of the wave receives lane `l`'s value (all lanes must call it: lanes are threads here)
+static inline int __builtin_amdgcn_readlane(int v, int l) {
+  auto& w = emu::ctx->wbuf[emu::wave];
+  memcpy(&w.a[emu::lane], &v, 4);
+  emu::wave_sync();
+  int r;
+  memcpy(&r, &w.a[l & 63], 4);
+  emu::wave_sync();
+  return r;
+}
 // buffer_load_dwordx4 ... lds: every lane copies `size` bytes (zeros when out of range) to lds + lane * size
 static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, void* lds, int size, int voff, int soff, int off, int) {
   char* dst = static_cast<char*>(lds) + emu::lane * size;
