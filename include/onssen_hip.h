@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 12   /* 12: onssen_log_magnitude_f32, onssen_cos_difference_f32, onssen_one_hot_f32 (the reference's stand-alone feature helpers).  11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 13   /* 13: onssen_blstm_pipe2_* (a two-layer stack software-pipelined over consecutive calls: layer 1 of batch n-1 and layer 0 of batch n in ONE persistent launch, each on half of the XCDs).  12: onssen_log_magnitude_f32, onssen_cos_difference_f32, onssen_one_hot_f32 (the reference's stand-alone feature helpers).  11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -322,6 +322,29 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
                              int ug, const float* const* wih_p_host, const float* const* whh_p_host,
                              const float* const* bias_p_host, float* y, void* ws, size_t ws_bytes, int flags,
                              void* stream);
+
+/* ---- Two-layer stack, SOFTWARE-PIPELINED over consecutive calls (round 6) -----------------------------------------------
+ * The same `self.rnn(x)` (onssen/nn/deep_clustering.py:35) for num_layers = 2 and B <= 32, arranged for THROUGHPUT over a stream
+ * of batches (the evaluation loop of onssen/utils/test.py:29-41 hands over one batch after the other): a B <= 32 layer fills the
+ * chip's 8 XCDs only with 8-row groups, whose time step costs what a 16-row group's does bar the MFMAs (1.42 vs 1.88 us at
+ * H = 600) -- so call n runs layer 1 of batch n-1 and layer 0 of batch n in ONE persistent launch, 16-row groups (stacked 8-row
+ * groups up to B = 16), each layer on its own half of the XCDs:
+ *     x3 image + input projection of x (batch n)  ->  [ layer 1 (batch n-1)  ||  layer 0 (batch n) ]  ->  layer 1's input
+ *     projection of batch n (kept in ws for call n+1).
+ * After call n the x3 image [T*B][KB][2][32] of layer 1's output FOR BATCH n-1 is at onssen_blstm_pipe2_y_image (feed it to
+ * onssen_linear_x3p*); call 0's image is the stack's answer to an all-zero layer-1 input projection (finite, meaningless), and one
+ * extra call (any x) drains the last batch.  Per batch the results are bit for bit those of onssen_blstm_forward_f32 on 16-row
+ * groups without ONSSEN_BLSTM_FUSE_IN0 (e.g. the same rows inside a B = 64 call); against the default B = 32 call (stacked 8-row
+ * groups, which add the lo x lo products) they differ in the last bits, inside the same tolerance.
+ *   flags: ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD exactly (the plain split-bf16 persistent recurrence), H <= 640.
+ *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of 2 device pointers as for onssen_blstm_forward_f32 in that form (x3 image
+ *   of the packed projection, the two directions' onssen_lstm_pack_whh_bf16x3 images, packed bias).
+ *   ws: onssen_blstm_pipe2_workspace_bytes() bytes, 256-byte aligned, ZEROED ONCE by its owner; header words as above. */
+size_t onssen_blstm_pipe2_workspace_bytes(int B, int T, int in_dim, int H, int ug);
+int onssen_blstm_pipe2_y_image(int B, int T, int in_dim, int H, int ug, size_t* offset_bytes, int* KB);
+int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
+                                   const float* const* wih_p_host, const float* const* whh_p_host,
+                                   const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ---- Training: nn.LSTM forward with saved state and its backward recurrence ------------------
  * What `loss.backward()` does for `self.rnn` (onssen/utils/train.py:80-84; nn.LSTM autograd), one layer at a time so that

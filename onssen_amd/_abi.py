@@ -10,7 +10,7 @@ import os
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 12
+ABI_VERSION = 13
 WAV_TRUNCATED = 1
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
@@ -53,6 +53,9 @@ SIGNATURES = {
     "onssen_blstm_y_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_x_image": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _vp, _sz, _i, _vp]),
+    "onssen_blstm_pipe2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "onssen_blstm_pipe2_y_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
+    "onssen_blstm_pipe2_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _sz, _i, _vp]),
     "onssen_linear_x3p_batched": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
                                              _i, _vp]),
@@ -300,6 +303,21 @@ class Lib:
                                                      arr(*whh_ptrs), arr(*bias_ptrs), y, ws, ws_bytes, flags, stream),
                    "onssen_blstm_forward_f32")
 
+    # ---- two-layer stack software-pipelined over consecutive calls (round 6)
+    def blstm_pipe2_workspace_bytes(self, B, T, in_dim, H, ug):
+        return int(self.dll.onssen_blstm_pipe2_workspace_bytes(B, T, in_dim, H, ug))
+
+    def blstm_pipe2_y_image(self, B, T, in_dim, H, ug):
+        """(byte offset inside the workspace, KB) of layer 1's x3 output image of the batch handed over one call earlier."""
+        off, kb = C.c_size_t(0), C.c_int(0)
+        self.check(self.dll.onssen_blstm_pipe2_y_image(B, T, in_dim, H, ug, C.byref(off), C.byref(kb)), "onssen_blstm_pipe2_y_image")
+        return int(off.value), int(kb.value)
+
+    def blstm_pipe2_forward(self, x, xs_b, xs_t, B, T, in_dim, H, ug, wih_ptrs, whh_ptrs, bias_ptrs, ws, ws_bytes, flags, stream):
+        arr = C.c_void_p * 2
+        self.check(self.dll.onssen_blstm_pipe2_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, arr(*wih_ptrs), arr(*whh_ptrs),
+                                                           arr(*bias_ptrs), ws, ws_bytes, flags, stream),
+                   "onssen_blstm_pipe2_forward_f32")
 
     # ---- training (row N1)
     def linear_x3p_batched(self, a_img, a_bs, M, K, w_img, w_bs, bias, N, out, c_bs, ldc, batch, stream):

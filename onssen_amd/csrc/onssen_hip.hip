@@ -1111,6 +1111,95 @@ int onssen_blstm_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, 
                             flags, stream, nullptr, nullptr, frames);
 }
 
+// ---- two-layer stack, software-pipelined over consecutive calls (round 6) -------------------------------------------
+// workspace: header | G0 | G1 | h hand-off images of 8 groups | x3 images: input, layer-0 output, layer-1 output | 64 KiB debug
+struct Pipe2Ws {
+  size_t g, hs, img_x, img_y, off_g0, off_g1, off_hs, off_imgx, off_img0, off_img1, total;
+};
+static bool pipe2_ws_layout(int B, int T, int in_dim, int H, int ug, Pipe2Ws* w) {
+  int Hp, NP, KQ2 = 0, Hs = 0;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK || B <= 0 || B > 32 || T <= 0 || in_dim <= 0) return false;
+  if (onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr) != ONSSEN_OK) return false;
+  w->g = align256((size_t)T * B * 2 * NP * sizeof(float));
+  w->hs = align256((size_t)8 * 2 * KQ2 * 2048);                 // 8 groups x 2 slots x KQ2 chunks of 2 KiB
+  w->img_x = align256((size_t)T * B * ceil_div(in_dim, 32) * 128);
+  w->img_y = align256((size_t)T * B * ceil_div(2 * Hp, 32) * 128);
+  w->off_g0 = ONSSEN_BLSTM_WS_HEADER_BYTES;
+  w->off_g1 = w->off_g0 + w->g;
+  w->off_hs = w->off_g1 + w->g;
+  w->off_imgx = w->off_hs + w->hs;
+  w->off_img0 = w->off_imgx + w->img_x;
+  w->off_img1 = w->off_img0 + w->img_y;
+  w->total = w->off_img1 + w->img_y + 65536;
+  return true;
+}
+
+size_t onssen_blstm_pipe2_workspace_bytes(int B, int T, int in_dim, int H, int ug) {
+  Pipe2Ws w;
+  return pipe2_ws_layout(B, T, in_dim, H, ug, &w) ? w.total : 0;
+}
+
+int onssen_blstm_pipe2_y_image(int B, int T, int in_dim, int H, int ug, size_t* offset_bytes, int* KB) {
+  Pipe2Ws w;
+  int Hp;
+  if (!pipe2_ws_layout(B, T, in_dim, H, ug, &w) || onssen_lstm_geometry(H, ug, &Hp, nullptr, nullptr, nullptr) != ONSSEN_OK)
+    return ONSSEN_E_ARG;
+  if (offset_bytes) *offset_bytes = w.off_img1;
+  if (KB) *KB = ceil_div(2 * Hp, 32);
+  return ONSSEN_OK;
+}
+
+int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
+                                   const float* const* wih_p_host, const float* const* whh_p_host,
+                                   const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream) {
+  int Hp, NP, KQ2 = 0, Hs = 0;
+  if (onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK) return ONSSEN_E_ARG;
+  if (!x || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || B > 32 || T <= 0 || in_dim <= 0) return ONSSEN_E_ARG;
+  // the plain split-bf16 persistent recurrence only (no fused first layer, no bf16-only products)
+  if ((flags & 0xff) != (ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD)) return ONSSEN_E_ARG;
+  Pipe2Ws wl;
+  if (!pipe2_ws_layout(B, T, in_dim, H, ug, &wl)) return ONSSEN_E_ARG;
+  if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return ONSSEN_E_ALIGN;
+  onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
+  if (ug > 20 || Hp / ug > 32 || KQ2 > 24) return ONSSEN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)ws;
+  float* G0 = (float*)(base + wl.off_g0);
+  float* G1 = (float*)(base + wl.off_g1);
+  uint16_t* img_x = (uint16_t*)(base + wl.off_imgx);
+  uint16_t* img0 = (uint16_t*)(base + wl.off_img0);
+  uint16_t* img1 = (uint16_t*)(base + wl.off_img1);
+  // layer 0 of THIS batch: input image, input projection
+  int rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
+  if (rc != ONSSEN_OK) return rc;
+  rc = onssen_linear_x3p(img_x, T * B, in_dim, (const uint16_t*)wih_p_host[0], bias_p_host[0], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G0, B,
+                         (int64_t)B * 2 * NP, 2 * NP, stream);
+  if (rc != ONSSEN_OK) return rc;
+  // ONE launch: layer 1 of the batch before (its G1 was left by the call before) beside layer 0 of this one
+  XcdArgs xa;
+  xa.G = G1; xa.whh = (const unsigned short*)whh_p_host[1]; xa.y = nullptr; xa.yimg = img1;
+  xa.G_b = G0; xa.whh_b = (const unsigned short*)whh_p_host[0]; xa.yimg_b = img0;
+  xa.hx = (unsigned short*)(base + wl.off_hs); xa.sync = (unsigned*)base; xa.B = B; xa.KBI = ceil_div(2 * Hp, 32);
+  xa.wih0 = nullptr; xa.ximg = img_x; xa.bias0 = bias_p_host[0]; xa.KC0 = 0; xa.KCM = 0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
+  xa.wtail = nullptr;
+  xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin_limit();
+  xa.dbg = nullptr; xa.ablate = (flags >> 8) & 8; xa.terms = 3; xa.save_g = nullptr; xa.save_c = nullptr; xa.frames = nullptr;
+  ONSSEN_CLEAR_ERROR();
+  switch (ug) {
+    case 4: rc = launch_xcd_pair<1>(xa, st); break;
+    case 8: rc = launch_xcd_pair<2>(xa, st); break;
+    case 12: rc = launch_xcd_pair<3>(xa, st); break;
+    case 16: rc = launch_xcd_pair<4>(xa, st); break;
+    case 20: rc = launch_xcd_pair<5>(xa, st); break;
+    default: return ONSSEN_E_ARG;
+  }
+  if (rc != ONSSEN_OK) return rc;
+  // layer 1's input projection of THIS batch, for the next call
+  return onssen_linear_x3p(img0, T * B, 2 * Hp, (const uint16_t*)wih_p_host[1], bias_p_host[1], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G1, B,
+                           (int64_t)B * 2 * NP, 2 * NP, stream);
+}
+
 // ---- training: one layer forward with saved state, and its backward recurrence ----------------
 int onssen_lstm_train_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
                                   const uint16_t* wih_img, const uint16_t* whh_x3, const float* bias_p, float* y,

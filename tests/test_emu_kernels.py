@@ -551,6 +551,87 @@ def test_blstm_xcd_local_persistent(lib, monkeypatch, H, ug, B, T, scramble, fus
     assert np.all(np.array(y)[:, :, :, H:] == 0)
 
 
+def _x3_decode(img, rows, K):
+    """fp32 values of an x3 image [rows][ceil(K/32)][2][32] (bf16 hi | lo halves): hi + lo."""
+    v = img.reshape(rows, -1, 2, 32).astype(np.uint32) << 16
+    f = v.view(np.float32)
+    return (f[:, :, 0, :] + f[:, :, 1, :]).reshape(rows, -1)[:, :K]
+
+
+@pytest.mark.parametrize("H,ug,B,T,scramble", [(8, 4, 3, 4, "0"), (24, 8, 17, 3, "0"), (16, 4, 9, 5, "1")])
+def test_blstm_pipe2_two_layers_pipelined_over_calls(lib, monkeypatch, H, ug, B, T, scramble):
+    """onssen_blstm_pipe2_forward_f32 (round 6): call n runs layer 1 of batch n-1 beside layer 0 of batch n in ONE persistent
+    launch (each on its own groups); after call n the workspace holds the x3 image of the stack's output for batch n-1.
+    Three different batches + one draining call against the oracle's two-layer stack; the image bits equal those of the
+    sequential persistent form's y (same arithmetic per group: 8-row stacked up to B = 16, 16-row unstacked above)."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
+    lib.dll.onssen_xcd_spin_limit(40000000)
+    F, L = 9, 2
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(5)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    wih3, whh3, bias = [], [], []
+    for l in range(L):
+        K = F if l == 0 else 2 * Hp
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
+        scratch = _shm((we,))
+        for d, sfx in enumerate(("", "_reverse")):
+            srcs = []
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                v = sd[f"rnn.{n}_l{l}{sfx}"]
+                sv = _shm(v.shape); sv[...] = v
+                srcs.append(sv)
+            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
+                          P(a[d]), P(scratch), P(c[d]), None)
+            lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
+        pl = _shm((2 * NP, (K + 31) // 32, 2, 32), dtype=np.uint16)
+        lib.x3_image(P(a), Kp, 0, 1, 2 * NP, K, P(pl), None)
+        wih3.append(pl), whh3.append(b3), bias.append(c)
+    nb = lib.blstm_pipe2_workspace_bytes(B, T, F, H, ug)
+    assert nb > 0 and lib.blstm_pipe2_workspace_bytes(33, T, F, H, ug) == 0      # B <= 32
+    ws = _shm((nb // 4 + 64,))
+    off, KB = lib.blstm_pipe2_y_image(B, T, F, H, ug)
+    flags = _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD
+    xs = [rand(rng, B, T, F) for _ in range(3)]
+    x = _shm((B, T, F))
+    got = []
+    for n in range(4):
+        x[...] = xs[min(n, 2)]
+        lib.blstm_pipe2_forward(P(x), T * F, F, B, T, F, H, ug, [P(a) for a in wih3], [P(a) for a in whh3], [P(a) for a in bias],
+                                P(ws), ws.nbytes, flags, None)
+        status = ws.view(np.uint32)
+        assert status[280] == 0, f"launch aborted (code {status[280]})"
+        assert status[281] == (1 if scramble == "1" else 0)
+        img = ws.view(np.uint16)[off // 2:off // 2 + T * B * KB * 64]
+        got.append(_x3_decode(np.array(img), T * B, 2 * Hp).reshape(T, B, 2, Hp))
+    assert np.all(np.isfinite(got[0]))                # call 0: the answer to an all-zero layer-1 projection
+    for n in range(3):
+        ref = O.blstm_stack(xs[n], sd, "rnn.", L)
+        y = got[n + 1]
+        out = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+        assert np.abs(out - ref).max() < 2e-5, n
+        assert np.all(y[:, :, :, H:] == 0)
+    # the sequential persistent form on the same rows: identical bits.  Up to 16 rows both run stacked tiles (4- or 8-row groups: a
+    # tile column never sees its neighbours); above, the pair runs 16-row groups, which the sequential form uses from 33 rows on
+    B2 = B if B <= 16 else 34
+    x2 = _shm((B2, T, F)); x2[...] = rand(rng, B2, T, F); x2[:B] = xs[1]
+    ws2 = _shm((lib.blstm_workspace_bytes(B2, T, F, H, L, ug) // 4 + 64,))
+    y2 = _shm((T, B2, 2, Hp), fill=np.nan)
+    lib.blstm_forward(P(x2), T * F, F, B2, T, F, H, L, ug, [P(a) for a in wih3], [P(a) for a in whh3], [P(a) for a in bias], P(y2), P(ws2),
+                      ws2.nbytes, flags, None)
+    off2, _ = lib.blstm_y_image(B2, T, F, H, L, ug)
+    img2 = _x3_decode(np.array(ws2.view(np.uint16)[off2 // 2:off2 // 2 + T * B2 * KB * 64]), T * B2, 2 * Hp).reshape(T, B2, 2, Hp)
+    np.testing.assert_array_equal(got[2], img2[:, :B])
+    # wrong flags are refused (the fused first layer, plain bf16 products, the launch-per-step form)
+    for bad in (flags | _abi.BLSTM_FUSE_IN0, flags | _abi.BLSTM_BF16, _abi.BLSTM_BF16X3):
+        with pytest.raises(_abi.OnssenError):
+            lib.blstm_pipe2_forward(P(x), T * F, F, B, T, F, H, ug, [P(a) for a in wih3], [P(a) for a in whh3], [P(a) for a in bias],
+                                    P(ws), ws.nbytes, bad, None)
+
+
 @pytest.mark.parametrize("H,B,T,ragged", [(48, 3, 4, False), (40, 17, 3, False), (48, 5, 4, True)])
 def test_blstm_xcd_24_unit_groups(lib, monkeypatch, H, B, T, ragged):
     """Round 4: 24 hidden units per member (640 < H <= 768 on the device: 32 members = every CU of an XCD) -- split-bf16 only,
