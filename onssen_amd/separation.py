@@ -204,3 +204,241 @@ def separate_dc(model, wav, window_size=256, hop_size=64, db_threshold=40.0, hos
         lab = torch.from_numpy(label.astype(np.int64)).to(wav.device).float()
         masks[b][act] = torch.stack([lab, 1.0 - lab], -1)
     return mask_istft(ri, masks, hop_size, wav.shape[-1])
+
+
+class DCPipeline:
+    """Deep-clustering separation of a STREAM of equally shaped batches, software-pipelined over consecutive batches (round 6;
+    the evaluation loop of onssen/utils/test.py:29-41 / egs/wsj0-2mix/deep_clustering/evaluate.py:31-45 hands over one batch after
+    the other).  A two-layer BLSTM of <= 32 rows fills the chip's 8 XCDs only with 8-row recurrence groups, whose time step costs
+    nearly what a 16-row group's does -- so ``push(batch n)`` runs, in ONE persistent launch, layer 1 of batch n-1 on half of the
+    XCDs and layer 0 of batch n on the other half (``onssen_blstm_pipe2_forward_f32``), with the rest of both batches' work around it:
+
+        STFT, target map, input projection of batch n -> [ layer 1 (n-1) || layer 0 (n) ] -> layer 1's projection of batch n;
+        fc_dc (active bins only) + 2-means + masks + iSTFT of batch n-1
+
+    and returns the separated batch n-1 -- (B, 2, n_samples), valid until the next-but-one ``push`` -- or None for the first
+    batch; ``flush()`` drains the last one.  Every batch gets exactly the arithmetic ``separate_dc`` gives it on 16-row recurrence
+    groups without the fused first layer (bit for bit what the same rows get inside a 64-row ``separate_dc`` call; last-bit
+    differences against the default 32-row call, inside the same tolerance); the price is one batch of latency.  Both parities of
+    the step are captured as hipGraphs (``graph=True``).
+
+    Needs an eval-mode ``deep_clustering`` with num_layers = 2, hidden <= 640, B <= 32 in the default split-bf16 arithmetic on the
+    persistent recurrence; anything else raises (use ``separate_dc``).  A launch that gave up a bounded wait is reported by the
+    next ``push`` / ``flush`` (XcdAborted; ``separate_dc_stream`` re-runs the affected batches with ``separate_dc``)."""
+
+    def __init__(self, model, B, n_samples, window_size=256, hop_size=64, db_threshold=40.0, iters=20, tol=1e-4, graph=True):
+        from . import _abi
+        from .hip import get_lib
+        from .nn._core import _XcdPolicy, _version_key, heads_take_image, precision
+        from .nn.deep_clustering import deep_clustering
+        dev = next(model.parameters()).device
+        D = getattr(model, "embedding_dim", 0)
+        F = window_size // 2 + 1
+        why = None
+        if not isinstance(model, deep_clustering) or model.num_layers != 2:
+            why = "a deep_clustering model with num_layers = 2"
+        elif model.training or dev.type != "cuda":
+            why = "an eval-mode model on a ROCm device"
+        elif F != model.input_dim:
+            why = f"window_size // 2 + 1 == input_dim ({model.input_dim})"
+        elif not 1 <= B <= 32 or model.hidden_dim > 640:
+            why = "1 <= B <= 32 and hidden_dim <= 640"
+        elif precision() != "bf16x3" or options.get("recurrence") != "1" or not _XcdPolicy.persistent_allowed():
+            why = "the default split-bf16 arithmetic on the persistent recurrence"
+        elif options.get("dc_cluster") != "1" or options.get("dc_compact") != "1" or D > 32 or not heads_take_image(B, model.hidden_dim, (D,)):
+            why = "the compacted device-side clustering (embedding_dim in 4, 8, 16, 20; dc_cluster / dc_compact on)"
+        if why:
+            raise RuntimeError(f"DCPipeline needs {why}; use separate_dc")
+        self.model, self.lib, self.dev = model, get_lib(), dev
+        self.B, self.n, self.nfft, self.hop = int(B), int(n_samples), int(window_size), int(hop_size)
+        self.T, self.F, self.D = 1 + self.n // self.hop, F, D
+        self.db, self.iters, self.tol = float(db_threshold), int(iters), float(tol)
+        self.H, self.ug = model.hidden_dim, 4 * -(-model.hidden_dim // 128)
+        self.flags = _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD
+        lib, T = self.lib, self.T
+        mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.wav = [torch.zeros(B, self.n, device=dev) for _ in range(2)]
+        self.logmag = [mk(B, T, F) for _ in range(2)]
+        self.ri = [mk(B, T, F, 2) for _ in range(2)]
+        self.out = [torch.zeros(B, 2, self.n, device=dev) for _ in range(2)]
+        self.masks = mk(B, T, F, 2)
+        self.cnb, self.comp_off, self.dest_off = lib.dc_compact_layout(B, T, F, D)
+        self.cws = []
+        for _ in range(2):
+            w = torch.empty(self.cnb, dtype=torch.uint8, device=dev)
+            w[:self.comp_off].zero_()
+            self.cws.append(w)
+        self.cstat = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
+        self.wnb = lib.blstm_pipe2_workspace_bytes(B, T, F, self.H, self.ug)
+        self.ws = torch.zeros(self.wnb, dtype=torch.uint8, device=dev)          # zeroed ONCE (ABI)
+        self.img_off, _ = lib.blstm_pipe2_y_image(B, T, F, self.H, self.ug)
+        self.count = 0               # batches pushed since the last reset
+        self.graphs = [None, None]
+        self.use_graph = bool(graph)
+        self._wkey = None
+        self._version_key = _version_key
+        self._prime()
+
+    # -- one pipeline step on the current stream: buffers of parity p take batch n, those of 1 - p hold batch n - 1
+    def _enqueue(self, p, back_end=True):
+        lib, B, T, F, D = self.lib, self.B, self.T, self.F, self.D
+        st = torch.cuda.current_stream().cuda_stream
+        pk = self.model._packed.get(self.ug)
+        hd = self.model._head.get(pk.Hp)
+        q = 1 - p
+        lib.stft_logmag(self.wav[p].data_ptr(), B, self.n, self.n, self.nfft, self.hop, 1e-7, self.logmag[p].data_ptr(),
+                        self.ri[p].data_ptr(), st)
+        lib.dc_index(self.logmag[p].data_ptr(), B, T, F, D, self.db, self.cws[p].data_ptr(), self.cnb, st)
+        lib.blstm_pipe2_forward(self.logmag[p].data_ptr(), T * F, F, B, T, F, self.H, self.ug,
+                                [t.data_ptr() for t in pk.wih_img], [t.data_ptr() for t in pk.whh_x3], [t.data_ptr() for t in pk.bias],
+                                self.ws.data_ptr(), self.wnb, self.flags, st)
+        if not back_end:
+            return
+        cw = self.cws[q]
+        lib.linear_x3p_compact(self.ws.data_ptr() + self.img_off, T * B, 2 * pk.Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
+                               cw.data_ptr() + self.dest_off, T * F, F, cw.data_ptr() + self.comp_off, B, T * F * D, False, st)
+        lib.dc_cluster_compact(B, T, F, D, self.iters, self.masks.data_ptr(), cw.data_ptr(), self.cnb, st, tol=self.tol)
+        m = self.masks
+        lib.mask_istft(self.ri[q].data_ptr(), m.data_ptr(), m.stride(0), m.stride(3), m.stride(1), m.stride(2), B, 2, T, self.nfft,
+                       self.hop, self.n, self.out[p].data_ptr(), st)
+
+    def _prime(self):
+        """Two eager steps on silence: every kernel has run once, both target maps and the layer-1 projection hold finite data."""
+        from .nn._core import _XcdStatus
+        _XcdStatus.poll()
+        for p in (0, 1):
+            self._enqueue(p, back_end=p == 1)
+        self._post()
+        self.count = 0
+
+    def _post(self):
+        from .nn._core import _XcdStatus
+        _XcdStatus.post(self.ws)
+        for w in self.cws:
+            _XcdStatus.post_cluster(w, self.cstat)
+
+    def _capture(self):
+        key = self._version_key(self.model.rnn.flat_weights() + [self.model.fc_dc.weight, self.model.bn.running_mean])
+        if self._wkey == key and self.graphs[0] is not None:
+            return
+        pk = self.model._packed.get(self.ug)         # (re)pack eagerly: inside the capture these only mark the images as captured
+        self.model._head.get(pk.Hp)
+        torch.cuda.synchronize(self.dev)
+        self.graphs = [None, None]
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._enqueue(p)
+            self.graphs[p] = g
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        self._wkey = key
+
+    def step(self, p):
+        if self.use_graph:
+            self.graphs[p].replay()
+        else:
+            self._enqueue(p)
+
+    def replay(self):
+        """One steady-state step on the input buffers as they are (``self.wav[parity]``: bench.py fills them once and times this):
+        no copy, no status traffic.  At least one batch must be in flight (the parities alternate from there)."""
+        if self.count == 0:
+            raise RuntimeError("DCPipeline.replay: push a batch first")
+        if self.use_graph:
+            self._capture()
+        self.step(self.count & 1)
+        self.count += 1
+
+    @torch.no_grad()
+    def push(self, wav, check=True):
+        """Hand over batch n (B, n_samples) float32 on the device; returns the separated batch n-1 (B, 2, n_samples) or None."""
+        from .nn._core import _XcdStatus
+        if tuple(wav.shape) != (self.B, self.n) or not wav.is_cuda:
+            raise ValueError(f"DCPipeline.push: expected a ({self.B}, {self.n}) tensor on {self.dev}, got {tuple(wav.shape)} on {wav.device}")
+        if check:
+            _XcdStatus.poll()                      # reports of earlier steps that have landed (raises XcdAborted)
+        if self.use_graph:
+            self._capture()
+        p = self.count & 1
+        self.wav[p].copy_(wav, non_blocking=True)
+        if self.count == 0:
+            # the first batch of a stream has nothing behind it: no back end (the other parity's clustering workspace holds a map that
+            # was consumed by the drain, or none) -- an eager step, the captured graphs are the steady state
+            self._enqueue(p, back_end=False)
+        else:
+            self.step(p)
+        if check:
+            self._post()
+        self.count += 1
+        return self.out[p] if self.count > 1 else None
+
+    @torch.no_grad()
+    def flush(self):
+        """Drain: the separated LAST batch (or None if nothing is in flight); the pipeline is empty afterwards."""
+        from .nn._core import _XcdStatus
+        if self.count == 0:
+            return None
+        p = self.count & 1
+        self.wav[p].zero_()
+        if self.use_graph:
+            self._capture()
+        self.step(p)
+        self._post()
+        self.count = 0
+        _XcdStatus.flush()
+        return self.out[p]
+
+    def reset(self):
+        """Forget the batch in flight (after an aborted step: the exchange header was zeroed by the status poll)."""
+        self.count = 0
+
+
+@torch.no_grad()
+def separate_dc_stream(model, batches, window_size=256, hop_size=64, db_threshold=40.0, graph=True):
+    """Generator: ``separate_dc`` over an iterable of equally shaped (B, n) device batches, through ``DCPipeline`` -- yields one
+    (B, 2, n) result per batch, in order (a fresh tensor each).  A step whose persistent launch gave up a bounded wait is
+    recovered here: the two batches it touched are separated again with ``separate_dc`` and the pipeline restarts.  Batches
+    the pipeline cannot take (see DCPipeline) go through ``separate_dc`` one by one."""
+    import warnings
+    from .nn._core import XcdAborted, _XcdPolicy, _XcdStatus
+    pipe, held = None, []                      # held: inputs whose result has not been yielded yet (at most 2)
+    for wav in batches:
+        if pipe is None:
+            try:
+                pipe = DCPipeline(model, wav.shape[0], wav.shape[1], window_size, hop_size, db_threshold, graph=graph)
+            except RuntimeError:
+                pipe = False
+        if pipe is False or tuple(wav.shape) != (pipe.B, pipe.n):
+            for h in held:                     # (a shape change: drain what is in flight first)
+                yield separate_dc(model, h, window_size, hop_size, db_threshold)
+            held = []
+            if pipe:
+                pipe.reset()
+            yield separate_dc(model, wav, window_size, hop_size, db_threshold)
+            continue
+        held.append(wav)
+        try:
+            out = pipe.push(wav)
+            if out is not None:
+                res = out.clone()
+                _XcdStatus.flush()             # the step that produced it has completed cleanly (the next one is not enqueued yet)
+                held.pop(0)
+                yield res
+        except XcdAborted as e:
+            _XcdPolicy.recovered += 1
+            warnings.warn(f"onssen_amd: {e}  Re-running the batches of that pipeline step with separate_dc.", RuntimeWarning)
+            pipe.reset()
+            for h in held:
+                yield separate_dc(model, h, window_size, hop_size, db_threshold)
+            held = []
+    if pipe and held:
+        try:
+            res = pipe.flush().clone()
+            yield res
+        except XcdAborted as e:
+            _XcdPolicy.recovered += 1
+            warnings.warn(f"onssen_amd: {e}  Re-running the last batch with separate_dc.", RuntimeWarning)
+            pipe.reset()
+            yield separate_dc(model, held[-1], window_size, hop_size, db_threshold)
