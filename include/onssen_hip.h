@@ -336,7 +336,8 @@ int onssen_blstm_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, 
  * extra call (any x) drains the last batch.  Per batch the results are bit for bit those of onssen_blstm_forward_f32 on 16-row
  * groups without ONSSEN_BLSTM_FUSE_IN0 (e.g. the same rows inside a B = 64 call); against the default B = 32 call (stacked 8-row
  * groups, which add the lo x lo products) they differ in the last bits, inside the same tolerance.
- *   flags: ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD exactly (the plain split-bf16 persistent recurrence), H <= 640.
+ *   flags: ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD exactly (the plain split-bf16 persistent recurrence), H <= 640; plus, as a
+ *   measurement aid, ONSSEN_BLSTM_G_READY: only the persistent launch, on the projections an earlier call left in ws.
  *   wih_p_host / whh_p_host / bias_p_host: HOST arrays of 2 device pointers as for onssen_blstm_forward_f32 in that form (x3 image
  *   of the packed projection, the two directions' onssen_lstm_pack_whh_bf16x3 images, packed bias).
  *   ws: onssen_blstm_pipe2_workspace_bytes() bytes, 256-byte aligned, ZEROED ONCE by its owner; header words as above. */

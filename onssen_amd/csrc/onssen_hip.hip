@@ -1156,7 +1156,8 @@ int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, i
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK) return ONSSEN_E_ARG;
   if (!x || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || B > 32 || T <= 0 || in_dim <= 0) return ONSSEN_E_ARG;
   // the plain split-bf16 persistent recurrence only (no fused first layer, no bf16-only products)
-  if ((flags & 0xff) != (ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD)) return ONSSEN_E_ARG;
+  if ((flags & 0xff & ~ONSSEN_BLSTM_G_READY) != (ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD)) return ONSSEN_E_ARG;
+  const bool g_ready = (flags & ONSSEN_BLSTM_G_READY) != 0;     // measurement aid: the pair launch by itself, on the projections an earlier call left
   Pipe2Ws wl;
   if (!pipe2_ws_layout(B, T, in_dim, H, ug, &wl)) return ONSSEN_E_ARG;
   if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
@@ -1171,11 +1172,14 @@ int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, i
   uint16_t* img0 = (uint16_t*)(base + wl.off_img0);
   uint16_t* img1 = (uint16_t*)(base + wl.off_img1);
   // layer 0 of THIS batch: input image, input projection
-  int rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
-  if (rc != ONSSEN_OK) return rc;
-  rc = onssen_linear_x3p(img_x, T * B, in_dim, (const uint16_t*)wih_p_host[0], bias_p_host[0], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G0, B,
-                         (int64_t)B * 2 * NP, 2 * NP, stream);
-  if (rc != ONSSEN_OK) return rc;
+  int rc = ONSSEN_OK;
+  if (!g_ready) {
+    rc = onssen_x3_image_f32(x, xs_t, xs_b, B, T * B, in_dim, img_x, stream);
+    if (rc != ONSSEN_OK) return rc;
+    rc = onssen_linear_x3p(img_x, T * B, in_dim, (const uint16_t*)wih_p_host[0], bias_p_host[0], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G0, B,
+                           (int64_t)B * 2 * NP, 2 * NP, stream);
+    if (rc != ONSSEN_OK) return rc;
+  }
   // ONE launch: layer 1 of the batch before (its G1 was left by the call before) beside layer 0 of this one
   XcdArgs xa;
   xa.G = G1; xa.whh = (const unsigned short*)whh_p_host[1]; xa.y = nullptr; xa.yimg = img1;
@@ -1194,7 +1198,7 @@ int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, i
     case 20: rc = launch_xcd_pair<5>(xa, st); break;
     default: return ONSSEN_E_ARG;
   }
-  if (rc != ONSSEN_OK) return rc;
+  if (rc != ONSSEN_OK || g_ready) return rc;
   // layer 1's input projection of THIS batch, for the next call
   return onssen_linear_x3p(img0, T * B, 2 * Hp, (const uint16_t*)wih_p_host[1], bias_p_host[1], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G1, B,
                            (int64_t)B * 2 * NP, 2 * NP, stream);

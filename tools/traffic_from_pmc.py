@@ -29,6 +29,15 @@ if f is not None and w is not None:
     out.update({"kernel": kname + ", ...> (layer >= 1 of the headline step)", "xcd_FETCH_SIZE_KB_per_launch_raw": f,
                 "xcd_WRITE_SIZE_KB_per_launch_raw": w, "dispatches": [nf, nw],
                 "xcd_recurrence_hbm_bytes_per_launch": int((2 * f + w) * 1024)})
+# the PAIR launch of the pipelined step (onssen_blstm_pipe2_forward_f32): the unstacked instantiation on 16-row groups, two layers' worth
+pname = "lstm_xcd_kernel<5, 8, false, 3, false, false"
+f, nf = mean(pname, "FETCH_SIZE")
+w, nw = mean(pname, "WRITE_SIZE")
+if f is not None and w is not None:
+    out.update({"pair_kernel": pname + ", ...> (layer 1 of batch k-1 || layer 0 of batch k)", "xcd_pair_FETCH_SIZE_KB_per_launch_raw": f,
+                "xcd_pair_WRITE_SIZE_KB_per_launch_raw": w, "pair_dispatches": [nf, nw],
+                "xcd_pair_recurrence_hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                "xcd_pair_algorithmic_bytes_per_launch": 2 * 319539200})
 for label, part in (("linear_x3q_l1", "linear_x3q_kernel<0, 3, false, 3"), ("linear_x3q_head_full_embedding", "linear_x3q_kernel<1, 3"),
                     ("linear_x3q_head_active_rows_only", "linear_x3q_kernel<4, 3"), ("kmeans2_search_farthest", "kmeans2_search_kernel<2"),
                     ("kmeans2_lloyd", "kmeans2_lloyd_kernel"),
