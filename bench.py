@@ -323,6 +323,19 @@ def trained_leg(dev, B=32, steps=1000):
         sig = step()
         sdr = batch_SDR_torch(sig, ref)
         sdr_mix = batch_SDR_torch(torch.stack([wav, wav], 1), ref)
+        # the same weights and mixtures through the two-batch pipeline (what the headline line times): its step, its SI-SDR
+        piped = None
+        try:
+            from onssen_amd.separation import DCPipeline
+            pipe = DCPipeline(model, B, n, 256, 64)
+            pipe.push(wav)
+            sdr_p = batch_SDR_torch(pipe.push(wav), ref)
+            pipe.wav[0].copy_(wav); pipe.wav[1].copy_(wav)
+            ms_p = time_replays(pipe.replay, 20, warm=20)
+            piped = {"ms_per_step": ms_p, "x_real_time": B * 3.2 / ms_p * 1e3, "si_sdr_db_separated_mean": float(sdr_p.mean()),
+                     "lloyd_iterations": lloyd_iterations(B, 400, F, D, ws=pipe.cws[pipe.count & 1])}
+        except RuntimeError as e:
+            piped = {"error": f"{e}"[:200]}
     torch.cuda.synchronize()
     _XcdStatus.poll(wait=True)
     return {"workload": f"the headline step (dc_l2, {B} x 400-frame chunks, hipGraph replay) with weights from {steps} training steps on the "
@@ -330,6 +343,7 @@ def trained_leg(dev, B=32, steps=1000):
             "training": {"steps": steps, "seconds": train_s, "ms_per_step_with_corpus": train_s / steps * 1e3,
                          "loss_first_100": float(np.mean(losses[:100])), "loss_last_100": float(np.mean(losses[-100:]))},
             "ms_per_step": ms, "x_real_time": B * 3.2 / ms * 1e3, "lloyd_iterations": lloyd_iterations(B, 400, F, D),
+            "pipelined": piped,
             "si_sdr_db": {"separated_mean": float(sdr.mean()), "separated_min": float(sdr.min()), "mixture_mean": float(sdr_mix.mean())}}
 
 
@@ -705,7 +719,7 @@ def main():
             try:
                 keep = wav.clone()
                 set_inputs(torch.from_numpy(synth_batch(77, B, N_SAMPLES, SR)).to(dev))
-                ms2 = time_replays(run, 10)
+                ms2 = time_replays(run, 20, warm=100)      # (the host has just synthesised the new batch with the GPU idle: back to sustained clocks first)
                 second = {"inputs": f"{B} distinct synthetic utterances (seeds 77000..)", "ms_per_step": ms2,
                           "x_real_time": B * (T_FRAMES * HOP / SR) / ms2 * 1e3, "lloyd_iterations": lloyd_now()}
                 set_inputs(keep)
@@ -713,7 +727,7 @@ def main():
             except Exception as e:
                 second = {"error": f"{type(e).__name__}: {e}"[:200]}
             if pipe is not None:
-                ms1 = time_replays(run_single, 10)
+                ms1 = time_replays(run_single, 20, warm=40)
                 single = {"ms_per_step": ms1, "x_real_time": B * (T_FRAMES * HOP / SR) / ms1 * 1e3,
                           "what": "the same batch one at a time (separation.separate_dc's launches in one hipGraph: STFT -> layer 0 with its fused "
                                   "projection -> layer 1 -> fc_dc -> 2-means -> iSTFT, stacked 8-row recurrence groups on all 8 XCDs): the step "
