@@ -74,9 +74,10 @@ def test_recorded_eight_rank_self_test_line():
 
 
 def test_recorded_bench_line_carries_the_contract():
-    """profiles/r06_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
-    key the bench contract names, the roofline and CPU-baseline blocks (round 6: BASELINE.md section 3's protocol), and the round-5 additions."""
-    r = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_final.json")).read().strip().splitlines()[-1])
+    """profiles/r06b_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
+    key the bench contract names, the roofline and CPU-baseline blocks (round 6: BASELINE.md section 3's protocol), the round-5 additions and
+    (round 6b) the two-batch pipeline the headline step runs through, with the one-batch-at-a-time step beside it."""
+    r = json.loads(open(os.path.join(ROOT, "profiles", "r06b_bench_final.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in r, k
     assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 5 and r["higher_is_better"] is True and r["scaling"] == "weak"
@@ -87,6 +88,17 @@ def test_recorded_bench_line_carries_the_contract():
         assert k in roof, k
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["legs_le_step"] is True                                                   # the legs timed one by one sum to <= the step
+    # the pipelined step: one persistent launch holds two layers' recurrences (twice the FLOPs of one), every step is a whole batch
+    pl = r["config"]["pipeline"]
+    assert pl["depth"] == 2 and abs(pl["batch_latency_ms"] - 2 * r["ms_per_step"]) < 1e-9
+    assert "pair launch" in roof["kernel"] and abs(roof["algorithmic_flop_per_launch"] - 2 * 2.0 * 2 * 32 * 4 * 600 * 600 * 400) < 1.0
+    assert abs(roof["achieved"] - roof["algorithmic_flop_per_launch"] / (roof["us_per_launch"] * 1e-6) / 1e12) < 1e-6 * roof["achieved"]
+    assert set(roof["legs_ms"]) == {"stft_logmag", "threshold_target_map", "input_proj_l0_with_split", "pair_recurrence_l1_prev_l0_this",
+                                    "input_proj_l1", "fc_dc_l2norm_active_rows_only", "init_lloyd_masks", "mask_istft"}
+    seq = roof["one_batch_at_a_time_form"]
+    assert seq["kernel"] == "lstm_xcd_kernel" and 0 < seq["frac"] < roof["frac"]
+    one = r["one_batch_at_a_time_step"]
+    assert one["ms_per_step"] > r["ms_per_step"] and abs(one["x_real_time"] - 32 * 3.2 / (one["ms_per_step"] * 1e-3)) < 1e-6 * one["x_real_time"]
     cpu = r["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
@@ -105,5 +117,7 @@ def test_recorded_bench_line_carries_the_contract():
     assert r["lloyd_iterations"]["cap"] == 20 and "second_input_set" in r
     ex = r["extra_configs"]
     assert ex["trained_weights_dc_l2_b32"]["si_sdr_db"]["separated_mean"] > 8.0           # the headline step on a trained network separates
+    tp = ex["trained_weights_dc_l2_b32"]["pipelined"]                                      # ... and so does the pipelined one, faster
+    assert tp["si_sdr_db_separated_mean"] > 8.0 and tp["ms_per_step"] < ex["trained_weights_dc_l2_b32"]["ms_per_step"]
     assert [row["chunks"] for row in ex["batch_sweep"]["dc_l2"]["rows"]] == [8, 16, 32, 64, 128, 256]
     assert ex["cfg4_training_step_dc_l3_b16"]["ms_per_step"] < 7.5
