@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ONSSEN_ABI_VERSION 13   /* 13: onssen_blstm_pipe2_* (a two-layer stack software-pipelined over consecutive calls: layer 1 of batch n-1 and layer 0 of batch n in ONE persistent launch, each on half of the XCDs).  12: onssen_log_magnitude_f32, onssen_cos_difference_f32, onssen_one_hot_f32 (the reference's stand-alone feature helpers).  11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
+#define ONSSEN_ABI_VERSION 14   /* 14: onssen_blstm_pipe2_forward_ragged_f32 (the pipelined pair launch over a stream of RAGGED batches of whole utterances: each half of the launch runs its own batch's time steps and row lengths).  13: onssen_blstm_pipe2_* (a two-layer stack software-pipelined over consecutive calls: layer 1 of batch n-1 and layer 0 of batch n in ONE persistent launch, each on half of the XCDs).  12: onssen_log_magnitude_f32, onssen_cos_difference_f32, onssen_one_hot_f32 (the reference's stand-alone feature helpers).  11: onssen_wav_info, onssen_wav_read_batch_f32 (host-side batch RIFF reader of the file loader), onssen_lstm_pack_wih_image_f32, onssen_clip_adam_f32, onssen_lstm_train_backward_img_f32, onssen_lstm_pack_train_f32.  10: onssen_linear_x3p_norms, onssen_l2norm_rows_grad_y_f32, onssen_linear_x3p_batched_split_alt, onssen_x3_image_both_colsum_f32, onssen_dc_head_grad_images_f32, onssen_lstm_wgrad_images_f32, onssen_linear_x3t, onssen_blstm_x_image; ug = 24 (640 < H <= 768) in the persistent split-bf16 recurrence.  9: ragged batches of whole utterances (onssen_*_ragged_f32), the compacted deep-clustering back end, `tol` of onssen_dc_cluster_*, onssen_lstm_train_forward_form_f32.  8: onssen_linear_x3p_resid, onssen_linear_x3p_pair, onssen_x3_image_both_f32.  7: onssen_xcd_spin_limit, onssen_debug_cotenant_spin, chimera mask-loss gradient, compacted clustering.  6: onssen_dropout_f32, onssen_loss_dc_grad_f32, onssen_linear_x3p_batched_split, db_rows of onssen_lstm_train_backward_f32, l2norm_rows and bn_rows kernels; backward recurrence exchanges tagged partial sums.  5: status word [282] (non-finite h), W_hh fragment images unit-major, fp64 SDR workspace */
 
 #define ONSSEN_OK 0
 #define ONSSEN_E_ARG (-1)         /* invalid argument / unsupported shape */
@@ -346,6 +346,17 @@ int onssen_blstm_pipe2_y_image(int B, int T, int in_dim, int H, int ug, size_t* 
 int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
                                    const float* const* wih_p_host, const float* const* whh_p_host,
                                    const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream);
+/* ... over a stream of RAGGED batches of whole utterances (round 6c; the reference evaluates them one by one, onssen/utils/test.py:29-41;
+ * onssen_blstm_forward_ragged_f32 runs K of different lengths per call): batch n is B <= 16 rows padded to ITS longest utterance,
+ * T frames, row b live for frames[b] <= T of them; the launch's other half still works on batch n-1 (T_prev, frames_prev -- the
+ * values that call n-1 was given; call 0: any valid pair, e.g. this call's own).  The workspace is laid out for T_cap >= every T
+ * of the stream (onssen_blstm_pipe2_workspace_bytes / _y_image with T = T_cap); the image of batch n-1 holds T_prev * B rows, zeros
+ * at t >= frames_prev[b].  Every row's outputs at its own frames are bit for bit those of onssen_blstm_forward_ragged_f32 (i.e. of
+ * its own batch-1 run): stacked tiles in both. */
+int onssen_blstm_pipe2_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T_cap, int T, const int32_t* frames,
+                                          int T_prev, const int32_t* frames_prev, int in_dim, int H, int ug,
+                                          const float* const* wih_p_host, const float* const* whh_p_host,
+                                          const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream);
 
 /* ---- Training: nn.LSTM forward with saved state and its backward recurrence ------------------
  * What `loss.backward()` does for `self.rnn` (onssen/utils/train.py:80-84; nn.LSTM autograd), one layer at a time so that

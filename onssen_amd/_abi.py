@@ -10,7 +10,7 @@ import os
 
 EPI_BIAS, EPI_L2NORM, EPI_SIGMOID, EPI_RELU = 0, 1, 2, 3
 EPI_BF16 = 0x100   # OR-ed into the mode of linear_x3p: plain bf16 products
-ABI_VERSION = 13
+ABI_VERSION = 14
 WAV_TRUNCATED = 1
 BLSTM_SPLIT_ROWS = 1
 BLSTM_BF16X3 = 2
@@ -56,6 +56,7 @@ SIGNATURES = {
     "onssen_blstm_pipe2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "onssen_blstm_pipe2_y_image": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
     "onssen_blstm_pipe2_forward_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _i, _i, _pp, _pp, _pp, _vp, _sz, _i, _vp]),
+    "onssen_blstm_pipe2_forward_ragged_f32": (_i, [_vp, _i64, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _i, _pp, _pp, _pp, _vp, _sz, _i, _vp]),
     "onssen_linear_x3p_batched": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "onssen_linear_x3p_batched_split": (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _i, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64, _i64,
                                              _i, _vp]),
@@ -318,6 +319,15 @@ class Lib:
         self.check(self.dll.onssen_blstm_pipe2_forward_f32(x, xs_b, xs_t, B, T, in_dim, H, ug, arr(*wih_ptrs), arr(*whh_ptrs),
                                                            arr(*bias_ptrs), ws, ws_bytes, flags, stream),
                    "onssen_blstm_pipe2_forward_f32")
+
+    def blstm_pipe2_forward_ragged(self, x, xs_b, xs_t, B, T_cap, T, frames, T_prev, frames_prev, in_dim, H, ug, wih_ptrs, whh_ptrs,
+                                   bias_ptrs, ws, ws_bytes, flags, stream):
+        """The pair launch over a stream of ragged batches: this call's batch (T, frames) beside the one before (T_prev, frames_prev)."""
+        arr = C.c_void_p * 2
+        self.check(self.dll.onssen_blstm_pipe2_forward_ragged_f32(x, xs_b, xs_t, B, T_cap, T, frames, T_prev, frames_prev, in_dim, H, ug,
+                                                                  arr(*wih_ptrs), arr(*whh_ptrs), arr(*bias_ptrs), ws, ws_bytes, flags,
+                                                                  stream),
+                   "onssen_blstm_pipe2_forward_ragged_f32")
 
     # ---- training (row N1)
     def linear_x3p_batched(self, a_img, a_bs, M, K, w_img, w_bs, bias, N, out, c_bs, ldc, batch, stream):

@@ -1149,17 +1149,22 @@ int onssen_blstm_pipe2_y_image(int B, int T, int in_dim, int H, int ug, size_t* 
   return ONSSEN_OK;
 }
 
-int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
-                                   const float* const* wih_p_host, const float* const* whh_p_host,
-                                   const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream) {
+// T_cap lays the workspace out (>= every T that passes through it); the uniform form has T_cap = T = T_prev and no frames
+static int blstm_pipe2_impl(const float* x, int64_t xs_b, int64_t xs_t, int B, int T_cap, int T, const int32_t* frames, int T_prev,
+                            const int32_t* frames_prev, int in_dim, int H, int ug, const float* const* wih_p_host,
+                            const float* const* whh_p_host, const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags,
+                            void* stream) {
   int Hp, NP, KQ2 = 0, Hs = 0;
   if (onssen_lstm_geometry(H, ug, &Hp, &NP, nullptr, nullptr) != ONSSEN_OK) return ONSSEN_E_ARG;
   if (!x || !ws || !wih_p_host || !whh_p_host || !bias_p_host || B <= 0 || B > 32 || T <= 0 || in_dim <= 0) return ONSSEN_E_ARG;
+  if (T > T_cap || T_prev <= 0 || T_prev > T_cap) return ONSSEN_E_ARG;
+  // ragged rows keep the bits of their own batch-1 run: stacked tiles only, i.e. <= 16 rows; both batches bring their frames
+  if ((frames != nullptr) != (frames_prev != nullptr) || (frames && B > 16)) return ONSSEN_E_ARG;
   // the plain split-bf16 persistent recurrence only (no fused first layer, no bf16-only products)
   if ((flags & 0xff & ~ONSSEN_BLSTM_G_READY) != (ONSSEN_BLSTM_BF16X3 | ONSSEN_BLSTM_XCD)) return ONSSEN_E_ARG;
   const bool g_ready = (flags & ONSSEN_BLSTM_G_READY) != 0;     // measurement aid: the pair launch by itself, on the projections an earlier call left
   Pipe2Ws wl;
-  if (!pipe2_ws_layout(B, T, in_dim, H, ug, &wl)) return ONSSEN_E_ARG;
+  if (!pipe2_ws_layout(B, T_cap, in_dim, H, ug, &wl)) return ONSSEN_E_ARG;
   if (ws_bytes < wl.total) return ONSSEN_E_WORKSPACE;
   if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) return ONSSEN_E_ALIGN;
   onssen_lstm_geometry_x3(H, ug, &KQ2, &Hs, nullptr);
@@ -1187,8 +1192,9 @@ int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, i
   xa.hx = (unsigned short*)(base + wl.off_hs); xa.sync = (unsigned*)base; xa.B = B; xa.KBI = ceil_div(2 * Hp, 32);
   xa.wih0 = nullptr; xa.ximg = img_x; xa.bias0 = bias_p_host[0]; xa.KC0 = 0; xa.KCM = 0; xa.x0 = x; xa.xs_b = (long)xs_b; xa.xs_t = (long)xs_t;
   xa.wtail = nullptr;
-  xa.T = T; xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin_limit();
-  xa.dbg = nullptr; xa.ablate = (flags >> 8) & 8; xa.terms = 3; xa.save_g = nullptr; xa.save_c = nullptr; xa.frames = nullptr;
+  xa.T = T_prev; xa.T_b = T; xa.frames = frames_prev; xa.frames_b = frames;
+  xa.Hp = Hp; xa.NP = NP; xa.KQ2 = KQ2; xa.NU = Hp / ug; xa.row0 = 0; xa.nbg = 0; xa.spin_limit = xcd_spin_limit();
+  xa.dbg = nullptr; xa.ablate = (flags >> 8) & 8; xa.terms = 3; xa.save_g = nullptr; xa.save_c = nullptr;
   ONSSEN_CLEAR_ERROR();
   switch (ug) {
     case 4: rc = launch_xcd_pair<1>(xa, st); break;
@@ -1202,6 +1208,22 @@ int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, i
   // layer 1's input projection of THIS batch, for the next call
   return onssen_linear_x3p(img0, T * B, 2 * Hp, (const uint16_t*)wih_p_host[1], bias_p_host[1], 2 * NP, ONSSEN_EPI_BIAS, 0, 0.f, G1, B,
                            (int64_t)B * 2 * NP, 2 * NP, stream);
+}
+
+int onssen_blstm_pipe2_forward_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T, int in_dim, int H, int ug,
+                                   const float* const* wih_p_host, const float* const* whh_p_host,
+                                   const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream) {
+  return blstm_pipe2_impl(x, xs_b, xs_t, B, T, T, nullptr, T, nullptr, in_dim, H, ug, wih_p_host, whh_p_host, bias_p_host, ws, ws_bytes,
+                          flags, stream);
+}
+
+int onssen_blstm_pipe2_forward_ragged_f32(const float* x, int64_t xs_b, int64_t xs_t, int B, int T_cap, int T, const int32_t* frames,
+                                          int T_prev, const int32_t* frames_prev, int in_dim, int H, int ug,
+                                          const float* const* wih_p_host, const float* const* whh_p_host,
+                                          const float* const* bias_p_host, void* ws, size_t ws_bytes, int flags, void* stream) {
+  if (!frames || !frames_prev) return ONSSEN_E_ARG;
+  return blstm_pipe2_impl(x, xs_b, xs_t, B, T_cap, T, frames, T_prev, frames_prev, in_dim, H, ug, wih_p_host, whh_p_host, bias_p_host, ws,
+                          ws_bytes, flags, stream);
 }
 
 // ---- training: one layer forward with saved state, and its backward recurrence ----------------

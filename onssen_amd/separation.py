@@ -395,6 +395,213 @@ class DCPipeline:
         self.count = 0
 
 
+class DCRaggedPipeline:
+    """``DCPipeline`` for a stream of RAGGED batches of whole utterances (round 6c) -- the shape the reference evaluates one by one
+    (onssen/utils/test.py:29-41) and ``separate_dc(..., lengths=)`` runs K at a time: every batch is B <= 16 rows padded to ITS OWN
+    longest utterance.  A ragged batch of <= 16 rows runs on stacked 4-row recurrence groups, whose time step costs what an 8-row
+    group's does, one layer after the other; here ``push(batch n)`` runs layer 1 of batch n-1 and layer 0 of batch n in ONE persistent
+    launch on stacked 8-row groups (``onssen_blstm_pipe2_forward_ragged_f32``: each half of the launch has its own number of time steps
+    and its own row lengths), with the rest of both batches' work around it exactly as in ``DCPipeline``, and returns the separated batch
+    n-1 -- (B, 2, n_{n-1}), valid until the next-but-one ``push`` -- or None for the first batch; ``flush()`` drains the last one.
+
+    Every utterance's result inside its own length is bit for bit what ``separate_dc(model, wav, lengths=lengths)`` gives it (stacked
+    tiles in both: a tile column never sees its neighbours), i.e. what the batch-1 call on that utterance returns; zeros after it.
+    Eager launches (a new longest utterance per batch: nothing to capture); buffers are sized once for ``n_cap`` samples per row.
+    Needs what ``DCPipeline`` needs, with B <= 16."""
+
+    def __init__(self, model, B, n_cap, window_size=256, hop_size=64, db_threshold=40.0, iters=20, tol=1e-4):
+        from . import _abi
+        from .hip import get_lib
+        from .nn._core import _XcdPolicy, heads_take_image, precision
+        from .nn.deep_clustering import deep_clustering
+        dev = next(model.parameters()).device
+        D = getattr(model, "embedding_dim", 0)
+        F = window_size // 2 + 1
+        why = None
+        if not isinstance(model, deep_clustering) or model.num_layers != 2:
+            why = "a deep_clustering model with num_layers = 2"
+        elif model.training or dev.type != "cuda":
+            why = "an eval-mode model on a ROCm device"
+        elif F != model.input_dim:
+            why = f"window_size // 2 + 1 == input_dim ({model.input_dim})"
+        elif not 1 <= B <= 16 or model.hidden_dim > 640:
+            why = "1 <= B <= 16 (ragged rows run on stacked tiles) and hidden_dim <= 640"
+        elif precision() != "bf16x3" or options.get("recurrence") != "1" or not _XcdPolicy.persistent_allowed():
+            why = "the default split-bf16 arithmetic on the persistent recurrence"
+        elif options.get("dc_cluster") != "1" or options.get("dc_compact") != "1" or D > 32 or not heads_take_image(B, model.hidden_dim, (D,)):
+            why = "the compacted device-side clustering (embedding_dim in 4, 8, 16, 20; dc_cluster / dc_compact on)"
+        elif n_cap < hop_size:
+            why = "n_cap >= hop_size"
+        if why:
+            raise RuntimeError(f"DCRaggedPipeline needs {why}; use separate_dc(..., lengths=)")
+        self.model, self.lib, self.dev = model, get_lib(), dev
+        self.B, self.n_cap, self.nfft, self.hop = int(B), int(n_cap), int(window_size), int(hop_size)
+        self.T_cap, self.F, self.D = 1 + self.n_cap // self.hop, F, D
+        self.db, self.iters, self.tol = float(db_threshold), int(iters), float(tol)
+        self.H, self.ug = model.hidden_dim, 4 * -(-model.hidden_dim // 128)
+        self.flags = _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD
+        lib, T = self.lib, self.T_cap
+        mk = lambda k: torch.empty(k, device=dev, dtype=torch.float32)
+        self.logmag = [torch.zeros(B * T * F, device=dev) for _ in range(2)]
+        self.ri = [mk(B * T * F * 2) for _ in range(2)]
+        self.out = [mk(B * 2 * self.n_cap) for _ in range(2)]
+        self.masks = mk(B * T * F * 2)
+        self.cnb, self.comp_off, _ = lib.dc_compact_layout(B, T, F, D)
+        self.cws = []
+        for _ in range(2):
+            w = torch.empty(self.cnb, dtype=torch.uint8, device=dev)
+            w[:self.comp_off].zero_()
+            self.cws.append(w)
+        self.cstat = int(lib.dll.onssen_dc_cluster_status_offset(B, D))
+        self.wnb = lib.blstm_pipe2_workspace_bytes(B, T, F, self.H, self.ug)
+        self.ws = torch.zeros(self.wnb, dtype=torch.uint8, device=dev)          # zeroed ONCE (ABI)
+        self.img_off, _ = lib.blstm_pipe2_y_image(B, T, F, self.H, self.ug)
+        self.meta = [None, None]     # per parity: (T, n, frames, lengths) of the batch its buffers hold
+        self.count = 0
+
+    def _step(self, p, x_ptr, cur, back_end):
+        """The pair launch for the batch ``cur`` = (T, n, frames, lengths) whose features sit at ``x_ptr`` beside the batch of parity
+        1 - p, then (``back_end``) that batch's head GEMM, clustering, masks and iSTFT into ``out[p]``."""
+        lib, B, F, D = self.lib, self.B, self.F, self.D
+        st = torch.cuda.current_stream().cuda_stream
+        pk = self.model._packed.get(self.ug)
+        hd = self.model._head.get(pk.Hp)
+        q = 1 - p
+        T, n, frames, lengths = cur
+        Tq, nq, frames_q, lengths_q = self.meta[q] if back_end else cur
+        lib.blstm_pipe2_forward_ragged(x_ptr, T * F, F, B, self.T_cap, T, frames.data_ptr(), Tq, frames_q.data_ptr(), F, self.H, self.ug,
+                                       [t.data_ptr() for t in pk.wih_img], [t.data_ptr() for t in pk.whh_x3],
+                                       [t.data_ptr() for t in pk.bias], self.ws.data_ptr(), self.wnb, self.flags, st)
+        if not back_end:
+            return None
+        cw = self.cws[q]
+        _, comp_off, dest_off = lib.dc_compact_layout(B, Tq, F, D)
+        lib.linear_x3p_compact(self.ws.data_ptr() + self.img_off, Tq * B, 2 * pk.Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
+                               cw.data_ptr() + dest_off, Tq * F, F, cw.data_ptr() + comp_off, B, Tq * F * D, False, st)
+        lib.dc_cluster_compact(B, Tq, F, D, self.iters, self.masks.data_ptr(), cw.data_ptr(), self.cnb, st, tol=self.tol)
+        lib.mask_istft(self.ri[q].data_ptr(), self.masks.data_ptr(), Tq * F * 2, 1, F * 2, 2, B, 2, Tq, self.nfft, self.hop, nq,
+                       self.out[p].data_ptr(), st, frames=frames_q.data_ptr(), lengths=lengths_q.data_ptr())
+        return self.out[p][:B * 2 * nq].view(B, 2, nq)
+
+    def _post(self, q, back_end):
+        from .nn._core import _XcdStatus
+        _XcdStatus.post(self.ws)
+        if back_end:
+            _XcdStatus.post_cluster(self.cws[q], self.cstat)
+
+    @torch.no_grad()
+    def push(self, wav, lengths, check=True):
+        """Hand over batch n: ``wav`` (B, n) float32 on the device, row b holding ``lengths[b]`` <= n valid samples (n <= n_cap);
+        returns the separated batch n-1 (B, 2, n_{n-1}) or None."""
+        from .features import _lengths_i32
+        from .nn._core import _XcdStatus
+        if wav.dim() != 2 or wav.shape[0] != self.B or not wav.is_cuda or not self.hop <= wav.shape[1] <= self.n_cap:
+            raise ValueError(f"DCRaggedPipeline.push: expected a ({self.B}, n <= {self.n_cap}) tensor on {self.dev}, got "
+                             f"{tuple(wav.shape)} on {wav.device}")
+        wav = wav.float()
+        if wav.stride(1) != 1:
+            wav = wav.contiguous()
+        B, n = wav.shape
+        lengths = _lengths_i32(lengths, B, n, self.dev, "lengths", lo=max(self.hop, self.nfft // 2 + 1))
+        frames = (1 + lengths // self.hop).to(torch.int32)
+        if check:
+            _XcdStatus.poll()                      # reports of earlier steps that have landed (raises XcdAborted)
+        p = self.count & 1
+        T = 1 + n // self.hop
+        cur = (T, n, frames, lengths)
+        st = torch.cuda.current_stream().cuda_stream
+        self.lib.stft_logmag(wav.data_ptr(), B, n, wav.stride(0), self.nfft, self.hop, 1e-7, self.logmag[p].data_ptr(),
+                             self.ri[p].data_ptr(), st, n_per_utt=lengths.data_ptr())
+        self.lib.dc_index(self.logmag[p].data_ptr(), B, T, self.F, self.D, self.db, self.cws[p].data_ptr(), self.cnb, st,
+                          frames=frames.data_ptr())
+        back_end = self.count > 0
+        out = self._step(p, self.logmag[p].data_ptr(), cur, back_end)
+        self.meta[p] = cur
+        if check:
+            self._post(1 - p, back_end)
+        self.count += 1
+        return out
+
+    @torch.no_grad()
+    def flush(self):
+        """Drain: the separated LAST batch (or None if nothing is in flight); the pipeline is empty afterwards."""
+        from .nn._core import _XcdStatus
+        if self.count == 0:
+            return None
+        p = self.count & 1
+        q = 1 - p
+        # the launch's other half needs SOME batch: the last one's own features again (its layer-0 output is not used)
+        out = self._step(p, self.logmag[q].data_ptr(), self.meta[q], True)
+        self._post(q, True)
+        self.count = 0
+        _XcdStatus.flush()
+        return out
+
+    def reset(self):
+        """Forget the batch in flight (after an aborted step: the exchange header was zeroed by the status poll)."""
+        self.count = 0
+
+
+@torch.no_grad()
+def separate_dc_ragged_stream(model, batches, window_size=256, hop_size=64, db_threshold=40.0):
+    """Generator: ``separate_dc(model, wav, lengths=lengths)`` over an iterable of ragged batches ``(wav (B, n), lengths (B,))`` --
+    B <= 16 whole utterances each, every batch padded to its own longest one -- through ``DCRaggedPipeline``: yields one (B, 2, n)
+    result per batch, in order (a fresh tensor each), bit for bit what ``separate_dc`` returns for it.  The pipeline's buffers are
+    sized for the longest batch seen so far (a longer one drains it and starts a larger one); a batch it cannot take (another B,
+    more than 16 rows, a model or mode ``DCRaggedPipeline`` refuses) goes through ``separate_dc``; a step whose persistent launch
+    gave up a bounded wait is recovered by separating the batches it touched again with ``separate_dc``."""
+    import warnings
+    from .nn._core import XcdAborted, _XcdPolicy, _XcdStatus
+    pipe, held = None, []                      # held: (wav, lengths) whose result has not been yielded yet (at most 2)
+    sep = lambda w, l: separate_dc(model, w, window_size, hop_size, db_threshold, lengths=l)
+
+    def drain():
+        nonlocal held
+        if pipe and held:
+            try:
+                res = pipe.flush().clone()
+                held = []
+                return [res]
+            except XcdAborted as e:
+                _XcdPolicy.recovered += 1
+                warnings.warn(f"onssen_amd: {e}  Re-running the last batch with separate_dc.", RuntimeWarning)
+                pipe.reset()
+        res = [sep(w, l) for w, l in held[-1:]] if pipe else []
+        held = []
+        return res
+
+    for wav, lengths in batches:
+        B, n = wav.shape
+        if pipe is not None and pipe is not False and (B != pipe.B or n > pipe.n_cap):
+            yield from drain()
+            pipe = None
+        if pipe is None:
+            try:
+                pipe = DCRaggedPipeline(model, B, int(n * 1.25) if B <= 16 else n, window_size, hop_size, db_threshold)
+            except RuntimeError:
+                pipe = False
+        if pipe is False:
+            yield sep(wav, lengths)
+            pipe = None
+            continue
+        held.append((wav, lengths))
+        try:
+            out = pipe.push(wav, lengths)
+            if out is not None:
+                res = out.clone()
+                _XcdStatus.flush()             # the step that produced it has completed cleanly (the next one is not enqueued yet)
+                held.pop(0)
+                yield res
+        except XcdAborted as e:
+            _XcdPolicy.recovered += 1
+            warnings.warn(f"onssen_amd: {e}  Re-running the batches of that pipeline step with separate_dc.", RuntimeWarning)
+            pipe.reset()
+            for w, l in held:
+                yield sep(w, l)
+            held = []
+    yield from drain()
+
+
 @torch.no_grad()
 def separate_dc_stream(model, batches, window_size=256, hop_size=64, db_threshold=40.0, graph=True):
     """Generator: ``separate_dc`` over an iterable of equally shaped (B, n) device batches, through ``DCPipeline`` -- yields one

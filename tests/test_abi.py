@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     lib = get_lib()
     for name in declared_symbols():
         assert hasattr(lib.dll, name), name
-    assert lib.dll.onssen_abi_version() == 13
+    assert lib.dll.onssen_abi_version() == 14
     assert lib.lstm_geometry(600, 8) == (600, 2400, 38, 75 * 38 * 2 * 256)
     assert lib.dll.onssen_lstm_geometry(600, 7, None, None, None, None) == -1
     assert b"invalid argument" in lib.dll.onssen_error_string(-1)

@@ -632,6 +632,96 @@ def test_blstm_pipe2_two_layers_pipelined_over_calls(lib, monkeypatch, H, ug, B,
                                     P(ws), ws.nbytes, bad, None)
 
 
+@pytest.mark.parametrize("H,ug,B,scramble", [(8, 4, 3, "0"), (24, 8, 9, "0"), (16, 4, 5, "1")])
+def test_blstm_pipe2_ragged_batches_pipelined_over_calls(lib, monkeypatch, H, ug, B, scramble):
+    """onssen_blstm_pipe2_forward_ragged_f32 (round 6c): the pair launch over a stream of RAGGED batches -- each call brings a batch
+    padded to its OWN longest row (T, frames), the launch's other half still runs the batch before (T_prev, frames_prev); one workspace
+    laid out for T_cap.  Every row at its own frames against the oracle's batch-1 run of that row, zeros behind them; the image bits
+    equal those of onssen_blstm_forward_ragged_f32 on the same batch (stacked tiles in both)."""
+    monkeypatch.setenv("ONSSEN_EMU_FORK", "1")
+    monkeypatch.setenv("ONSSEN_EMU_SCRAMBLE_XCC", scramble)
+    lib.dll.onssen_xcd_spin_limit(40000000)
+    F, L, T_cap = 9, 2, 6
+    sd = make_state_dict("chimera", F, H, L, 4, 2, seed=H + ug, gain=2.0)
+    rng = np.random.default_rng(7)
+    Hp, NP, KQ, we = lib.lstm_geometry(H, ug)
+    _, _, we3 = lib.lstm_geometry_x3(H, ug)
+    wih3, whh3, bias = [], [], []
+    for l in range(L):
+        K = F if l == 0 else 2 * Hp
+        Kp = (F + 3) // 4 * 4 if l == 0 else 2 * Hp
+        a, c, b3 = _shm((2, NP, Kp)), _shm((2, NP)), _shm((2, we3), dtype=np.uint16)
+        scratch = _shm((we,))
+        for d, sfx in enumerate(("", "_reverse")):
+            srcs = []
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                v = sd[f"rnn.{n}_l{l}{sfx}"]
+                sv = _shm(v.shape); sv[...] = v
+                srcs.append(sv)
+            lib.lstm_pack(P(srcs[0]), P(srcs[1]), P(srcs[2]), P(srcs[3]), srcs[0].shape[1], 0 if l == 0 else 1, H, ug,
+                          P(a[d]), P(scratch), P(c[d]), None)
+            lib.lstm_pack_whh_bf16x3(P(srcs[1]), H, ug, P(b3[d]), None)
+        pl = _shm((2 * NP, (K + 31) // 32, 2, 32), dtype=np.uint16)
+        lib.x3_image(P(a), Kp, 0, 1, 2 * NP, K, P(pl), None)
+        wih3.append(pl), whh3.append(b3), bias.append(c)
+    nb = lib.blstm_pipe2_workspace_bytes(B, T_cap, F, H, ug)
+    ws = _shm((nb // 4 + 64,))
+    off, KB = lib.blstm_pipe2_y_image(B, T_cap, F, H, ug)
+    flags = _abi.BLSTM_BF16X3 | _abi.BLSTM_XCD
+    # three batches of different padded lengths (the second is the longest, the third the shortest), every row with its own length
+    Ts = [4, 6, 3]
+    frs = [np.minimum(rng.integers(1, T + 1, B), T).astype(np.int32) for T in Ts]
+    for f, T in zip(frs, Ts):
+        f[rng.integers(0, B)] = T                                     # (a batch is padded to its longest row)
+    xs = [rand(rng, B, T, F) for T in Ts]
+    wih_p, whh_p, bias_p = [P(a) for a in wih3], [P(a) for a in whh3], [P(a) for a in bias]
+    got = []
+    prev = None
+    for n in range(4):
+        k = min(n, 2)
+        T = Ts[k]
+        x = _shm((B, T, F)); x[...] = xs[k]
+        fr = _shm((B,), dtype=np.int32); fr[...] = frs[k]
+        if prev is None:
+            prev = (T, fr)
+        lib.blstm_pipe2_forward_ragged(P(x), T * F, F, B, T_cap, T, P(fr), prev[0], P(prev[1]), F, H, ug, wih_p, whh_p, bias_p,
+                                       P(ws), ws.nbytes, flags, None)
+        status = ws.view(np.uint32)
+        assert status[280] == 0, f"launch aborted (code {status[280]})"
+        Tp = prev[0]
+        img = np.array(ws.view(np.uint16)[off // 2:off // 2 + Tp * B * KB * 64])
+        got.append(_x3_decode(img, Tp * B, 2 * Hp).reshape(Tp, B, 2, Hp))
+        prev = (T, fr)
+    for n in range(3):
+        y, T = got[n + 1], Ts[n]
+        out = np.concatenate([y[:, :, 0, :H], y[:, :, 1, :H]], -1).transpose(1, 0, 2)
+        for b in range(B):
+            m = int(frs[n][b])
+            ref = O.blstm_stack(xs[n][b:b + 1, :m], sd, "rnn.", L)
+            assert np.abs(out[b, :m] - ref[0]).max() < 2e-5, (n, b)
+            assert np.all(out[b, m:] == 0), (n, b)
+        assert np.all(y[:, :, :, H:] == 0)
+    # the sequential ragged form on the same batch: identical bits
+    n = 1
+    T = Ts[n]
+    x2 = _shm((B, T, F)); x2[...] = xs[n]
+    fr2 = _shm((B,), dtype=np.int32); fr2[...] = frs[n]
+    ws2 = _shm((lib.blstm_workspace_bytes(B, T, F, H, L, ug) // 4 + 64,))
+    y2 = _shm((T, B, 2, Hp), fill=np.nan)
+    lib.blstm_forward(P(x2), T * F, F, B, T, F, H, L, ug, wih_p, whh_p, bias_p, P(y2), P(ws2), ws2.nbytes, flags, None, frames=P(fr2))
+    off2, _ = lib.blstm_y_image(B, T, F, H, L, ug)
+    img2 = _x3_decode(np.array(ws2.view(np.uint16)[off2 // 2:off2 // 2 + T * B * KB * 64]), T * B, 2 * Hp).reshape(T, B, 2, Hp)
+    np.testing.assert_array_equal(got[n + 1], img2)
+    # refused: a longer batch than the workspace was laid out for, more than 16 ragged rows, one batch without its frames
+    x = _shm((B, T_cap + 1, F))
+    with pytest.raises(_abi.OnssenError):
+        lib.blstm_pipe2_forward_ragged(P(x), (T_cap + 1) * F, F, B, T_cap, T_cap + 1, P(fr2), T, P(fr2), F, H, ug, wih_p, whh_p, bias_p,
+                                       P(ws), ws.nbytes, flags, None)
+    with pytest.raises(_abi.OnssenError):
+        lib.blstm_pipe2_forward_ragged(P(x2), T * F, F, B, T_cap, T, None, T, P(fr2), F, H, ug, wih_p, whh_p, bias_p, P(ws), ws.nbytes,
+                                       flags, None)
+
+
 @pytest.mark.parametrize("H,B,T,ragged", [(48, 3, 4, False), (40, 17, 3, False), (48, 5, 4, True)])
 def test_blstm_xcd_24_unit_groups(lib, monkeypatch, H, B, T, ragged):
     """Round 4: 24 hidden units per member (640 < H <= 768 on the device: 32 members = every CU of an XCD) -- split-bf16 only,

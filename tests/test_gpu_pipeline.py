@@ -185,3 +185,105 @@ def test_headline_shape_pipeline(dev):
     _core._XcdStatus.post(pipe.ws)
     _core._XcdStatus.flush()
     assert t_pipe < t_seq
+
+
+# ---- round 6c: the pipeline over RAGGED batches of whole utterances (onssen_blstm_pipe2_forward_ragged_f32) -----------------------
+def _ragged_batches(dev, B, ns, seed=300):
+    """One ragged batch per entry of ``ns`` (its padded length): row lengths between half of it and all of it, one row at the full length."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, n in enumerate(ns):
+        lengths = rng.integers(max(n // 2, 192), n + 1, B)
+        lengths[rng.integers(0, B)] = n
+        wav = np.zeros((B, n), np.float32)
+        for b in range(B):
+            wav[b, :lengths[b]] = synth_mixture(seed + 131 * k + b, int(lengths[b]))
+        out.append((torch.from_numpy(wav).to(dev), torch.from_numpy(lengths.astype(np.int32))))
+    return out
+
+
+@pytest.mark.parametrize("H,B,ns", [(32, 5, (64 * 24, 64 * 31 + 17, 64 * 12, 64 * 31 + 17)), (64, 16, (64 * 40, 64 * 22 + 5, 64 * 33, 64 * 9)),
+                                    (600, 16, (64 * 30, 64 * 45 + 63, 64 * 38, 64 * 45))])
+def test_ragged_pipeline_is_bit_identical_to_separate_dc_with_lengths(dev, H, B, ns):
+    """Every batch of the stream -- each padded to its own longest row -- against ``separate_dc(model, wav, lengths=)`` (whose rows are
+    bit for bit their own batch-1 runs, tests/test_gpu_ragged.py): equal bits, zeros behind every row's own length."""
+    from onssen_amd.nn import _core
+    from onssen_amd.separation import DCRaggedPipeline, separate_dc
+    m = _dc(dev, H, seed=H + B)
+    xs = _ragged_batches(dev, B, ns, seed=H)
+    refs = [separate_dc(m, w, lengths=l) for w, l in xs]
+    a0 = _core._XcdPolicy.aborts
+    pipe = DCRaggedPipeline(m, B, max(ns) + 100)
+    outs = []
+    assert pipe.push(*xs[0]) is None
+    for w, l in xs[1:]:
+        outs.append(pipe.push(w, l).clone())
+    outs.append(pipe.flush().clone())
+    _core._XcdStatus.flush()
+    assert _core._XcdPolicy.aborts == a0
+    for k, (o, r) in enumerate(zip(outs, refs)):
+        assert o.shape == r.shape and torch.isfinite(o).all()
+        assert torch.equal(o, r), (k, float((o - r).abs().max()))
+        for b in range(B):
+            assert not o[b, :, int(xs[k][1][b]):].any()
+    # a second stream through the same object, other parities
+    assert pipe.push(*xs[3]) is None
+    assert torch.equal(pipe.push(*xs[1]), refs[3])
+    assert torch.equal(pipe.flush(), refs[1])
+    # one utterance of the stream alone (the reference's batch-1 loop): the same bits inside its length
+    w, l = xs[1]
+    b = 2
+    one = separate_dc(m, w[b:b + 1, :int(l[b])])
+    assert torch.equal(outs[1][b, :, :int(l[b])], one[0])
+
+
+def test_ragged_stream_generator_grows_falls_back_and_recovers(dev):
+    """``separate_dc_ragged_stream``: one result per batch, in order; a longer batch than the buffers drains the pipeline and starts a
+    larger one; a batch of another B or of more than 16 rows goes through ``separate_dc``; with the bounded waits at 0 every persistent
+    launch gives up and every batch is re-run."""
+    from onssen_amd.hip import get_lib
+    from onssen_amd.nn import _core
+    from onssen_amd.separation import separate_dc, separate_dc_ragged_stream
+    m = _dc(dev, 48, seed=9)
+    xs = _ragged_batches(dev, 6, (64 * 20, 64 * 18, 64 * 40, 64 * 41, 64 * 12), seed=11)
+    odd = _ragged_batches(dev, 3, (64 * 15,), seed=12)[0]
+    big = _ragged_batches(dev, 18, (64 * 10,), seed=13)[0]
+    items = xs[:2] + [odd] + xs[2:4] + [big] + xs[4:]
+    refs = [separate_dc(m, w, lengths=l) for w, l in items]
+    got = list(separate_dc_ragged_stream(m, items))
+    assert len(got) == len(refs)
+    for k, (o, r) in enumerate(zip(got, refs)):
+        assert torch.equal(o, r), k
+    lib = get_lib()
+    P = _core._XcdPolicy
+    r0 = P.recovered
+    old = lib.dll.onssen_xcd_spin_limit(0)
+    try:
+        with warnings.catch_warnings(record=True) as wn:
+            warnings.simplefilter("always")
+            got = list(separate_dc_ragged_stream(m, xs))
+    finally:
+        lib.dll.onssen_xcd_spin_limit(old)
+    assert P.recovered > r0 and any("separate_dc" in str(x.message) for x in wn)
+    assert len(got) == len(xs)
+    own = [refs[i] for i in (0, 1, 3, 4, 6)]
+    for g, r in zip(got, own):        # launch-per-step path vs persistent path: a borderline bin may change sides
+        np.testing.assert_allclose(g.cpu().numpy(), r.cpu().numpy(), atol=2e-3)
+    while not P.persistent_allowed():             # consume the back-off the forced aborts left behind
+        separate_dc(m, xs[0][0], lengths=xs[0][1])
+    separate_dc(m, xs[0][0], lengths=xs[0][1])
+    _core._XcdStatus.flush()
+    assert P.persistent_allowed()
+
+
+def test_ragged_pipeline_refuses_what_it_cannot_run(dev):
+    from onssen_amd.separation import DCRaggedPipeline
+    m = _dc(dev, 32)
+    with pytest.raises(RuntimeError):
+        DCRaggedPipeline(m, 17, 64 * 20)
+    pipe = DCRaggedPipeline(m, 4, 64 * 20)
+    w = torch.zeros(4, 64 * 21, device=dev)
+    with pytest.raises(ValueError):
+        pipe.push(w, [64 * 21] * 4)                       # longer than n_cap
+    with pytest.raises(ValueError):
+        pipe.push(w[:, :64 * 10], [64 * 10 + 1] * 4)      # a length past the padded width
