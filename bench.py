@@ -397,6 +397,36 @@ def ragged_leg(dev, K=16, batches=6):
             separate_dc(model, one[0][b:b + 1, :one[2][b]].contiguous())
         torch.cuda.synchronize()
         dt1 = time.perf_counter() - t1
+        # round 6c: the same batches through the ragged pipeline (separation.DCRaggedPipeline: layer 1 of batch n-1 beside layer 0 of
+        # batch n in one persistent launch, stacked 8-row groups) -- same bits per utterance, checked below
+        piped = {}
+        try:
+            from onssen_amd.separation import DCRaggedPipeline
+            pipe = DCRaggedPipeline(model, K, 8 * 8000)
+
+            def through(ss, keep=False):
+                res = []
+                for wav, ln, _ in ss:
+                    o = pipe.push(wav, ln, check=False)
+                    if keep and o is not None:
+                        res.append(o.clone())
+                o = pipe.flush()
+                if keep:
+                    res.append(o.clone())
+                return res
+            for name, ss in (("as_they_come", sets), ("bucketed_by_length", sets_sorted)):
+                through(ss[:2])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                through(ss)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - t0
+                got = through(ss, keep=True)
+                same = all(torch.equal(g, separate_dc(model, wav, lengths=ln)) for g, (wav, ln, _) in zip(got, ss))
+                piped[name] = {"ms_per_utterance": dtp / (K * batches) * 1e3, "x_real_time": sum(sum(ns) for _, _, ns in ss) / 8000.0 / dtp,
+                               "bit_identical_to_separate_dc": bool(same)}
+        except Exception as e:
+            piped = {"error": f"{type(e).__name__}: {e}"[:300]}
     _XcdStatus.poll(wait=True)
     audio = sum(sum(ns) for _, _, ns in sets) / 8000.0
     return {"workload": f"separate_dc on {batches} ragged batches of {K} whole utterances (3-8 s each, padded to the batch's longest), "
@@ -405,7 +435,9 @@ def ragged_leg(dev, K=16, batches=6):
             "one_by_one_ms_per_utterance": dt1 / K * 1e3, "one_by_one_x_real_time": sum(one[2]) / 8000.0 / dt1,
             "padding_overhead": sum(K * max(ns) for _, _, ns in sets) / sum(sum(ns) for _, _, ns in sets),
             "bucketed_by_length": {"ms_per_utterance": dts / (K * batches) * 1e3, "x_real_time": audio / dts,
-                                   "padding_overhead": sum(K * max(ns) for _, _, ns in sets_sorted) / sum(sum(ns) for _, _, ns in sets_sorted)}}
+                                   "padding_overhead": sum(K * max(ns) for _, _, ns in sets_sorted) / sum(sum(ns) for _, _, ns in sets_sorted)},
+            "pipelined": dict(piped, what="separation.DCRaggedPipeline (onssen_blstm_pipe2_forward_ragged_f32): layer 1 of batch n-1 beside layer 0 "
+                                          "of batch n in one persistent launch, stacked 8-row groups; per-batch latency two steps")}
 
 
 def dp_training_leg(dev, rank, world, one_dev, layers=3, B=16, steps=6, warmup=3):

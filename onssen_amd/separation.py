@@ -409,28 +409,35 @@ class DCRaggedPipeline:
     Eager launches (a new longest utterance per batch: nothing to capture); buffers are sized once for ``n_cap`` samples per row.
     Needs what ``DCPipeline`` needs, with B <= 16."""
 
+    @staticmethod
+    def why_not(model, B, window_size=256):
+        """None if this model / batch size / mode can run here, else what is missing (no allocation, no launch)."""
+        from .nn._core import _XcdPolicy, heads_take_image, precision
+        from .nn.deep_clustering import deep_clustering
+        if not isinstance(model, deep_clustering) or model.num_layers != 2:
+            return "a deep_clustering model with num_layers = 2"
+        dev = next(model.parameters()).device
+        D = getattr(model, "embedding_dim", 0)
+        if model.training or dev.type != "cuda":
+            return "an eval-mode model on a ROCm device"
+        if window_size // 2 + 1 != model.input_dim:
+            return f"window_size // 2 + 1 == input_dim ({model.input_dim})"
+        if not 1 <= B <= 16 or model.hidden_dim > 640:
+            return "1 <= B <= 16 (ragged rows run on stacked tiles) and hidden_dim <= 640"
+        if precision() != "bf16x3" or options.get("recurrence") != "1" or not _XcdPolicy.persistent_allowed():
+            return "the default split-bf16 arithmetic on the persistent recurrence"
+        if options.get("dc_cluster") != "1" or options.get("dc_compact") != "1" or D > 32 or not heads_take_image(B, model.hidden_dim, (D,)):
+            return "the compacted device-side clustering (embedding_dim in 4, 8, 16, 20; dc_cluster / dc_compact on)"
+        return None
+
     def __init__(self, model, B, n_cap, window_size=256, hop_size=64, db_threshold=40.0, iters=20, tol=1e-4):
         from . import _abi
         from .hip import get_lib
-        from .nn._core import _XcdPolicy, heads_take_image, precision
-        from .nn.deep_clustering import deep_clustering
         dev = next(model.parameters()).device
         D = getattr(model, "embedding_dim", 0)
         F = window_size // 2 + 1
-        why = None
-        if not isinstance(model, deep_clustering) or model.num_layers != 2:
-            why = "a deep_clustering model with num_layers = 2"
-        elif model.training or dev.type != "cuda":
-            why = "an eval-mode model on a ROCm device"
-        elif F != model.input_dim:
-            why = f"window_size // 2 + 1 == input_dim ({model.input_dim})"
-        elif not 1 <= B <= 16 or model.hidden_dim > 640:
-            why = "1 <= B <= 16 (ragged rows run on stacked tiles) and hidden_dim <= 640"
-        elif precision() != "bf16x3" or options.get("recurrence") != "1" or not _XcdPolicy.persistent_allowed():
-            why = "the default split-bf16 arithmetic on the persistent recurrence"
-        elif options.get("dc_cluster") != "1" or options.get("dc_compact") != "1" or D > 32 or not heads_take_image(B, model.hidden_dim, (D,)):
-            why = "the compacted device-side clustering (embedding_dim in 4, 8, 16, 20; dc_cluster / dc_compact on)"
-        elif n_cap < hop_size:
+        why = self.why_not(model, B, window_size)
+        if why is None and n_cap < hop_size:
             why = "n_cap >= hop_size"
         if why:
             raise RuntimeError(f"DCRaggedPipeline needs {why}; use separate_dc(..., lengths=)")
@@ -459,18 +466,18 @@ class DCRaggedPipeline:
         self.meta = [None, None]     # per parity: (T, n, frames, lengths) of the batch its buffers hold
         self.count = 0
 
-    def _step(self, p, x_ptr, cur, back_end):
-        """The pair launch for the batch ``cur`` = (T, n, frames, lengths) whose features sit at ``x_ptr`` beside the batch of parity
-        1 - p, then (``back_end``) that batch's head GEMM, clustering, masks and iSTFT into ``out[p]``."""
+    def _step(self, p, cur, back_end):
+        """The pair launch for the batch ``cur`` = (T, n, frames, lengths, logmag, ri) beside the batch of parity 1 - p, then
+        (``back_end``) that batch's head GEMM, clustering, masks and iSTFT into ``out[p]``."""
         lib, B, F, D = self.lib, self.B, self.F, self.D
         st = torch.cuda.current_stream().cuda_stream
         pk = self.model._packed.get(self.ug)
         hd = self.model._head.get(pk.Hp)
         q = 1 - p
-        T, n, frames, lengths = cur
-        Tq, nq, frames_q, lengths_q = self.meta[q] if back_end else cur
-        lib.blstm_pipe2_forward_ragged(x_ptr, T * F, F, B, self.T_cap, T, frames.data_ptr(), Tq, frames_q.data_ptr(), F, self.H, self.ug,
-                                       [t.data_ptr() for t in pk.wih_img], [t.data_ptr() for t in pk.whh_x3],
+        T, n, frames, lengths, x, _ = cur
+        Tq, nq, frames_q, lengths_q, _, ri_q = self.meta[q] if back_end else cur
+        lib.blstm_pipe2_forward_ragged(x.data_ptr(), T * F, F, B, self.T_cap, T, frames.data_ptr(), Tq, frames_q.data_ptr(), F, self.H,
+                                       self.ug, [t.data_ptr() for t in pk.wih_img], [t.data_ptr() for t in pk.whh_x3],
                                        [t.data_ptr() for t in pk.bias], self.ws.data_ptr(), self.wnb, self.flags, st)
         if not back_end:
             return None
@@ -479,7 +486,7 @@ class DCRaggedPipeline:
         lib.linear_x3p_compact(self.ws.data_ptr() + self.img_off, Tq * B, 2 * pk.Hp, hd.img.data_ptr(), hd.b.data_ptr(), hd.N, D, 1e-12,
                                cw.data_ptr() + dest_off, Tq * F, F, cw.data_ptr() + comp_off, B, Tq * F * D, False, st)
         lib.dc_cluster_compact(B, Tq, F, D, self.iters, self.masks.data_ptr(), cw.data_ptr(), self.cnb, st, tol=self.tol)
-        lib.mask_istft(self.ri[q].data_ptr(), self.masks.data_ptr(), Tq * F * 2, 1, F * 2, 2, B, 2, Tq, self.nfft, self.hop, nq,
+        lib.mask_istft(ri_q.data_ptr(), self.masks.data_ptr(), Tq * F * 2, 1, F * 2, 2, B, 2, Tq, self.nfft, self.hop, nq,
                        self.out[p].data_ptr(), st, frames=frames_q.data_ptr(), lengths=lengths_q.data_ptr())
         return self.out[p][:B * 2 * nq].view(B, 2, nq)
 
@@ -488,6 +495,20 @@ class DCRaggedPipeline:
         _XcdStatus.post(self.ws)
         if back_end:
             _XcdStatus.post_cluster(self.cws[q], self.cstat)
+
+    def _advance(self, cur, check):
+        """Target map of ``cur`` (the features are in place), the pipeline step, the status posts."""
+        T, n, frames, lengths, x, _ = cur
+        p = self.count & 1
+        self.lib.dc_index(x.data_ptr(), self.B, T, self.F, self.D, self.db, self.cws[p].data_ptr(), self.cnb,
+                          torch.cuda.current_stream().cuda_stream, frames=frames.data_ptr())
+        back_end = self.count > 0
+        out = self._step(p, cur, back_end)
+        self.meta[p] = cur
+        if check:
+            self._post(1 - p, back_end)
+        self.count += 1
+        return out
 
     @torch.no_grad()
     def push(self, wav, lengths, check=True):
@@ -508,19 +529,29 @@ class DCRaggedPipeline:
             _XcdStatus.poll()                      # reports of earlier steps that have landed (raises XcdAborted)
         p = self.count & 1
         T = 1 + n // self.hop
-        cur = (T, n, frames, lengths)
-        st = torch.cuda.current_stream().cuda_stream
         self.lib.stft_logmag(wav.data_ptr(), B, n, wav.stride(0), self.nfft, self.hop, 1e-7, self.logmag[p].data_ptr(),
-                             self.ri[p].data_ptr(), st, n_per_utt=lengths.data_ptr())
-        self.lib.dc_index(self.logmag[p].data_ptr(), B, T, self.F, self.D, self.db, self.cws[p].data_ptr(), self.cnb, st,
-                          frames=frames.data_ptr())
-        back_end = self.count > 0
-        out = self._step(p, self.logmag[p].data_ptr(), cur, back_end)
-        self.meta[p] = cur
+                             self.ri[p].data_ptr(), torch.cuda.current_stream().cuda_stream, n_per_utt=lengths.data_ptr())
+        return self._advance((T, n, frames, lengths, self.logmag[p], self.ri[p]), check)
+
+    @torch.no_grad()
+    def push_features(self, logmag, stft_ri, frames, lengths, n, check=True):
+        """``push`` for a batch whose features come from elsewhere (the evaluation loader's items, onssen/data/wsj0_2mix.py:231-245,
+        collated by ``evaluate.tester.collate``): ``logmag`` (B, T, F) and ``stft_ri`` (B, T, F, 2) float32 on the device, row b owning
+        its first ``frames[b]`` <= T frames and ``lengths[b]`` <= n output samples.  The tensors are used where they are (no copy) and
+        kept until their batch has left the pipeline."""
+        from .features import _lengths_i32
+        from .nn._core import _XcdStatus
+        B, T, F = logmag.shape
+        if (B != self.B or F != self.F or T > self.T_cap or n > self.n_cap or tuple(stft_ri.shape) != (B, T, F, 2) or not logmag.is_cuda
+                or not stft_ri.is_cuda):
+            raise ValueError(f"DCRaggedPipeline.push_features: expected ({self.B}, T <= {self.T_cap}, {self.F}) features and their "
+                             f"(..., 2) spectrum on {self.dev}, n <= {self.n_cap}; got {tuple(logmag.shape)}, {tuple(stft_ri.shape)}, n = {n}")
+        logmag, stft_ri = logmag.float().contiguous(), stft_ri.float().contiguous()
+        frames = _lengths_i32(frames, B, T, self.dev, "frames")
+        lengths = _lengths_i32(lengths, B, n, self.dev, "lengths")
         if check:
-            self._post(1 - p, back_end)
-        self.count += 1
-        return out
+            _XcdStatus.poll()
+        return self._advance((T, int(n), frames, lengths, logmag, stft_ri), check)
 
     @torch.no_grad()
     def flush(self):
@@ -531,7 +562,7 @@ class DCRaggedPipeline:
         p = self.count & 1
         q = 1 - p
         # the launch's other half needs SOME batch: the last one's own features again (its layer-0 output is not used)
-        out = self._step(p, self.logmag[q].data_ptr(), self.meta[q], True)
+        out = self._step(p, self.meta[q], True)
         self._post(q, True)
         self.count = 0
         _XcdStatus.flush()

@@ -151,6 +151,21 @@ def test_eval_batched_equals_the_one_by_one_loop(dev, monkeypatch, kind):
         assert abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one)), (K, got, one_by_one)     # (fp64 sums grouped differently)
     got = t.eval(batch=3, bucket=2)                                # 6 utterances read ahead, sorted by length, two batches of 3
     assert abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
+    if kind == "dc":
+        # round 6c: batch = 2 .. 16 of a two-layer network goes through separation.DCRaggedPipeline (the calls above did); the plain
+        # loop gives the same mean, and so does a stream whose last chunk is smaller (drained, then run by the plain loop or a new pipeline)
+        from onssen_amd.separation import DCRaggedPipeline
+        calls = []
+        real = DCRaggedPipeline.push_features
+        monkeypatch.setattr(DCRaggedPipeline, "push_features", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+        got = t.eval(batch=8)
+        assert len(calls) == -(-len(loader) // 8) and abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
+        calls.clear()
+        got = t.eval(batch=8, pipeline=False)
+        assert not calls and abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
+        got = t.eval(batch=7, bucket=3)
+        assert calls and abs(got - one_by_one) <= 1e-9 * max(1.0, abs(one_by_one))
+        monkeypatch.setattr(DCRaggedPipeline, "push_features", real)
     # every utterance's own SDR, bit for bit
     from onssen_amd.evaluate import batch_SDR_torch
     with torch.no_grad():
