@@ -427,6 +427,32 @@ def ragged_leg(dev, K=16, batches=6):
                                "bit_identical_to_separate_dc": bool(same)}
         except Exception as e:
             piped = {"error": f"{type(e).__name__}: {e}"[:300]}
+        # the honest comparison for the pipeline: the SAME utterances 2K at a time through the plain call (8-row groups fill the chip
+        # there too, at the price of padding 2K rows to their longest and of twice the batch in flight)
+        k2 = {}
+        try:
+            def merged(ss):
+                res = []
+                for i in range(0, len(ss) - 1, 2):
+                    (w0, l0, n0), (w1, l1, n1) = ss[i], ss[i + 1]
+                    n = max(w0.shape[1], w1.shape[1])
+                    w = torch.zeros(2 * K, n, device=dev)
+                    w[:K, :w0.shape[1]] = w0
+                    w[K:, :w1.shape[1]] = w1
+                    res.append((w, torch.cat([l0, l1]), n0 + n1))
+                return res
+            for name, ss in (("as_they_come", merged(sets)), ("bucketed_by_length", merged(sets_sorted))):
+                for wav, ln, _ in ss[:1]:
+                    separate_dc(model, wav, lengths=ln)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for wav, ln, _ in ss:
+                    separate_dc(model, wav, lengths=ln)
+                torch.cuda.synchronize()
+                dtk = time.perf_counter() - t0
+                k2[name] = {"ms_per_utterance": dtk / (K * batches) * 1e3, "x_real_time": sum(sum(ns) for _, _, ns in ss) / 8000.0 / dtk}
+        except Exception as e:
+            k2 = {"error": f"{type(e).__name__}: {e}"[:300]}
     _XcdStatus.poll(wait=True)
     audio = sum(sum(ns) for _, _, ns in sets) / 8000.0
     return {"workload": f"separate_dc on {batches} ragged batches of {K} whole utterances (3-8 s each, padded to the batch's longest), "
@@ -437,7 +463,9 @@ def ragged_leg(dev, K=16, batches=6):
             "bucketed_by_length": {"ms_per_utterance": dts / (K * batches) * 1e3, "x_real_time": audio / dts,
                                    "padding_overhead": sum(K * max(ns) for _, _, ns in sets_sorted) / sum(sum(ns) for _, _, ns in sets_sorted)},
             "pipelined": dict(piped, what="separation.DCRaggedPipeline (onssen_blstm_pipe2_forward_ragged_f32): layer 1 of batch n-1 beside layer 0 "
-                                          "of batch n in one persistent launch, stacked 8-row groups; per-batch latency two steps")}
+                                          "of batch n in one persistent launch, stacked 8-row groups; per-batch latency two steps"),
+            "plain_call_on_2K_rows": dict(k2, what=f"separate_dc on the same utterances {2 * K} at a time (8-row groups fill the chip in the plain "
+                                                   "call too; more padding, twice the rows in flight)")}
 
 
 def dp_training_leg(dev, rank, world, one_dev, layers=3, B=16, steps=6, warmup=3):

@@ -28,14 +28,19 @@ for cfg, cls, tcls in (("config_dc.json", "deep_clustering", tester_dc), ("confi
     t = tcls(args)
     secs = sum(float(lab[2].shape[-1]) / 8000.0 * lab[2].shape[0] for _, lab in args.test_loader)
     n = sum(1 for _ in args.test_loader)
-    for batch in (1, 8, 16, 32):
-        t.eval(batch=batch)                        # warm-up: weight packing, workspaces
+    for batch, kw in ((1, {}), (8, {}), (16, {}), (32, {}), (8, dict(pipeline=False)), (16, dict(pipeline=False)), (16, dict(bucket=4)),
+                      (16, dict(bucket=4, pipeline=False))):
+        if kw.get("pipeline") is False and tcls is not tester_dc:
+            continue                               # (round 6c: tester_dc pipelines batch = 2 .. 16 over consecutive forwards by default)
+        if tcls is not tester_dc:
+            kw = {k: v for k, v in kw.items() if k != "pipeline"}
+        t.eval(batch=batch, **kw)                  # warm-up: weight packing, workspaces
         torch.cuda.synchronize()
         dt = 1e9
         for _ in range(3):                         # best of three: the loop is short, a host hiccup is a large fraction of it
             t0 = time.perf_counter()
-            sdr = t.eval(batch=batch)
+            sdr = t.eval(batch=batch, **kw)
             torch.cuda.synchronize()
             dt = min(dt, time.perf_counter() - t0)
-        print(f"{cls:16s} batch {batch:2d}: {n} utterances, {secs:.1f} s of audio: eval() {dt * 1e3:.1f} ms = {dt / n * 1e3:.3f} ms per utterance = "
+        print(f"{cls:16s} batch {batch:2d} {str(kw):36s}: {n} utterances, {secs:.1f} s of audio: eval() {dt * 1e3:.1f} ms = {dt / n * 1e3:.3f} ms per utterance = "
               f"{secs / dt:.0f} x real time (SI-SDR {sdr:.4f})", flush=True)
