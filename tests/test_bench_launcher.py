@@ -74,10 +74,10 @@ def test_recorded_eight_rank_self_test_line():
 
 
 def test_recorded_bench_line_carries_the_contract():
-    """profiles/r06b_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
+    """profiles/r06c_bench_final.json = `python3 bench.py --gpus 1 --steps 20 --warmup 5` on the GPU box (the driver's command): every
     key the bench contract names, the roofline and CPU-baseline blocks (round 6: BASELINE.md section 3's protocol), the round-5 additions and
     (round 6b) the two-batch pipeline the headline step runs through, with the one-batch-at-a-time step beside it."""
-    r = json.loads(open(os.path.join(ROOT, "profiles", "r06b_bench_final.json")).read().strip().splitlines()[-1])
+    r = json.loads(open(os.path.join(ROOT, "profiles", "r06c_bench_final.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in r, k
     assert r["n_gpus"] == 1 and r["steps"] == 20 and r["warmup"] == 5 and r["higher_is_better"] is True and r["scaling"] == "weak"
@@ -108,11 +108,11 @@ def test_recorded_bench_line_carries_the_contract():
     assert cpu["cores_physical"] >= cpu["threads_used"] == cpu["cores"] >= 1 and cpu["host_threads"] >= cpu["cores_physical"]
     assert cpu["kmeans_n_init"] == 10 and "n_init=10" in cpu["sample"]
     assert set(cpu["whole_path"]) == {"B1", "B1_kmeans_auto", "B32", "B32_kmeans_auto"}
-    assert all(v["passes"] >= 3 and v["ms"] > 0 for v in cpu["whole_path"].values()) and cpu["whole_path"]["B32"]["passes"] == 10
+    assert all(v["passes"] >= 3 and v["ms"] > 0 for v in cpu["whole_path"].values()) and 3 <= cpu["whole_path"]["B32"]["passes"] <= 10      # (time-capped: a slow box gets 9)
     assert abs(cpu["value"] - cpu["whole_path"]["B32"]["x_real_time"]) < 1e-9
     assert cpu["whole_path"]["B32_kmeans_auto"]["ms"] < cpu["whole_path"]["B32"]["ms"]
     net = cpu["network_only"]
-    assert net["B1"]["passes"] == 10 and net["B32"]["passes"] == 10
+    assert 3 <= net["B1"]["passes"] <= 10 and 3 <= net["B32"]["passes"] <= 10
     assert str(cpu["cores_physical"]) in net["B32"]["threads_tried"] and str(net["B32"]["threads"]) in net["B32"]["threads_tried"]
     assert r["lloyd_iterations"]["cap"] == 20 and "second_input_set" in r
     ex = r["extra_configs"]
@@ -121,3 +121,11 @@ def test_recorded_bench_line_carries_the_contract():
     assert tp["si_sdr_db_separated_mean"] > 8.0 and tp["ms_per_step"] < ex["trained_weights_dc_l2_b32"]["ms_per_step"]
     assert [row["chunks"] for row in ex["batch_sweep"]["dc_l2"]["rows"]] == [8, 16, 32, 64, 128, 256]
     assert ex["cfg4_training_step_dc_l3_b16"]["ms_per_step"] < 7.5
+    # round 6c: the pair launch's PMC traffic in the line (per launch, like `achieved`), and the ragged pipeline beside the plain ragged call
+    assert 0.9 < roof["traffic"] / 639078400 < 1.2 and "PMC" in roof["traffic_source"]
+    rg = ex["b16_ragged_utterances"]
+    for order in ("as_they_come", "bucketed_by_length"):
+        assert rg["pipelined"][order]["bit_identical_to_separate_dc"] is True
+        assert rg["plain_call_on_2K_rows"][order]["x_real_time"] > 0
+    assert rg["pipelined"]["as_they_come"]["x_real_time"] > rg["x_real_time"]
+    assert rg["pipelined"]["bucketed_by_length"]["x_real_time"] > rg["bucketed_by_length"]["x_real_time"]
