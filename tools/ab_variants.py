@@ -42,7 +42,9 @@ def run(names, cmd):
                 try:
                     r = json.loads(out[-1])
                     extra = r.get("roofline", {}).get("us_per_time_step")
-                    print(f"{name:16s} ms_per_step {r['ms_per_step']:.4f}" + (f"  recurrence us/step {extra:.3f}" if extra else ""), flush=True)
+                    gem = (r.get("roofline", {}).get("other_kernels") or {}).get("ms_by_call") or {}
+                    print(f"{name:16s} ms_per_step {r['ms_per_step']:.4f}" + (f"  recurrence us/step {extra:.3f}" if extra else "")
+                          + ("  gemm ms " + " ".join(f"{k}={v:.4f}" for k, v in gem.items() if v) if gem else ""), flush=True)
                 except Exception:
                     print(f"{name:16s} FAILED: {out[-3:]}", flush=True)
     finally:
