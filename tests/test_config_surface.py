@@ -180,3 +180,18 @@ def test_cpu_tensors_raise_without_the_scaffolding_switch(monkeypatch):
             m.eval()([x])
     monkeypatch.setenv("ONSSEN_CPU_AUTOGRAD", "1")
     assert m.train()([x])[0].shape == (2, 5, 129, 20)
+
+
+def test_pipelines_refuse_a_cpu_model_loudly():
+    """The stream pipelines (separation.DCPipeline / DCRaggedPipeline) exist on the device only: a CPU model raises before anything is
+    allocated, and says what to use instead; tester_dc.eval checks the same predicate before it routes batches through the pipeline."""
+    import pytest
+    from onssen_amd import nn as onn
+    from onssen_amd.separation import DCPipeline, DCRaggedPipeline
+    m2 = onn.deep_clustering(129, 8, 2, 20).eval()
+    assert "ROCm device" in DCRaggedPipeline.why_not(m2, 4)
+    assert "num_layers = 2" in DCRaggedPipeline.why_not(onn.deep_clustering(129, 8, 3, 20).eval(), 4)
+    with pytest.raises(RuntimeError, match="separate_dc"):
+        DCRaggedPipeline(m2, 4, 64 * 20)
+    with pytest.raises(RuntimeError, match="separate_dc"):
+        DCPipeline(m2, 4, 64 * 20)
