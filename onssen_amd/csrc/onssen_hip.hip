@@ -93,6 +93,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define ONSSEN_KNOB_INT(name, dflt) (dflt)
 #endif
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+#ifndef ONSSEN_X3R_DEFAULT
+#define ONSSEN_X3R_DEFAULT 0     // onssen_linear_x3p, bias mode: 1 = the 32x32x16-MFMA kernel (linear_x3r_kernel) unless ONSSEN_X3R=0 says otherwise
+#endif
 
 // ---- device code, one translation unit (the host-side emulation compiles exactly this file too)
 #include "pack.inc"
@@ -630,7 +633,21 @@ static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* 
   do {                                                       \
     if (bf16_only) ONSSEN_XQ2(MODE_, 1); else ONSSEN_XQ2(MODE_, 3); \
   } while (0)
-    if (mode == ONSSEN_EPI_BIAS) ONSSEN_XQ(ONSSEN_EPI_BIAS);
+    // the bias mode (the projections): v_mfma_f32_32x32x16_bf16 tiles (linear_x3r_kernel, round 6c) unless ONSSEN_X3R=0 -- every tile
+    // shape, so that a row's bits do not depend on the shape its batch selects
+    const char* env_r = getenv("ONSSEN_X3R");
+    const bool use_r = mode == ONSSEN_EPI_BIAS && (env_r ? atoi(env_r) != 0 : ONSSEN_X3R_DEFAULT != 0);
+    if (use_r) {
+#define ONSSEN_XR(T_)                                                                                                 \
+  do {                                                                                                                \
+    if (bm == 256 && bn == 320) hipLaunchKernelGGL((linear_x3r_kernel<T_, 320, 256>), gridq, dim3(512), 0, st, p);    \
+    else if (bm == 256) hipLaunchKernelGGL((linear_x3r_kernel<T_, 256, 256>), gridq, dim3(512), 0, st, p);            \
+    else if (bn == 320) hipLaunchKernelGGL((linear_x3r_kernel<T_, 320, 128>), gridq, dim3(512), 0, st, p);            \
+    else hipLaunchKernelGGL((linear_x3r_kernel<T_, 256, 128>), gridq, dim3(512), 0, st, p);                           \
+  } while (0)
+      if (bf16_only) ONSSEN_XR(1); else ONSSEN_XR(3);
+#undef ONSSEN_XR
+    } else if (mode == ONSSEN_EPI_BIAS) ONSSEN_XQ(ONSSEN_EPI_BIAS);
     else if (mode == ONSSEN_EPI_L2NORM) {
       if (bm == 256) { if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 1, false, 320, 256>), gridq, dim3(512), 0, st, p);
                        else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_L2NORM, 3, false, 320, 256>), gridq, dim3(512), 0, st, p); }

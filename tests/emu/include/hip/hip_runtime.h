@@ -281,6 +281,27 @@ static inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu
   emu::wave_sync();
   return c;
 }
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i=l&31][k=8*(l>>5)+j] and B[k=8*(l>>5)+j][col=l&31], j=0..7; the 16 accumulators of a
+// lane are column l&31, rows (reg&3) + 8*(reg>>2) + 4*(l>>5)
+typedef float emu_f32x16 __attribute__((vector_size(64)));
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c, int, int, int) {
+  struct Buf { short a[64][8]; short b[64][8]; };
+  static Buf bufs[16];
+  Buf& w = bufs[emu::wave];
+  for (int j = 0; j < 8; ++j) { w.a[emu::lane][j] = a[j]; w.b[emu::lane][j] = b[j]; }
+  emu::wave_sync();
+  const int col = emu::lane & 31, half = emu::lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    float acc = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int j = 0; j < 8; ++j)
+        acc = fmaf(emu_bf16_to_f32(w.a[row + 32 * g][j]), emu_bf16_to_f32(w.b[col + 32 * g][j]), acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
 

@@ -285,6 +285,38 @@ def test_linear_x3_images(lib, mode, group, K, tile, monkeypatch):
     np.testing.assert_allclose(out, ref, atol=3e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tile,K,bf16", [("320", 70, False), ("256", 37, False), ("320/128", 33, False), ("256/128", 96, False), ("320", 40, True)])
+def test_linear_x3_images_bias_mode_on_32x32_tiles(lib, tile, K, bf16, monkeypatch):
+    """linear_x3r_kernel (round 6c): onssen_linear_x3p's bias mode on v_mfma_f32_32x32x16_bf16 tiles (ONSSEN_X3R=1), all four tile
+    shapes, both term counts: ragged M / N / K, strided C rows, against fp64 and -- to the last-bit budget of a re-ordered fp32 sum --
+    against the 16 x 16 kernel."""
+    monkeypatch.setenv("ONSSEN_X3Q", tile.split("/")[0])
+    monkeypatch.setenv("ONSSEN_X3Q_BM", tile.split("/")[1] if "/" in tile else "256")
+    rng = np.random.default_rng(18)
+    Bb, Tt, N = 3, 91, 440
+    x, W, bias = rand(rng, Bb, Tt, K), rand(rng, N, K), rand(rng, N)
+    KB, M = (K + 31) // 32, Bb * Tt
+    a_img = np.full((M, KB, 2, 32), 0x7fc0, np.uint16)
+    w_img = np.full((N, KB, 2, 32), 0x7fc0, np.uint16)
+    lib.x3_image(P(x), K, Tt * K, Bb, M, K, P(a_img), None)
+    lib.x3_image(P(W), K, 0, 1, N, K, P(w_img), None)
+    mode = _abi.EPI_BIAS | (_abi.EPI_BF16 if bf16 else 0)
+    outs = {}
+    for r in ("1", "0"):
+        monkeypatch.setenv("ONSSEN_X3R", r)
+        out = np.full((Bb, Tt, N + 4), np.nan, np.float32)               # (C rows 4 floats apart from dense: strides, not a contiguous block)
+        lib.linear_x3p(P(a_img), M, K, P(w_img), P(bias), N, mode, 0, 1e-12, P(out), Bb, N + 4, Tt * (N + 4), None)
+        assert not np.isnan(out[:, :, :N]).any() and np.isnan(out[:, :, N:]).all()
+        outs[r] = out[:, :, :N]
+    ref = x.astype(np.float64) @ W.T.astype(np.float64) + bias
+    if bf16:
+        xr, Wr = O.bf16_round(x), O.bf16_round(W)
+        np.testing.assert_allclose(outs["1"], xr.astype(np.float64) @ Wr.T.astype(np.float64) + bias, atol=2e-5, rtol=1e-5)
+    else:
+        np.testing.assert_allclose(outs["1"], ref, atol=3e-4, rtol=1e-4)
+    np.testing.assert_allclose(outs["1"], outs["0"], atol=2e-5, rtol=2e-6)
+
+
 @pytest.mark.parametrize("group,N,tile", [(2, 514, "256"), (2, 38, "128"), (20, 440, "256")])
 def test_linear_x3_images_with_residual(lib, group, N, tile, monkeypatch):
     """onssen_linear_x3p_resid: phase_net's head epilogue (onssen/nn/phase_network.py:58-66) on the pre-split-operand GEMM --
