@@ -93,6 +93,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define ONSSEN_KNOB_INT(name, dflt) (dflt)
 #endif
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+#ifndef ONSSEN_X3Q_SMALL_DEFAULT
+#define ONSSEN_X3Q_SMALL_DEFAULT 0   // onssen_linear_x3p, bias mode: KB (32-k blocks) up to which 128 x 128 tiles run (0 = never); ONSSEN_X3Q_SMALL overrides
+#endif
 #ifndef ONSSEN_X3R_DEFAULT
 #define ONSSEN_X3R_DEFAULT 0     // onssen_linear_x3p, bias mode: 1 = the 32x32x16-MFMA kernel (linear_x3r_kernel) unless ONSSEN_X3R=0 says otherwise
 #endif
@@ -637,7 +640,15 @@ static int linear_x3p_impl(const uint16_t* a_img, int M, int K, const uint16_t* 
     // shape, so that a row's bits do not depend on the shape its batch selects
     const char* env_r = getenv("ONSSEN_X3R");
     const bool use_r = mode == ONSSEN_EPI_BIAS && (env_r ? atoi(env_r) != 0 : ONSSEN_X3R_DEFAULT != 0);
-    if (use_r) {
+    // short K (the first layer's projection: 5 k-steps, then 245 MB of C): 128 x 128 tiles, 64 KB of LDS -- two workgroups per CU, one's
+    // stores under the other's k-loop (round 6c experiment, ONSSEN_X3Q_SMALL = the largest KB that takes it; same bits as every x3q tile)
+    const char* env_s = getenv("ONSSEN_X3Q_SMALL");
+    const int small_kb = env_s ? atoi(env_s) : ONSSEN_X3Q_SMALL_DEFAULT;
+    if (mode == ONSSEN_EPI_BIAS && !use_r && KB <= small_kb) {
+      const dim3 grids((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128));
+      if (bf16_only) hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_BIAS, 1, false, 128, 128>), grids, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((linear_x3q_kernel<ONSSEN_EPI_BIAS, 3, false, 128, 128>), grids, dim3(512), 0, st, p);
+    } else if (use_r) {
 #define ONSSEN_XR(T_)                                                                                                 \
   do {                                                                                                                \
     if (bm == 256 && bn == 320) hipLaunchKernelGGL((linear_x3r_kernel<T_, 320, 256>), gridq, dim3(512), 0, st, p);    \
